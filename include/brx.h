@@ -1,0 +1,228 @@
+/*
+ * include/brx.h -- C-ABI of libbrx_hip.so, the MI355X-native replacement for Badread's per-read
+ * hot path (badread/simulate.py:63-86 -> build_fragment :91, sequence_fragment :256,
+ * qscore_model.get_qscores qscore_model.py:32, and the edlib.align calls they make).
+ *
+ * Badread has no plugin/FFI interface of its own (it is pure Python; its one native dependency is
+ * the `edlib` wheel).  This header therefore declares the boundary a maintainer would bind with
+ * ctypes from badread/simulate.py -- see INTEGRATION.md for the stub.  Rules:
+ *   - plain C, plain pointers and sizes, no torch / HIP types in any signature;
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller (the Python host holds them
+ *     as PyTorch-ROCm tensors); the library never frees caller memory and never allocates output;
+ *   - scratch is one caller-provided device arena; if it is too small a call fails with
+ *     BRX_E_SCRATCH and brx_scratch_needed() tells how much the same call wants;
+ *   - no exceptions cross the ABI: int status + brx_last_error();
+ *   - a context belongs to one device and one host thread; work is enqueued on the caller's
+ *     HIP stream (pass torch.cuda.current_stream().cuda_stream, or NULL for the default stream).
+ *
+ * The same descriptor structs (with HOST pointers) parameterise the CPU oracle under oracle/,
+ * which is test infrastructure only.
+ */
+#ifndef BRX_H
+#define BRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes */
+enum {
+    BRX_OK = 0,
+    BRX_E_ARG = -1,        /* bad argument                                                    */
+    BRX_E_HIP = -2,        /* a HIP runtime call failed (message in brx_last_error)            */
+    BRX_E_SCRATCH = -3,    /* scratch arena too small; see brx_scratch_needed()                */
+    BRX_E_OUTPUT = -4,     /* output buffer too small; see brx_output_needed()                 */
+    BRX_E_NOFRAG = -5,     /* a read failed 1000 times to draw a fragment (simulate.py:159-165) */
+    BRX_E_STATE = -6,      /* reference / models / params not set                             */
+    BRX_E_INTERNAL = -7    /* a kernel flagged an internal inconsistency                      */
+};
+
+/* per-read status bits written to brx_read_stats.status */
+enum {
+    BRX_RS_NOFRAG = 1u,       /* get_fragment gave up after 1000 tries                        */
+    BRX_RS_TOO_MANY_SEGS = 2u,/* more chimera pieces than the planner's fixed limit           */
+    BRX_RS_BAND = 4u,         /* alignment score exceeded its proven upper bound (bug)        */
+    BRX_RS_QMISS = 8u,        /* qscore fallback reached a 1-op cigar absent from the model   */
+    BRX_RS_EMPTY = 16u        /* read trimmed to zero length: skipped, like simulate.py:70-71  */
+};
+
+/* base codes: 0..3 = A,C,G,T; 4 = N; 5..15 = other symbols of this reference (sym[] gives ASCII) */
+#define BRX_CODE_N 4
+
+/* ------------------------------------------------------------------ reference (misc.py:122-153) */
+typedef struct {
+    uint64_t base_off;     /* index of the contig's first base in the packed array             */
+    uint32_t length;       /* bases                                                            */
+    uint32_t flags;        /* bit0 circular, bit1 hairpin_left, bit2 hairpin_right             */
+    uint32_t name_off;     /* into names[]                                                     */
+    uint32_t name_len;
+} brx_contig;
+
+typedef struct {           /* run of non-ACGT bases: packed coordinates [start,end) hold `code` */
+    uint64_t start, end;
+    uint32_t code;
+    uint32_t pad_;
+} brx_exception;
+
+typedef struct {
+    const uint32_t *d_packed;        /* 2-bit bases, 16 per word, base g at bits 2*(g%16) of word g/16 */
+    uint64_t n_bases;
+    const brx_contig *d_contigs;     /* [n_contigs]                                              */
+    uint32_t n_contigs;
+    const brx_exception *d_exceptions; /* sorted by start, non-overlapping                        */
+    uint32_t n_exceptions;
+    const uint8_t *d_names;          /* concatenated contig names (ASCII)                        */
+    uint32_t names_len;
+    uint8_t sym[16];                 /* code -> ASCII                                            */
+    uint8_t comp[16];                /* code -> complement code (misc.py:56-67)                  */
+    const double *d_cum_weight;      /* [n_contigs] running sum of depth*length (simulate.py:118-121) */
+    double total_weight;
+} brx_reference;
+
+/* ------------------------------------------------------------------ error model (error_model.py:86-229)
+ * Flattened by the host from the `kmer,p;alt,p;...` file after align_kmers():
+ *   row r = 2-bit value of the k-mer (first base most significant); alts of row r are
+ *   [row_off[r], row_off[r+1]); an absent row (error_model.py:143) has an empty range.
+ *   thr[a]   cumulative probability of alts row_off[r]..a as a 32-bit fixed-point threshold:
+ *            alt a is chosen iff it is the first with draw < thr[a]; if none is and the row's last
+ *            thr is 0xFFFFFFFF the last alt is chosen (rows with sum p >= 1), otherwise the
+ *            remainder goes to add_one_random_change (error_model.py:151-158).
+ *   desc[a]  offset o into pool: pool[o], pool[o+1] = bitmask of positions whose string differs
+ *            from the k-mer base; pool[o+2 .. o+2+k) = per-position string lengths;
+ *            then the alt's characters (base codes), in order.
+ *   self_thr[r] = thr of alt 0 (the unchanged k-mer), 0 for an absent row: one compare rejects
+ *            the ~93 % of draws that leave the k-mer unchanged (simulate.py:300).
+ * pool[0..528) is a fixed preamble used for add_one_random_change results:
+ *   pool[c] = c for c<16 (single chars), pool[16 + 2*(16x+y)] = x,y (all two-char strings).     */
+#define BRX_POOL_PREAMBLE 528
+typedef struct {
+    int32_t k;                  /* k-mer size; 1 for the 'random' model                          */
+    int32_t type;               /* 0 = 'random' (no table), 1 = table                            */
+    uint32_t n_rows;            /* 4^k                                                           */
+    uint32_t n_alts;
+    uint32_t pool_len;
+    uint32_t pad_;
+    const uint32_t *d_row_off;  /* [n_rows+1]                                                    */
+    const uint32_t *d_self_thr; /* [n_rows]                                                      */
+    const uint32_t *d_thr;      /* [n_alts]                                                      */
+    const uint32_t *d_desc;     /* [n_alts]                                                      */
+    const uint8_t *d_pool;      /* [pool_len]                                                    */
+} brx_error_model;
+
+/* ------------------------------------------------------------------ qscore model (qscore_model.py:178-287)
+ * A cigar window of w non-D ops (w odd) is keyed as
+ *   key = (w << 56) | sum_i op_i << (bits*i)   with op codes 0 '=',1 'X',2 'I' in 2 bits and the
+ *   D-run length between op i and op i+1 in `gap_bits` bits placed after op i
+ * (see brx_qs_key in badread_amd/csrc).  A run longer than the field holds is encoded as all-ones,
+ * which no table row uses, so it misses and falls back exactly like the reference's string lookup
+ * (qscore_model.py:278-286).  Open-addressing hash: slot = hash(key) & (hash_size-1), linear probe,
+ * empty slot = key ~0.                                                                           */
+typedef struct {
+    int32_t k;                  /* kmer_size: largest non-D window length in the model (odd)      */
+    int32_t gap_bits;           /* 3 or 4                                                        */
+    uint32_t hash_size;         /* power of two                                                  */
+    uint32_t n_rows;
+    uint32_t n_entries;
+    uint32_t pad_;
+    const uint64_t *d_hash_key; /* [hash_size]                                                   */
+    const uint32_t *d_hash_row; /* [hash_size]                                                   */
+    const uint32_t *d_row_off;  /* [n_rows+1] into thr/score                                     */
+    const uint32_t *d_thr;      /* [n_entries] cumulative 32-bit thresholds; first draw < thr wins, else last */
+    const uint8_t *d_score;     /* [n_entries] phred score                                       */
+} brx_qscore_model;
+
+/* ------------------------------------------------------------------ simulation parameters
+ * The derived fields argparse validation leaves on `args` (badread/__main__.py:239-313).         */
+typedef struct {
+    /* fragment lengths, fragment_lengths.py:47-64 */
+    double frag_mean, frag_stdev, gamma_k, gamma_t;
+    /* identities, identities.py:76-103.  mode 0: constant id_max; 1: id_max*beta(id_a,id_b);
+       2: 1-10^(-normal(id_a,id_b)/10) */
+    int32_t identity_mode;
+    int32_t pad0_;
+    double id_a, id_b, id_max;
+    /* adapters, simulate.py:361-387: rates/amounts as fractions */
+    double start_rate, start_amount, end_rate, end_amount;
+    const uint8_t *d_start_adapter;   /* base codes */
+    const uint8_t *d_end_adapter;
+    uint32_t start_adapter_len, end_adapter_len;
+    /* problems: fractions (simulate.py:101,172-173) */
+    double junk_rate, random_rate, chimera_rate;
+    /* glitches (simulate.py:459-482) */
+    double glitch_rate, glitch_size, glitch_skip;
+} brx_sim_params;
+
+/* ------------------------------------------------------------------ per-read results */
+typedef struct {
+    uint32_t status;           /* BRX_RS_* bits                                                 */
+    uint32_t frag_len;         /* error-free_length: len(fragment) before padding (simulate.py:74) */
+    uint32_t seq_len;          /* length= : trimmed read length                                 */
+    uint32_t n_cols;           /* columns of the final alignment (pads included)                */
+    uint32_t n_match;          /* '=' columns: read_identity = n_match / n_cols (misc.py:228-240) */
+    uint32_t edit_distance;
+    uint32_t loop_count;       /* k-mer draws consumed by the mutate loop                       */
+    uint32_t change_count;     /* positions changed                                             */
+    uint32_t n_alignments;     /* in-loop identity alignments (simulate.py:325-346)             */
+    uint32_t rec_len;          /* bytes of this read's FASTQ record (0 if skipped)              */
+    uint64_t rec_off;          /* offset of the record in the output buffer                     */
+    double target_identity;
+    double qerr_sum;           /* sum over read bases of 10^(-q/10) (qscore_model.py:71-73)     */
+} brx_read_stats;
+
+typedef struct brx_ctx brx_ctx;
+
+/* ------------------------------------------------------------------ entry points */
+int brx_create(int device_id, brx_ctx **out);
+void brx_destroy(brx_ctx *ctx);
+const char *brx_last_error(const brx_ctx *ctx);
+const char *brx_version(void);
+
+int brx_set_reference(brx_ctx *ctx, const brx_reference *ref);
+int brx_set_error_model(brx_ctx *ctx, const brx_error_model *em);
+int brx_set_qscore_model(brx_ctx *ctx, const brx_qscore_model *qm);
+int brx_set_params(brx_ctx *ctx, const brx_sim_params *p);
+int brx_set_scratch(brx_ctx *ctx, void *d_scratch, size_t bytes);
+size_t brx_scratch_needed(const brx_ctx *ctx);
+size_t brx_output_needed(const brx_ctx *ctx);
+
+/* replaces the body of the `while total_size < target_size` loop (simulate.py:63-86) for reads
+ * [first_read, first_read+n_reads): FASTQ records are written back-to-back in read order into
+ * d_out; d_stats[i] describes read first_read+i.  *out_bytes receives the bytes written.
+ * Synchronous with respect to the host on return (small size read-backs happen inside).         */
+int brx_simulate_batch(brx_ctx *ctx, uint64_t seed, uint64_t first_read, uint32_t n_reads,
+                       uint8_t *d_out, size_t out_cap, brx_read_stats *d_stats,
+                       size_t *out_bytes, void *hip_stream);
+
+/* replaces badread.simulate.sequence_fragment (simulate.py:256-358) for caller-supplied fragments:
+ * fragment i is d_frags[frag_off[i] .. frag_off[i+1]) as base codes, with target identity
+ * d_target[i]; read index first_read+i keys the random streams.  Output per fragment i:
+ * sequence codes then phred+33 bytes, each seq_len long, at d_out + stats[i].rec_off.           */
+int brx_sequence_fragments(brx_ctx *ctx, uint64_t seed, uint64_t first_read, uint32_t n_frags,
+                           const uint8_t *d_frags, const uint64_t *d_frag_off,
+                           const double *d_target, uint8_t *d_out, size_t out_cap,
+                           brx_read_stats *d_stats, size_t *out_bytes, void *hip_stream);
+
+/* replaces edlib.align(query, target, task='path') (simulate.py:330,340; qscore_model.py:37;
+ * error_model.py:202) for a batch: pair i aligns query d_seqs[q_off[i]..q_off[i+1]) against target
+ * d_seqs[t_off[i]..t_off[i+1]) (any byte alphabet).  k_hint[i] >= 0 is a proven upper bound on the
+ * distance (no band search), -1 = unknown (band doubling from 64).  Writes the edit distance to
+ * d_dist[i], the number of alignment columns to d_ncols[i] and, if d_ops != NULL, the per-column
+ * ops (0 '=',1 'X',2 'I',3 'D', forward order) at d_ops + ops_off[i] (capacity qlen+tlen).        */
+int brx_align_batch(brx_ctx *ctx, uint32_t n_pairs, const uint8_t *d_seqs,
+                    const uint64_t *d_q_off, const uint64_t *d_t_off, const int32_t *d_k_hint,
+                    int32_t *d_dist, uint32_t *d_ncols, uint32_t *d_nmatch,
+                    uint8_t *d_ops, const uint64_t *d_ops_off, void *hip_stream);
+
+/* time (ms) the device spent in each pipeline stage during the last brx_simulate_batch call,
+ * measured with HIP events on the launch stream: index = BRX_STAGE_* */
+enum { BRX_STAGE_PLAN = 0, BRX_STAGE_BUILD = 1, BRX_STAGE_MUTATE = 2, BRX_STAGE_ALIGN = 3,
+       BRX_STAGE_QSCORE = 4, BRX_STAGE_EMIT = 5, BRX_STAGE_COUNT = 6 };
+int brx_last_stage_ms(const brx_ctx *ctx, float ms[BRX_STAGE_COUNT]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRX_H */
