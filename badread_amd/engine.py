@@ -1,0 +1,441 @@
+"""
+ctypes binding of libbrx_hip.so (C-ABI: include/brx.h) and the host-side driver of the HIP path.
+
+This is the ONLY compute backend of the product.  There is no CPU fallback: importing the engine
+without the built library, or constructing it without a ROCm device, raises immediately.  Device
+buffers are PyTorch-ROCm tensors (memory + streams only); every kernel is hand-written HIP in
+badread_amd/csrc/.
+
+`EngineBase` also defines the small interface (`simulate_batch`, `sequence_fragments`,
+`align_batch`) that the tests' oracle-backed checker implements, so the host logic (sharding,
+stop rule, ordering) can be exercised on CPU under gloo without touching the product path.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.realpath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libbrx_hip.so')
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+class BrxContig(ctypes.Structure):
+    _fields_ = [('base_off', ctypes.c_uint64), ('length', ctypes.c_uint32), ('flags', ctypes.c_uint32),
+                ('name_off', ctypes.c_uint32), ('name_len', ctypes.c_uint32)]
+
+
+class BrxException(ctypes.Structure):
+    _fields_ = [('start', ctypes.c_uint64), ('end', ctypes.c_uint64), ('code', ctypes.c_uint32),
+                ('pad_', ctypes.c_uint32)]
+
+
+class BrxReference(ctypes.Structure):
+    _fields_ = [('d_packed', ctypes.c_void_p), ('n_bases', ctypes.c_uint64),
+                ('d_contigs', ctypes.c_void_p), ('n_contigs', ctypes.c_uint32),
+                ('d_exceptions', ctypes.c_void_p), ('n_exceptions', ctypes.c_uint32),
+                ('d_names', ctypes.c_void_p), ('names_len', ctypes.c_uint32),
+                ('sym', ctypes.c_uint8 * 16), ('comp', ctypes.c_uint8 * 16),
+                ('d_cum_weight', ctypes.c_void_p), ('total_weight', ctypes.c_double)]
+
+
+class BrxErrorModel(ctypes.Structure):
+    _fields_ = [('k', ctypes.c_int32), ('type', ctypes.c_int32), ('n_rows', ctypes.c_uint32),
+                ('n_alts', ctypes.c_uint32), ('pool_len', ctypes.c_uint32), ('pad_', ctypes.c_uint32),
+                ('d_row_off', ctypes.c_void_p), ('d_self_thr', ctypes.c_void_p), ('d_thr', ctypes.c_void_p),
+                ('d_desc', ctypes.c_void_p), ('d_pool', ctypes.c_void_p)]
+
+
+class BrxQScoreModel(ctypes.Structure):
+    _fields_ = [('k', ctypes.c_int32), ('gap_bits', ctypes.c_int32), ('hash_size', ctypes.c_uint32),
+                ('n_rows', ctypes.c_uint32), ('n_entries', ctypes.c_uint32), ('pad_', ctypes.c_uint32),
+                ('d_hash_key', ctypes.c_void_p), ('d_hash_row', ctypes.c_void_p), ('d_row_off', ctypes.c_void_p),
+                ('d_thr', ctypes.c_void_p), ('d_score', ctypes.c_void_p)]
+
+
+class BrxSimParams(ctypes.Structure):
+    _fields_ = [('frag_mean', ctypes.c_double), ('frag_stdev', ctypes.c_double),
+                ('gamma_k', ctypes.c_double), ('gamma_t', ctypes.c_double),
+                ('identity_mode', ctypes.c_int32), ('pad0_', ctypes.c_int32),
+                ('id_a', ctypes.c_double), ('id_b', ctypes.c_double), ('id_max', ctypes.c_double),
+                ('start_rate', ctypes.c_double), ('start_amount', ctypes.c_double),
+                ('end_rate', ctypes.c_double), ('end_amount', ctypes.c_double),
+                ('d_start_adapter', ctypes.c_void_p), ('d_end_adapter', ctypes.c_void_p),
+                ('start_adapter_len', ctypes.c_uint32), ('end_adapter_len', ctypes.c_uint32),
+                ('junk_rate', ctypes.c_double), ('random_rate', ctypes.c_double), ('chimera_rate', ctypes.c_double),
+                ('glitch_rate', ctypes.c_double), ('glitch_size', ctypes.c_double), ('glitch_skip', ctypes.c_double)]
+
+
+READ_STATS_DTYPE = np.dtype([('status', '<u4'), ('frag_len', '<u4'), ('seq_len', '<u4'), ('n_cols', '<u4'),
+                             ('n_match', '<u4'), ('edit_distance', '<u4'), ('loop_count', '<u4'),
+                             ('change_count', '<u4'), ('n_alignments', '<u4'), ('rec_len', '<u4'),
+                             ('rec_off', '<u8'), ('target_identity', '<f8'), ('qerr_sum', '<f8')])
+assert READ_STATS_DTYPE.itemsize == 64
+
+RS_NOFRAG, RS_TOO_MANY_SEGS, RS_BAND, RS_QMISS, RS_EMPTY = 1, 2, 4, 8, 16
+E_SCRATCH, E_OUTPUT, E_NOFRAG = -3, -4, -5
+STAGE_NAMES = ('plan', 'build', 'mutate', 'align', 'qscore', 'emit')
+
+
+class SimParams(object):
+    """Plain-Python mirror of brx_sim_params; adapters are ACGT strings."""
+
+    def __init__(self, frag_mean=15000.0, frag_stdev=13000.0, identity_mode=1, id_a=57.3838, id_b=2.41616,
+                 id_max=0.99, start_rate=0.9, start_amount=0.6, end_rate=0.5, end_amount=0.2,
+                 start_adapter='AATGTACTTCGTTCAGTTACGTATTGCT', end_adapter='GCAATACGTAACTGAACGAAGT',
+                 junk_rate=0.01, random_rate=0.01, chimera_rate=0.01,
+                 glitch_rate=10000.0, glitch_size=25.0, glitch_skip=25.0):
+        self.frag_mean, self.frag_stdev = float(frag_mean), float(frag_stdev)
+        if self.frag_stdev != 0.0:
+            self.gamma_k = (self.frag_mean ** 2) / (self.frag_stdev ** 2)     # fragment_lengths.py:55-64
+            self.gamma_t = (self.frag_stdev ** 2) / self.frag_mean
+        else:
+            self.gamma_k = self.gamma_t = 0.0
+        self.identity_mode, self.id_a, self.id_b, self.id_max = int(identity_mode), float(id_a), float(id_b), float(id_max)
+        self.start_rate, self.start_amount = float(start_rate), float(start_amount)
+        self.end_rate, self.end_amount = float(end_rate), float(end_amount)
+        self.start_adapter, self.end_adapter = start_adapter or '', end_adapter or ''
+        self.junk_rate, self.random_rate, self.chimera_rate = float(junk_rate), float(random_rate), float(chimera_rate)
+        self.glitch_rate, self.glitch_size, self.glitch_skip = float(glitch_rate), float(glitch_size), float(glitch_skip)
+
+    def fill(self, struct, start_ptr, end_ptr):
+        for name in ('frag_mean', 'frag_stdev', 'gamma_k', 'gamma_t', 'identity_mode', 'id_a', 'id_b', 'id_max',
+                     'start_rate', 'start_amount', 'end_rate', 'end_amount', 'junk_rate', 'random_rate',
+                     'chimera_rate', 'glitch_rate', 'glitch_size', 'glitch_skip'):
+            setattr(struct, name, getattr(self, name))
+        struct.d_start_adapter, struct.d_end_adapter = start_ptr, end_ptr
+        struct.start_adapter_len, struct.end_adapter_len = len(self.start_adapter), len(self.end_adapter)
+        return struct
+
+
+def acgt_codes(seq):
+    lut = np.full(256, 4, dtype=np.uint8)
+    for i, ch in enumerate('ACGT'):
+        lut[ord(ch)] = i
+    return lut[np.frombuffer(seq.encode('latin-1'), dtype=np.uint8)].copy() if seq else np.zeros(1, np.uint8)
+
+
+class EngineBase(object):
+    """Interface shared by HipEngine and the tests' oracle-backed checker."""
+
+    def __init__(self):
+        self._keep = {}
+        self.sym = np.frombuffer(b'ACGTNNNNNNNNNNNN', dtype=np.uint8).copy()
+
+    # subclasses provide: _upload(np_array) -> (pointer int, keepalive)
+    def _fill_reference(self, pref, cum_weight=None):
+        s = BrxReference()
+        if cum_weight is None:
+            _, cum_weight = pref.contig_weights()
+        cum_weight = np.ascontiguousarray(cum_weight, dtype=np.float64)
+        keep = []
+        for field, arr in (('d_packed', pref.packed),
+                           ('d_contigs', pref.contigs if len(pref.contigs) else np.zeros(1, pref.contigs.dtype)),
+                           ('d_exceptions', pref.exceptions if len(pref.exceptions) else np.zeros(1, pref.exceptions.dtype)),
+                           ('d_names', np.frombuffer(pref.names_pool or b'\0', dtype=np.uint8)),
+                           ('d_cum_weight', cum_weight if len(cum_weight) else np.zeros(1))):
+            ptr, k = self._upload(arr)
+            setattr(s, field, ptr)
+            keep.append(k)
+        s.n_bases, s.n_contigs, s.n_exceptions = pref.n_bases, len(pref.contigs), len(pref.exceptions)
+        s.names_len = len(pref.names_pool)
+        for i in range(16):
+            s.sym[i] = int(pref.sym[i])
+            s.comp[i] = int(pref.comp[i])
+        s.total_weight = float(cum_weight[-1]) if len(cum_weight) else 0.0
+        self.sym = np.array(pref.sym, dtype=np.uint8)
+        self._keep['ref'] = keep
+        return s
+
+    def _fill_error_model(self, t):
+        s = BrxErrorModel()
+        s.k, s.type, s.n_rows, s.n_alts, s.pool_len = t['k'], t['type'], t['n_rows'], t['n_alts'], len(t['pool'])
+        keep = []
+        for field, key in (('d_row_off', 'row_off'), ('d_self_thr', 'self_thr'), ('d_thr', 'thr'),
+                           ('d_desc', 'desc'), ('d_pool', 'pool')):
+            ptr, k = self._upload(t[key])
+            setattr(s, field, ptr)
+            keep.append(k)
+        self._keep['em'] = keep
+        return s
+
+    def _fill_qscore_model(self, t):
+        s = BrxQScoreModel()
+        s.k, s.gap_bits, s.hash_size, s.n_rows, s.n_entries = t['k'], t['gap_bits'], t['hash_size'], t['n_rows'], t['n_entries']
+        keep = []
+        for field, key in (('d_hash_key', 'hash_key'), ('d_hash_row', 'hash_row'), ('d_row_off', 'row_off'),
+                           ('d_thr', 'thr'), ('d_score', 'score')):
+            ptr, k = self._upload(t[key])
+            setattr(s, field, ptr)
+            keep.append(k)
+        self._keep['qm'] = keep
+        return s
+
+    def _fill_params(self, params):
+        s = BrxSimParams()
+        p0, k0 = self._upload(acgt_codes(params.start_adapter))
+        p1, k1 = self._upload(acgt_codes(params.end_adapter))
+        self._keep['params'] = [k0, k1]
+        return params.fill(s, p0, p1)
+
+    def decode(self, codes):
+        """base codes -> str using the current reference alphabet."""
+        return self.sym[np.asarray(codes, dtype=np.uint8)].tobytes().decode('latin-1')
+
+
+# -----------------------------------------------------------------------------------------------
+_lib = None
+
+
+def load_library():
+    """dlopen libbrx_hip.so; raises with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m badread_amd.build` '
+                           '(hipcc, --offload-arch=gfx950).  There is no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.brx_create.restype = ctypes.c_int
+    lib.brx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.brx_destroy.restype = None
+    lib.brx_destroy.argtypes = [ctypes.c_void_p]
+    lib.brx_last_error.restype = ctypes.c_char_p
+    lib.brx_last_error.argtypes = [ctypes.c_void_p]
+    lib.brx_version.restype = ctypes.c_char_p
+    lib.brx_version.argtypes = []
+    for name, struct in (('brx_set_reference', BrxReference), ('brx_set_error_model', BrxErrorModel),
+                         ('brx_set_qscore_model', BrxQScoreModel), ('brx_set_params', BrxSimParams)):
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(struct)]
+    lib.brx_set_scratch.restype = ctypes.c_int
+    lib.brx_set_scratch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.brx_scratch_needed.restype = ctypes.c_size_t
+    lib.brx_scratch_needed.argtypes = [ctypes.c_void_p]
+    lib.brx_output_needed.restype = ctypes.c_size_t
+    lib.brx_output_needed.argtypes = [ctypes.c_void_p]
+    lib.brx_simulate_batch.restype = ctypes.c_int
+    lib.brx_simulate_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                       ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
+    lib.brx_sequence_fragments.restype = ctypes.c_int
+    lib.brx_sequence_fragments.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t),
+                                           ctypes.c_void_p]
+    lib.brx_align_batch.restype = ctypes.c_int
+    lib.brx_align_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 11
+    lib.brx_last_stage_ms.restype = ctypes.c_int
+    lib.brx_last_stage_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float * 6)]
+    _lib = lib
+    return lib
+
+
+class BrxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f'libbrx_hip error {code}: {message}')
+        self.code = code
+
+
+class HipEngine(EngineBase):
+    """One context on one MI355X.  Not thread-safe; one engine per process per GPU."""
+
+    def __init__(self, device=0, scratch_bytes=1 << 30):
+        super().__init__()
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('HipEngine needs a ROCm device (torch.cuda.is_available() is False); '
+                               'there is no CPU fallback')
+        self.torch = torch
+        self.device = torch.device('cuda', device)
+        self.lib = load_library()
+        ctx = ctypes.c_void_p()
+        rc = self.lib.brx_create(device, ctypes.byref(ctx))
+        if rc != 0:
+            raise BrxError(rc, 'brx_create failed')
+        self.ctx = ctx
+        self._scratch = None
+        self._out = None
+        self._stats = None
+        self._ensure_scratch(scratch_bytes)
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.brx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise BrxError(rc, self.lib.brx_last_error(self.ctx).decode('latin-1', 'replace'))
+
+    def _upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        raw = arr.view(np.uint8).reshape(-1) if arr.dtype.fields is None else np.frombuffer(arr.tobytes(), dtype=np.uint8)
+        if raw.size == 0:
+            raw = np.zeros(8, dtype=np.uint8)
+        t = self.torch.from_numpy(raw.copy()).to(self.device)
+        return t.data_ptr(), t
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ensure_scratch(self, nbytes):
+        if self._scratch is None or self._scratch.numel() < nbytes:
+            self._scratch = None
+            self._scratch = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+            self._check(self.lib.brx_set_scratch(self.ctx, ctypes.c_void_p(self._scratch.data_ptr()),
+                                                 self._scratch.numel()))
+
+    def _ensure_out(self, nbytes, n_reads):
+        if self._out is None or self._out.numel() < nbytes:
+            self._out = None
+            self._out = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+        need = n_reads * READ_STATS_DTYPE.itemsize
+        if self._stats is None or self._stats.numel() < need:
+            self._stats = self.torch.empty(int(need), dtype=self.torch.uint8, device=self.device)
+
+    # ------------------------------------------------------------------ configuration
+    def set_reference(self, pref, cum_weight=None):
+        s = self._fill_reference(pref, cum_weight)
+        self._check(self.lib.brx_set_reference(self.ctx, ctypes.byref(s)))
+
+    def set_error_model(self, tables):
+        s = self._fill_error_model(tables)
+        self._check(self.lib.brx_set_error_model(self.ctx, ctypes.byref(s)))
+
+    def set_qscore_model(self, tables):
+        s = self._fill_qscore_model(tables)
+        self._check(self.lib.brx_set_qscore_model(self.ctx, ctypes.byref(s)))
+
+    def set_params(self, params):
+        s = self._fill_params(params)
+        self._check(self.lib.brx_set_params(self.ctx, ctypes.byref(s)))
+
+    # ------------------------------------------------------------------ calls
+    def _retry(self, call, n_reads, out_guess):
+        """Run `call(out_ptr, out_cap, stats_ptr, out_bytes)` growing scratch/output as the library asks."""
+        self._ensure_out(out_guess, n_reads)
+        for _ in range(8):
+            out_bytes = ctypes.c_size_t(0)
+            rc = call(ctypes.c_void_p(self._out.data_ptr()), self._out.numel(),
+                      ctypes.c_void_p(self._stats.data_ptr()), ctypes.byref(out_bytes))
+            if rc == E_SCRATCH:
+                self._ensure_scratch(int(self.lib.brx_scratch_needed(self.ctx) * 1.25) + (1 << 20))
+                continue
+            if rc == E_OUTPUT:
+                self._ensure_out(int(self.lib.brx_output_needed(self.ctx) * 1.1) + (1 << 16), n_reads)
+                continue
+            self._check(rc)
+            return out_bytes.value
+        raise BrxError(E_SCRATCH, 'could not size scratch/output buffers after 8 attempts')
+
+    def simulate_batch_device(self, seed, first_read, n_reads, expected_bytes=None):
+        """Returns (device uint8 tensor view of the FASTQ bytes, stats as numpy structured array)."""
+        guess = expected_bytes or (n_reads * 34000 + (1 << 16))
+        nbytes = self._retry(lambda o, cap, st, ob: self.lib.brx_simulate_batch(
+            self.ctx, seed, first_read, n_reads, o, cap, st, ob, self._stream()), n_reads, guess)
+        stats = self._stats[:n_reads * READ_STATS_DTYPE.itemsize].cpu().numpy().view(READ_STATS_DTYPE)
+        return self._out[:nbytes], stats
+
+    def simulate_batch(self, seed, first_read, n_reads):
+        out, stats = self.simulate_batch_device(seed, first_read, n_reads)
+        return out.cpu().numpy(), stats
+
+    def sequence_fragments(self, seed, first_read, frags, targets):
+        """frags: list of uint8 code arrays; returns (list of (seq_codes, qual_bytes), stats)."""
+        n = len(frags)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(f) for f in frags])
+        flat = np.concatenate(frags).astype(np.uint8) if n else np.zeros(1, np.uint8)
+        p_fr, k1 = self._upload(flat)
+        p_off, k2 = self._upload(off)
+        p_tg, k3 = self._upload(np.asarray(targets, dtype=np.float64))
+        guess = int(off[-1]) * 3 + 4096 * n + 4096
+        nbytes = self._retry(lambda o, cap, st, ob: self.lib.brx_sequence_fragments(
+            self.ctx, seed, first_read, n, ctypes.c_void_p(p_fr), ctypes.c_void_p(p_off), ctypes.c_void_p(p_tg),
+            o, cap, st, ob, self._stream()), n, guess)
+        del k1, k2, k3
+        raw = self._out[:nbytes].cpu().numpy()
+        stats = self._stats[:n * READ_STATS_DTYPE.itemsize].cpu().numpy().view(READ_STATS_DTYPE).copy()
+        res = []
+        for st in stats:
+            o, L = int(st['rec_off']), int(st['seq_len'])
+            res.append((raw[o:o + L].copy(), raw[o + L:o + 2 * L].copy()))
+        return res, stats
+
+    def align_batch(self, queries, targets, k_hint=None, want_ops=True):
+        """queries/targets: lists of bytes.  Returns (list of op arrays or None, dist, ncols, nmatch)."""
+        n = len(queries)
+        q_off = np.zeros(n + 1, dtype=np.uint64)
+        t_off = np.zeros(n + 1, dtype=np.uint64)
+        q_off[1:] = np.cumsum([len(q) for q in queries])
+        t_off[1:] = np.cumsum([len(t) for t in targets])
+        ops_off = q_off + t_off
+        qbuf = np.frombuffer(b''.join(bytes(q) for q in queries) or b'\0', dtype=np.uint8)
+        tbuf = np.frombuffer(b''.join(bytes(t) for t in targets) or b'\0', dtype=np.uint8)
+        kh = np.full(n, -1, dtype=np.int32) if k_hint is None else np.asarray(k_hint, dtype=np.int32)
+        torch = self.torch
+        p_qs, k0 = self._upload(qbuf)
+        p_q, k2 = self._upload(q_off)
+        p_ts, k1 = self._upload(tbuf)
+        p_t, k3 = self._upload(t_off)
+        p_k, k4 = self._upload(kh)
+        p_oo, k5 = self._upload(ops_off)
+        d_dist = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        d_ncols = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        d_nmatch = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        d_ops = torch.empty(max(int(ops_off[-1]), 1), dtype=torch.uint8, device=self.device) if want_ops else None
+        for _ in range(8):
+            rc = self.lib.brx_align_batch(self.ctx, n, p_qs, p_q, p_ts, p_t, p_k, d_dist.data_ptr(), d_ncols.data_ptr(),
+                                          d_nmatch.data_ptr(), d_ops.data_ptr() if want_ops else None, p_oo,
+                                          self._stream().value)
+            if rc == E_SCRATCH:
+                self._ensure_scratch(int(self.lib.brx_scratch_needed(self.ctx) * 1.25) + (1 << 20))
+                continue
+            self._check(rc)
+            break
+        else:
+            raise BrxError(E_SCRATCH, 'could not size the alignment scratch after 8 attempts')
+        del k0, k1, k2, k3, k4, k5
+        dist = d_dist[:n].cpu().numpy()
+        ncols = d_ncols[:n].cpu().numpy()
+        nmatch = d_nmatch[:n].cpu().numpy()
+        ops_list = None
+        if want_ops:
+            raw = d_ops.cpu().numpy()
+            ops_list = [raw[int(ops_off[i]):int(ops_off[i]) + int(ncols[i])].copy() for i in range(n)]
+        return ops_list, dist, ncols, nmatch
+
+    def stage_ms(self):
+        arr = (ctypes.c_float * 6)()
+        self._check(self.lib.brx_last_stage_ms(self.ctx, ctypes.byref(arr)))
+        return dict(zip(STAGE_NAMES, [float(x) for x in arr]))
+
+
+_default_engine = None
+
+
+def default_engine():
+    """Process-wide HipEngine on LOCAL_RANK (or device 0)."""
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = HipEngine(int(os.environ.get('LOCAL_RANK', '0')))
+    return _default_engine
+
+
+def hip_align_batch(queries, targets):
+    """Aligner callable for ErrorModel loading: list of op arrays via the HIP Myers kernel."""
+    ops, _, _, _ = default_engine().align_batch(queries, targets)
+    return ops

@@ -206,13 +206,16 @@ int brx_sequence_fragments(brx_ctx *ctx, uint64_t seed, uint64_t first_read, uin
                            brx_read_stats *d_stats, size_t *out_bytes, void *hip_stream);
 
 /* replaces edlib.align(query, target, task='path') (simulate.py:330,340; qscore_model.py:37;
- * error_model.py:202) for a batch: pair i aligns query d_seqs[q_off[i]..q_off[i+1]) against target
- * d_seqs[t_off[i]..t_off[i+1]) (any byte alphabet).  k_hint[i] >= 0 is a proven upper bound on the
- * distance (no band search), -1 = unknown (band doubling from 64).  Writes the edit distance to
- * d_dist[i], the number of alignment columns to d_ncols[i] and, if d_ops != NULL, the per-column
- * ops (0 '=',1 'X',2 'I',3 'D', forward order) at d_ops + ops_off[i] (capacity qlen+tlen).        */
-int brx_align_batch(brx_ctx *ctx, uint32_t n_pairs, const uint8_t *d_seqs,
-                    const uint64_t *d_q_off, const uint64_t *d_t_off, const int32_t *d_k_hint,
+ * error_model.py:202) for a batch: pair i aligns query d_queries[q_off[i]..q_off[i+1]) against
+ * target d_targets[t_off[i]..t_off[i+1]) (any byte alphabet; equality is byte equality).
+ * k_hint[i] >= 0 is a proven upper bound on the distance (no band search), -1 = unknown (band
+ * doubling from 64, like edlib).  Writes the edit distance to d_dist[i], the number of alignment
+ * columns to d_ncols[i], the number of '=' columns to d_nmatch[i] and, if d_ops != NULL, the
+ * per-column ops (0 '=',1 'X',2 'I',3 'D', forward order; 'I' = byte present in the query only)
+ * at d_ops + ops_off[i] (capacity qlen+tlen).                                                    */
+int brx_align_batch(brx_ctx *ctx, uint32_t n_pairs,
+                    const uint8_t *d_queries, const uint64_t *d_q_off,
+                    const uint8_t *d_targets, const uint64_t *d_t_off, const int32_t *d_k_hint,
                     int32_t *d_dist, uint32_t *d_ncols, uint32_t *d_nmatch,
                     uint8_t *d_ops, const uint64_t *d_ops_off, void *hip_stream);
 
