@@ -1,0 +1,48 @@
+"""
+Build libbrx_hip.so in-tree with hipcc for gfx950 (`python -m badread_amd.build`).
+
+Flags that matter:
+  --offload-arch=gfx950   the only target (CDNA4 / MI355X); no other architectures, no fallbacks
+  -ffp-contract=off       part of the numerical spec: device doubles must round like the oracle's
+The .so is git-ignored but travels to the GPU box with the tree.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.realpath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(CSRC, 'libbrx_hip.so')
+SOURCES = ['brx_hip.hip']
+DEPS = ['brx_hip.hip', 'brx_kernels.h', 'brx_align.h', os.path.join('..', '..', 'include', 'brx.h'),
+        os.path.join('..', '..', 'include', 'brx_spec.h')]
+
+
+def hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return 'hipcc'
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+           '-Wall', '-Wno-unused-function', '-Wno-unused-parameter', '-Wno-unused-variable']
+    if verbose:
+        cmd.append('-Rpass-analysis=kernel-resource-usage')
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ['-o', OUT]
+    subprocess.check_call(cmd, cwd=CSRC)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))

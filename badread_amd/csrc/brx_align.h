@@ -1,0 +1,394 @@
+/*
+ * brx_align.h -- wavefront-cooperative banded Myers/Hyyro bit-vector global alignment for gfx950.
+ *
+ * Replaces every edlib.align(..., task='path') on Badread's simulate path
+ * (/root/reference/badread/simulate.py:330,340; qscore_model.py:37; error_model.py:202).
+ *
+ * One alignment per 64-lane wavefront.  The query is cut into 32-row words; lane l owns
+ * "superblock" s = l (mod 64) = G consecutive words (R = 32*G rows).  Lanes run the column
+ * recurrence systolically: superblock s works on column j at time step t = j + s, so the
+ * horizontal delta leaving superblock s-1 for column j (computed at t-1) reaches superblock s
+ * exactly when it needs it -- one cross-lane exchange per step, no carry look-ahead, no wasted
+ * work.  Only superblocks inside the Ukkonen band |i-j| <= f(k) are computed; a lane that leaves
+ * the band at the top re-enters 64 superblocks further down.  Each lane keeps the five equality
+ * masks (A,C,G,T,N) of its words in registers for as long as it owns them, so the only per-step
+ * memory traffic is one target byte in (4-byte prefetched) and 8*G bytes of traceback bits out,
+ * written as [time step][band slot] rows so that a wave's stores are contiguous.
+ *
+ * Traceback (canonical path: up/'I' first, then left/'D', then diagonal, from the bottom-right
+ * cell; identical to oracle/myers_ref.c) uses the stored vertical-plus (Pv) and horizontal-plus
+ * (Ph) bit-vectors only: a cell moves up iff its Pv bit is set, else left iff its Ph bit is set,
+ * else diagonally.  All 64 lanes speculate down the current diagonal at once (lane l looks at
+ * cell (i-l, j-l)); a ballot finds the first lane that is not a diagonal move, so one round
+ * retires a whole run of '='/'X' columns plus the indel that ends it.
+ *
+ * Exactness: cells outside the band are bounded above (+1 per row/column), cells whose true value
+ * is <= k are exact, and the canonical path only visits such cells when k >= distance; a
+ * traceback that would leave the band or ends with cost > k reports failure (the caller doubles
+ * k, or flags BRX_RS_BAND when k was a proven bound).
+ */
+#ifndef BRX_ALIGN_H
+#define BRX_ALIGN_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BRX_OP_EQ 0
+#define BRX_OP_X 1
+#define BRX_OP_I 2
+#define BRX_OP_D 3
+
+struct BrxGeom {
+    int Q, T;          /* query rows, target columns                              */
+    int dlo, dhi;      /* band of diagonals i-j                                   */
+    int G, R;          /* words per lane, rows per superblock (32*G)              */
+    int NS, NW;        /* superblocks, 32-row words                               */
+    int WSp;           /* band slots per time step in the traceback store         */
+    int t_end;         /* last time step = T + NS - 1                             */
+};
+
+/* k must be >= |Q-T|.  Returns G = 0 if the band is wider than 64 lanes x 32 words can hold. */
+__host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k) {
+    BrxGeom g;
+    g.Q = Q; g.T = T;
+    int dend = Q - T;
+    int adend = dend < 0 ? -dend : dend;
+    if (k < adend) k = adend;
+    int half = (k - adend) / 2;
+    g.dlo = (dend < 0 ? dend : 0) - half;
+    g.dhi = (dend > 0 ? dend : 0) + half;
+    int bw = g.dhi - g.dlo + 1;
+    int G = 1;
+    while (G <= 32 && bw > 56 * 32 * G) G *= 2;
+    if (G > 32) { g.G = 0; g.R = 0; g.NS = 0; g.NW = 0; g.WSp = 0; g.t_end = 0; return g; }
+    g.G = G; g.R = 32 * G;
+    g.NW = (Q + 31) / 32;
+    g.NS = (Q + g.R - 1) / g.R;
+    g.WSp = (bw + g.R - 2) / (g.R + 1) + 2;
+    if (g.WSp > g.NS) g.WSp = g.NS;
+    if (g.WSp < 1) g.WSp = 1;
+    g.t_end = T + g.NS - 1;
+    return g;
+}
+
+/* 8-byte units of traceback storage an alignment needs */
+__host__ __device__ inline uint64_t brx_tb_units(const BrxGeom &g) {
+    return (uint64_t)(g.t_end + 1) * (uint64_t)g.WSp * (uint64_t)g.G;
+}
+/* lanes holding more than BRX_REGPEQ_MAXG words read their equality masks from a table
+   [5][NW] (u32) that the wave builds behind the traceback store */
+#define BRX_REGPEQ_MAXG 4
+__host__ __device__ inline uint64_t brx_peq_units(const BrxGeom &g) {
+    return g.G > BRX_REGPEQ_MAXG ? ((uint64_t)5 * (uint64_t)g.NW * 4 + 7) / 8 + (uint64_t)64 * (uint64_t)g.G : 0;
+}
+__host__ __device__ inline uint64_t brx_align_units(const BrxGeom &g) { return brx_tb_units(g) + brx_peq_units(g); }
+
+__device__ inline int brx_jfirst(const BrxGeom &g, int s) {
+    int j = g.R * s - g.dhi + 1;
+    return j < 1 ? 1 : j;
+}
+__device__ inline int brx_jlast(const BrxGeom &g, int s) {
+    long long j = (long long)g.R * (s + 1) - g.dlo;
+    return j > g.T ? g.T : (int)j;
+}
+
+/* equality mask of word w for symbol c, straight from the query bytes (symbols outside 0..4) */
+__device__ inline uint32_t brx_eq_slow(const uint8_t *Qs, int Q, int w, uint32_t c) {
+    uint32_t m = 0;
+    int base = 32 * w;
+    for (int r = 0; r < 32; ++r) {
+        int idx = base + r;
+        if (idx < Q && Qs[idx] == c) m |= 1u << r;
+    }
+    return m;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * forward pass: fills tb[(t*WSp + s%WSp)*G + g] = {Pv after column j, Ph before its shift}
+ * Qs and Ts must be readable up to 8 bytes past their ends (buffers are padded by the caller) and
+ * 4-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+template <int G>
+__device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
+                                  const BrxGeom g, uint2 *__restrict__ tb) {
+    constexpr bool REGPEQ = true;
+    constexpr int PG = G;
+    const int lane = threadIdx.x & 63;
+    int s = lane;
+    bool has = s < g.NS;
+    int jf = has ? brx_jfirst(g, s) : 0, jl = has ? brx_jlast(g, s) : -1;
+    int slot = has ? s % g.WSp : 0;
+    uint32_t Pv[G], Mv[G];
+    uint32_t pe[PG][5];
+#pragma unroll
+    for (int x = 0; x < G; ++x) { Pv[x] = 0xFFFFFFFFu; Mv[x] = 0; }
+#pragma unroll
+    for (int x = 0; x < PG; ++x) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) pe[x][c] = 0;
+    }
+    int hout_last = 0, s_last = -1;
+    bool active_last = false;
+    uint32_t cbuf = 0, cnext = 0;
+
+    for (int t = 1; t <= g.t_end; ++t) {
+        int packed = (s_last << 3) | (active_last ? 4 : 0) | (hout_last + 1);
+        int nb = __shfl(packed, (lane + 63) & 63, 64);
+        int j = t - s;
+        bool active = has && j >= jf && j <= jl;
+        if (active) {
+            if (j == jf) {
+                /* superblock enters the band: cells below the band grow by +1 per row */
+#pragma unroll
+                for (int x = 0; x < G; ++x) {
+                    Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;
+                    int w = s * G + x;
+                    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+                    if (REGPEQ && w < g.NW) {
+                        const uint32_t *q4 = reinterpret_cast<const uint32_t *>(Qs + 32 * w);
+#pragma unroll 1
+                        for (int d = 0; d < 8; ++d) {
+                            uint32_t v = q4[d];
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                uint32_t code = (v >> (8 * b)) & 0xFFu;
+                                int r = 4 * d + b;
+                                bool ok = (32 * w + r) < g.Q;
+                                m0 |= (uint32_t)(ok && code == 0) << r;
+                                m1 |= (uint32_t)(ok && code == 1) << r;
+                                m2 |= (uint32_t)(ok && code == 2) << r;
+                                m3 |= (uint32_t)(ok && code == 3) << r;
+                                m4 |= (uint32_t)(ok && code == 4) << r;
+                            }
+                        }
+                    }
+                    if (REGPEQ) { pe[x % PG][0] = m0; pe[x % PG][1] = m1; pe[x % PG][2] = m2; pe[x % PG][3] = m3; pe[x % PG][4] = m4; }
+                }
+                int a = (j - 1) & ~3;
+                cbuf = *reinterpret_cast<const uint32_t *>(Ts + a);
+                cnext = *reinterpret_cast<const uint32_t *>(Ts + a + 4);
+            } else if (((j - 1) & 3) == 0) {
+                cbuf = cnext;
+                cnext = *reinterpret_cast<const uint32_t *>(Ts + (j - 1) + 4);
+            }
+            uint32_t c = (cbuf >> (8 * ((j - 1) & 3))) & 0xFFu;
+            int hin = 1;
+            if (s > 0 && (nb >> 3) == s - 1 && (nb & 4)) hin = (nb & 3) - 1;
+            uint32_t hp = hin > 0 ? 1u : 0u, hm = hin < 0 ? 1u : 0u;
+            uint2 *dst = tb + ((size_t)t * (size_t)g.WSp + (size_t)slot) * (size_t)G;
+#pragma unroll
+            for (int x = 0; x < G; ++x) {
+                int w = s * G + x;
+                if (w < g.NW) {
+                    uint32_t Eq;
+                    if (c < 5) {
+                        if (REGPEQ) {
+                            Eq = pe[x % PG][0];
+                            Eq = c == 1 ? pe[x % PG][1] : Eq;
+                            Eq = c == 2 ? pe[x % PG][2] : Eq;
+                            Eq = c == 3 ? pe[x % PG][3] : Eq;
+                            Eq = c == 4 ? pe[x % PG][4] : Eq;
+                        } else Eq = 0;
+                    } else Eq = brx_eq_slow(Qs, g.Q, w, c);
+                    uint32_t pv = Pv[x], mv = Mv[x];
+                    uint32_t Xv = Eq | mv;
+                    uint32_t Eq2 = Eq | hm;
+                    uint32_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
+                    uint32_t Ph = mv | ~(Xh | pv);
+                    uint32_t Mh = pv & Xh;
+                    uint32_t op = Ph >> 31, om = Mh >> 31;
+                    uint32_t PhS = (Ph << 1) | hp;
+                    uint32_t MhS = (Mh << 1) | hm;
+                    pv = MhS | ~(Xv | PhS);
+                    mv = PhS & Xv;
+                    Pv[x] = pv; Mv[x] = mv;
+                    dst[x] = make_uint2(pv, Ph);
+                    hp = op; hm = om;
+                }
+            }
+            hout_last = (int)hp - (int)hm;
+        }
+        active_last = active;
+        s_last = s;
+        if (has && j >= jl) {
+            s += 64;
+            has = s < g.NS;
+            if (has) { jf = brx_jfirst(g, s); jl = brx_jlast(g, s); slot = s % g.WSp; }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * traceback.  ops_end: one past the last byte of the caller's ops area (written backwards), or
+ * nullptr for counts only.  Returns true on success; *n_cols, *n_match valid for all lanes.
+ * ------------------------------------------------------------------------------------------- */
+__device__ inline bool brx_align_traceback(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
+                                           const BrxGeom g, const uint2 *__restrict__ tb,
+                                           uint8_t *ops_end, int *n_cols, int *n_match) {
+    const int lane = threadIdx.x & 63;
+    int i = g.Q, j = g.T;
+    int pos = 0, nmatch = 0;
+    bool ok = true;
+    const int shiftR = 31 - __clz(g.R);          /* R is a power of two */
+    while (i > 0 && j > 0) {
+        int ci = i - lane, cj = j - lane;
+        bool valid = ci >= 1 && cj >= 1;
+        bool inband = false, up = false, left = false, eq = false;
+        if (valid) {
+            int s = (ci - 1) >> shiftR;
+            inband = cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s);
+            if (inband) {
+                int x = ((ci - 1) & (g.R - 1)) >> 5;
+                int bit = (ci - 1) & 31;
+                uint2 v = tb[((size_t)(cj + s) * (size_t)g.WSp + (size_t)(s % g.WSp)) * (size_t)g.G + (size_t)x];
+                up = (v.x >> bit) & 1u;
+                left = (v.y >> bit) & 1u;
+            }
+            eq = Qs[ci - 1] == Ts[cj - 1];
+        }
+        bool diag = valid && inband && !up && !left;
+        unsigned long long dm = __ballot(diag);
+        unsigned long long um = __ballot(up);
+        unsigned long long vm = __ballot(valid && inband);
+        unsigned long long em = __ballot(eq);
+        int run = (~dm == 0ull) ? 64 : __ffsll((long long)~dm) - 1;
+        if (lane < run && ops_end) ops_end[-(pos + lane) - 1] = eq ? BRX_OP_EQ : BRX_OP_X;
+        unsigned long long runmask = run == 64 ? ~0ull : ((1ull << run) - 1ull);
+        nmatch += __popcll(em & runmask);
+        pos += run; i -= run; j -= run;
+        if (run < 64 && i > 0 && j > 0) {
+            if (!((vm >> run) & 1ull)) { ok = false; break; }
+            bool isup = (um >> run) & 1ull;
+            if (lane == 0 && ops_end) ops_end[-pos - 1] = isup ? BRX_OP_I : BRX_OP_D;
+            pos += 1;
+            if (isup) i -= 1; else j -= 1;
+        }
+    }
+    if (ok) {
+        if (ops_end) {
+            for (int x = lane; x < i; x += 64) ops_end[-(pos + x) - 1] = BRX_OP_I;
+            for (int x = lane; x < j; x += 64) ops_end[-(pos + x) - 1] = BRX_OP_D;
+        }
+        pos += i + j;
+    }
+    *n_cols = pos; *n_match = nmatch;
+    return ok;
+}
+
+/* dispatch on words-per-lane */
+/* Wide bands (more than BRX_REGPEQ_MAXG words per lane; reads that are both very long and very
+ * inaccurate): same systolic schedule, but the G words of a lane live in a per-wave state array
+ * st[x*64 + lane] = {Pv, Mv} behind the Peq table instead of registers.  Rare, so simplicity wins. */
+__device__ inline void brx_align_forward_wide(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
+                                              const BrxGeom g, uint2 *__restrict__ tb,
+                                              const uint32_t *__restrict__ peq, uint2 *__restrict__ st) {
+    const int lane = threadIdx.x & 63;
+    const int G = g.G;
+    int s = lane;
+    bool has = s < g.NS;
+    int jf = has ? brx_jfirst(g, s) : 0, jl = has ? brx_jlast(g, s) : -1;
+    int slot = has ? s % g.WSp : 0;
+    int hout_last = 0, s_last = -1;
+    bool active_last = false;
+    for (int t = 1; t <= g.t_end; ++t) {
+        int packed = (s_last << 3) | (active_last ? 4 : 0) | (hout_last + 1);
+        int nb = __shfl(packed, (lane + 63) & 63, 64);
+        int j = t - s;
+        bool active = has && j >= jf && j <= jl;
+        if (active) {
+            bool fresh = (j == jf);
+            uint32_t c = Ts[j - 1];
+            int hin = 1;
+            if (s > 0 && (nb >> 3) == s - 1 && (nb & 4)) hin = (nb & 3) - 1;
+            uint32_t hp = hin > 0 ? 1u : 0u, hm = hin < 0 ? 1u : 0u;
+            uint2 *dst = tb + ((size_t)t * (size_t)g.WSp + (size_t)slot) * (size_t)G;
+            for (int x = 0; x < G; ++x) {
+                int w = s * G + x;
+                if (w >= g.NW) break;
+                uint2 pm = fresh ? make_uint2(0xFFFFFFFFu, 0u) : st[x * 64 + lane];
+                uint32_t Eq = c < 5 ? peq[(size_t)c * (size_t)g.NW + (size_t)w] : brx_eq_slow(Qs, g.Q, w, c);
+                uint32_t pv = pm.x, mv = pm.y;
+                uint32_t Xv = Eq | mv;
+                uint32_t Eq2 = Eq | hm;
+                uint32_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
+                uint32_t Ph = mv | ~(Xh | pv);
+                uint32_t Mh = pv & Xh;
+                uint32_t op = Ph >> 31, om = Mh >> 31;
+                uint32_t PhS = (Ph << 1) | hp;
+                uint32_t MhS = (Mh << 1) | hm;
+                pv = MhS | ~(Xv | PhS);
+                mv = PhS & Xv;
+                st[x * 64 + lane] = make_uint2(pv, mv);
+                dst[x] = make_uint2(pv, Ph);
+                hp = op; hm = om;
+            }
+            hout_last = (int)hp - (int)hm;
+        }
+        active_last = active;
+        s_last = s;
+        if (has && j >= jl) {
+            s += 64;
+            has = s < g.NS;
+            if (has) { jf = brx_jfirst(g, s); jl = brx_jlast(g, s); slot = s % g.WSp; }
+        }
+    }
+}
+
+__device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32_t *peq) {
+    const int lane = threadIdx.x & 63;
+    for (int w = lane; w < g.NW; w += 64) {
+        uint32_t m[5] = {0, 0, 0, 0, 0};
+        for (int r = 0; r < 32; ++r) {
+            int idx = 32 * w + r;
+            uint32_t code = idx < g.Q ? Qs[idx] : 0xFFu;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) m[c] |= (uint32_t)(code == (uint32_t)c) << r;
+        }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) peq[(size_t)c * (size_t)g.NW + (size_t)w] = m[c];
+    }
+}
+
+__device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *Ts, const BrxGeom &g, uint2 *tb) {
+    if (g.G > BRX_REGPEQ_MAXG) {
+        uint32_t *peq = reinterpret_cast<uint32_t *>(tb + brx_tb_units(g));
+        uint2 *st = tb + brx_tb_units(g) + ((uint64_t)5 * (uint64_t)g.NW * 4 + 7) / 8;
+        brx_build_peq(Qs, g, peq);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        brx_align_forward_wide(Qs, Ts, g, tb, peq, st);
+        return;
+    }
+    switch (g.G) {
+    case 1: brx_align_forward<1>(Qs, Ts, g, tb); break;
+    case 2: brx_align_forward<2>(Qs, Ts, g, tb); break;
+    default: brx_align_forward<4>(Qs, Ts, g, tb); break;
+    }
+}
+
+/* Full alignment with a given band bound k.  Returns false if the band was too narrow.
+ * Handles empty inputs.  All lanes of the wave must call; results are wave-uniform. */
+__device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *Ts, int T, int k,
+                                      uint2 *tb, uint64_t tb_cap_units, uint8_t *ops_end,
+                                      int *n_cols, int *n_match, bool *no_space) {
+    const int lane = threadIdx.x & 63;
+    *no_space = false;
+    if (Q == 0 || T == 0) {
+        if (ops_end) {
+            for (int x = lane; x < Q; x += 64) ops_end[-x - 1] = BRX_OP_I;
+            for (int x = lane; x < T; x += 64) ops_end[-x - 1] = BRX_OP_D;
+        }
+        *n_cols = Q + T; *n_match = 0;
+        return true;
+    }
+    BrxGeom g = brx_make_geom(Q, T, k);
+    if (g.G == 0 || brx_align_units(g) > tb_cap_units) { *no_space = true; *n_cols = 0; *n_match = 0; return false; }
+    brx_align_forward_any(Qs, Ts, g, tb);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);      /* stores of this wave visible to its own later loads */
+    bool ok = brx_align_traceback(Qs, Ts, g, tb, ops_end, n_cols, n_match);
+    if (ok && (*n_cols - *n_match) > k) ok = false;
+    return ok;
+}
+
+#endif /* BRX_ALIGN_H */

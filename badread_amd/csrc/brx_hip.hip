@@ -1,0 +1,352 @@
+/*
+ * brx_hip.hip -- host side of libbrx_hip.so: the C-ABI declared in include/brx.h.
+ *
+ * Build (see badread_amd/build.py):
+ *   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared brx_hip.hip -o libbrx_hip.so
+ * -ffp-contract=off is part of the numerical spec (include/brx_spec.h): the device must round
+ * every double operation exactly like the CPU oracle.
+ *
+ * All device memory comes from the caller: descriptors point at caller tensors, and every
+ * temporary lives in the caller's scratch arena, carved by a bump allocator per call.
+ */
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "brx_kernels.h"
+
+struct brx_ctx {
+    int device;
+    int n_cu;
+    int waves_per_cu;
+    BrxDev dev;
+    bool has_ref, has_em, has_qm, has_params;
+    uint8_t *scratch;
+    size_t scratch_bytes;
+    size_t scratch_needed, output_needed;
+    uint64_t win_bytes;
+    uint64_t *h_totals;          /* pinned, 16 x u64 */
+    hipEvent_t ev[BRX_STAGE_COUNT + 1];
+    float stage_ms[BRX_STAGE_COUNT];
+    char err[512];
+};
+
+static int fail(brx_ctx *c, int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return fail((c), BRX_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Arena {
+    uint8_t *base; size_t cap; size_t used;
+    void *take(size_t bytes) {
+        size_t at = (used + 255) & ~(size_t)255;
+        used = at + bytes;
+        return used <= cap ? base + at : nullptr;
+    }
+    bool ok() const { return used <= cap; }
+};
+
+extern "C" const char *brx_version(void) { return "brx-hip 0.1 (gfx950)"; }
+
+extern "C" int brx_create(int device_id, brx_ctx **out) {
+    if (!out) return BRX_E_ARG;
+    brx_ctx *c = (brx_ctx *)calloc(1, sizeof(brx_ctx));
+    if (!c) return BRX_E_ARG;
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { free(c); return BRX_E_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free(c); return BRX_E_HIP; }
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const char *w = getenv("BRX_WAVES_PER_CU");
+    c->waves_per_cu = w ? atoi(w) : 16;
+    if (c->waves_per_cu < 1) c->waves_per_cu = 1;
+    const char *wb = getenv("BRX_WIN_KB");
+    c->win_bytes = (uint64_t)(wb ? atoi(wb) : 256) << 10;
+    if (hipHostMalloc((void **)&c->h_totals, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { free(c); return BRX_E_HIP; }
+    for (int i = 0; i <= BRX_STAGE_COUNT; ++i)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) { free(c); return BRX_E_HIP; }
+    c->err[0] = 0;
+    *out = c;
+    return BRX_OK;
+}
+
+extern "C" void brx_destroy(brx_ctx *c) {
+    if (!c) return;
+    for (int i = 0; i <= BRX_STAGE_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->h_totals) hipHostFree(c->h_totals);
+    free(c);
+}
+
+extern "C" const char *brx_last_error(const brx_ctx *c) { return c ? c->err : "null context"; }
+
+extern "C" int brx_set_reference(brx_ctx *c, const brx_reference *r) {
+    if (!c || !r) return BRX_E_ARG;
+    if (r->n_contigs == 0 || !r->d_packed || !r->d_contigs) return fail(c, BRX_E_ARG, "reference has no contigs");
+    c->dev.ref = *r; c->has_ref = true; return BRX_OK;
+}
+extern "C" int brx_set_error_model(brx_ctx *c, const brx_error_model *m) {
+    if (!c || !m) return BRX_E_ARG;
+    if (m->k < 1 || m->k > 16) return fail(c, BRX_E_ARG, "error model k-mer size %d out of range", m->k);
+    c->dev.em = *m; c->has_em = true; return BRX_OK;
+}
+extern "C" int brx_set_qscore_model(brx_ctx *c, const brx_qscore_model *m) {
+    if (!c || !m) return BRX_E_ARG;
+    if (m->k < 1 || (m->k & 1) == 0 || 2 * m->k + m->gap_bits * (m->k - 1) > 56 || (m->hash_size & (m->hash_size - 1)))
+        return fail(c, BRX_E_ARG, "unsupported qscore model geometry");
+    c->dev.qm = *m; c->has_qm = true; return BRX_OK;
+}
+extern "C" int brx_set_params(brx_ctx *c, const brx_sim_params *p) {
+    if (!c || !p) return BRX_E_ARG;
+    c->dev.p = *p; c->has_params = true; return BRX_OK;
+}
+extern "C" int brx_set_scratch(brx_ctx *c, void *d_scratch, size_t bytes) {
+    if (!c) return BRX_E_ARG;
+    c->scratch = (uint8_t *)d_scratch; c->scratch_bytes = bytes; return BRX_OK;
+}
+extern "C" size_t brx_scratch_needed(const brx_ctx *c) { return c ? c->scratch_needed : 0; }
+extern "C" size_t brx_output_needed(const brx_ctx *c) { return c ? c->output_needed : 0; }
+extern "C" int brx_last_stage_ms(const brx_ctx *c, float ms[BRX_STAGE_COUNT]) {
+    if (!c || !ms) return BRX_E_ARG;
+    for (int i = 0; i < BRX_STAGE_COUNT; ++i) ms[i] = c->stage_ms[i];
+    return BRX_OK;
+}
+
+static int read_totals(brx_ctx *c, hipStream_t st, const uint64_t *d_totals, int n) {
+    HIPCHK(c, hipMemcpyAsync(c->h_totals, d_totals, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return BRX_OK;
+}
+
+static int scratch_short(brx_ctx *c, size_t needed) {
+    c->scratch_needed = needed;
+    return fail(c, BRX_E_SCRATCH, "scratch arena too small: need about %zu bytes, have %zu", needed, c->scratch_bytes);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * the shared pipeline: plan (or raw fragments) -> build -> mutate -> final -> records
+ * ------------------------------------------------------------------------------------------- */
+static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t n_reads, bool raw,
+                        const uint8_t *d_frags, const uint64_t *d_frag_off, const double *d_target,
+                        uint8_t *d_out, size_t out_cap, brx_read_stats *d_stats, size_t *out_bytes, hipStream_t st) {
+    if (!c->has_em || !c->has_qm) return fail(c, BRX_E_STATE, "error/qscore model not set");
+    if (!raw && (!c->has_ref || !c->has_params)) return fail(c, BRX_E_STATE, "reference or parameters not set");
+    if (!c->scratch) return fail(c, BRX_E_STATE, "scratch arena not set");
+    if (out_bytes) *out_bytes = 0;
+    if (n_reads == 0) return BRX_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    BrxDev dev = c->dev;
+    dev.seed = seed; dev.first_read = first_read; dev.n_reads = n_reads; dev.raw_mode = raw ? 1u : 0u;
+    Arena A; A.base = c->scratch; A.cap = c->scratch_bytes; A.used = 0;
+    const uint32_t nb64 = (n_reads + 63) / 64;
+    const uint32_t n_waves = std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
+
+    RS *rs = (RS *)A.take((size_t)n_reads * sizeof(RS));
+    uint64_t *totals = (uint64_t *)A.take(16 * sizeof(uint64_t));
+    uint32_t *order = (uint32_t *)A.take((size_t)n_reads * 4);
+    uint32_t *counters = (uint32_t *)A.take(64 * 4);        /* [0] mutate queue, [1] flags, [2..] final queues */
+    uint64_t *units_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
+    uint64_t *tboff_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
+    if (!A.ok()) return scratch_short(c, A.used + (size_t)n_reads * 200000);
+    HIPCHK(c, hipMemsetAsync(counters, 0, 64 * 4, st));
+    HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, st));
+
+    /* ---- stage: plan ---- */
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    if (raw) hipLaunchKernelGGL(k_init_raw, dim3(nb64), dim3(64), 0, st, dev, rs, d_frag_off, d_target);
+    else hipLaunchKernelGGL(k_plan_count, dim3(nb64), dim3(64), 0, st, dev, rs);
+    hipLaunchKernelGGL(k_scan_plan, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
+    int rc = read_totals(c, st, totals, 3);
+    if (rc) return rc;
+    const uint64_t tot_segs = c->h_totals[0], tot_pieces = c->h_totals[1], f_bytes = c->h_totals[2];
+    PSeg *segs = (PSeg *)A.take((size_t)(tot_segs + 1) * sizeof(PSeg));
+    PPiece *pieces = (PPiece *)A.take((size_t)(tot_pieces + 1) * sizeof(PPiece));
+    uint8_t *Fbuf = (uint8_t *)A.take((size_t)f_bytes + 64);
+    uint32_t *repl = (uint32_t *)A.take(((size_t)f_bytes + 64) * 4);
+    uint8_t *win = (uint8_t *)A.take((size_t)n_waves * c->win_bytes);
+    if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
+    if (!raw) hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces);
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+
+    /* ---- stage: build ---- */
+    if (raw) hipLaunchKernelGGL(k_copy_frags, dim3(n_reads), dim3(64), 0, st, dev, rs, d_frags, d_frag_off, Fbuf);
+    hipLaunchKernelGGL(k_build, dim3(n_reads), dim3(64), 0, st, dev, rs, segs, Fbuf, repl);
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(64), 0, st, n_reads, rs, order);
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
+
+    /* ---- stage: mutate ---- */
+    hipLaunchKernelGGL(k_mutate, dim3(n_waves), dim3(64), 0, st, dev, rs, order, counters + 0, Fbuf, repl, win,
+                       (uint64_t)c->win_bytes, counters + 1);
+    hipLaunchKernelGGL(k_scan_mut, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
+    HIPCHK(c, hipEventRecord(c->ev[3], st));
+    rc = read_totals(c, st, totals, 5);
+    if (rc) return rc;
+    {
+        uint32_t flags = 0;
+        HIPCHK(c, hipMemcpy(&flags, counters + 1, 4, hipMemcpyDeviceToHost));
+        if (flags & 1u) {                              /* an in-loop alignment did not fit its window scratch */
+            c->win_bytes *= 4;
+            return scratch_short(c, c->scratch_bytes + (size_t)n_waves * c->win_bytes);
+        }
+    }
+    const uint64_t seq_bytes = c->h_totals[3], ops_bytes = c->h_totals[4];
+    uint8_t *seqbuf = (uint8_t *)A.take((size_t)seq_bytes + 64);
+    uint8_t *opsbuf = (uint8_t *)A.take((size_t)ops_bytes + 64);
+    if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
+
+    /* ---- stage: final alignment + qscores, in chunks that fit the remaining arena ---- */
+    std::vector<uint32_t> h_order(n_reads);
+    std::vector<RS> h_rs(n_reads);
+    HIPCHK(c, hipMemcpy(h_order.data(), order, (size_t)n_reads * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost));
+    size_t tb_at = (A.used + 255) & ~(size_t)255;
+    size_t tb_cap = c->scratch_bytes > tb_at ? c->scratch_bytes - tb_at : 0;
+    uint8_t *tb_base = c->scratch + tb_at;
+    uint64_t max_units = 0, sum_units = 0;
+    for (uint32_t i = 0; i < n_reads; ++i) { max_units = std::max(max_units, h_rs[i].units); sum_units += h_rs[i].units; }
+    if ((max_units + 64) * 8 > tb_cap) {
+        size_t want = std::min<uint64_t>((sum_units + 64ull * n_reads) * 8, (uint64_t)8 << 30);
+        return scratch_short(c, tb_at + std::max<size_t>((size_t)(max_units + 64) * 8, want));
+    }
+    std::vector<uint64_t> h_tboff(n_reads);
+    std::vector<std::pair<uint32_t, uint32_t>> chunks;
+    {
+        uint32_t begin = 0; uint64_t used = 0;
+        for (uint32_t i = 0; i < n_reads; ++i) {
+            uint64_t need = ((h_rs[h_order[i]].units + 31) & ~31ull) * 8;      /* 256-byte granules */
+            if (used + need > tb_cap) { chunks.push_back({begin, i}); begin = i; used = 0; }
+            h_tboff[i] = used; used += need;
+        }
+        chunks.push_back({begin, n_reads});
+    }
+    for (uint32_t i = 0; i < n_reads; ++i) h_rs[h_order[i]].tb_off = h_tboff[i];
+    /* only tb_off changed on the host: write it back through the sorted-order staging array */
+    HIPCHK(c, hipMemcpyAsync(tboff_sorted, h_tboff.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, st));
+    (void)units_sorted;
+    hipLaunchKernelGGL(k_set_tboff, dim3(nb64), dim3(64), 0, st, n_reads, rs, order, tboff_sorted);
+    if (chunks.size() > 60) return scratch_short(c, tb_at + (size_t)std::min<uint64_t>((sum_units + 64ull * n_reads) * 8 / 8 + 1, (uint64_t)64 << 30));
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+        uint32_t b = chunks[ci].first, e = chunks[ci].second;
+        if (e == b) continue;
+        uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
+        hipLaunchKernelGGL(k_final, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 2 + ci, Fbuf, repl,
+                           seqbuf, opsbuf, tb_base);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[4], st));
+    HIPCHK(c, hipEventRecord(c->ev[5], st));
+
+    /* ---- stage: records ---- */
+    hipLaunchKernelGGL(k_recsize, dim3(nb64), dim3(64), 0, st, dev, rs, pieces);
+    hipLaunchKernelGGL(k_scan_rec, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
+    rc = read_totals(c, st, totals, 6);
+    if (rc) return rc;
+    const uint64_t rec_bytes = c->h_totals[5];
+    if (rec_bytes > out_cap) {
+        c->output_needed = rec_bytes;
+        return fail(c, BRX_E_OUTPUT, "output buffer too small: need %llu bytes", (unsigned long long)rec_bytes);
+    }
+    hipLaunchKernelGGL(k_emit, dim3(n_reads), dim3(64), 0, st, dev, rs, pieces, seqbuf, d_out);
+    hipLaunchKernelGGL(k_stats, dim3(nb64), dim3(64), 0, st, dev, rs, d_stats);
+    HIPCHK(c, hipEventRecord(c->ev[6], st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+        c->stage_ms[i] = ms;
+    }
+    if (out_bytes) *out_bytes = (size_t)rec_bytes;
+    /* a read that exhausted its 1000 tries is fatal in the reference (simulate.py:164) */
+    if (!raw) {
+        HIPCHK(c, hipMemcpy(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_reads; ++i) if (h_rs[i].status & BRX_RS_NOFRAG) {
+            snprintf(c->err, sizeof(c->err), "read %llu failed to generate a sequence fragment", (unsigned long long)(first_read + i));
+            return BRX_E_NOFRAG;
+        }
+    }
+    return BRX_OK;
+}
+
+extern "C" int brx_simulate_batch(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t n_reads,
+                                  uint8_t *d_out, size_t out_cap, brx_read_stats *d_stats,
+                                  size_t *out_bytes, void *hip_stream) {
+    if (!c || !d_out || !d_stats) return BRX_E_ARG;
+    return run_pipeline(c, seed, first_read, n_reads, false, nullptr, nullptr, nullptr, d_out, out_cap, d_stats, out_bytes,
+                        (hipStream_t)hip_stream);
+}
+
+extern "C" int brx_sequence_fragments(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t n_frags,
+                                      const uint8_t *d_frags, const uint64_t *d_frag_off, const double *d_target,
+                                      uint8_t *d_out, size_t out_cap, brx_read_stats *d_stats, size_t *out_bytes,
+                                      void *hip_stream) {
+    if (!c || !d_out || !d_stats || !d_frags || !d_frag_off || !d_target) return BRX_E_ARG;
+    return run_pipeline(c, seed, first_read, n_frags, true, d_frags, d_frag_off, d_target, d_out, out_cap, d_stats, out_bytes,
+                        (hipStream_t)hip_stream);
+}
+
+extern "C" int brx_align_batch(brx_ctx *c, uint32_t n_pairs, const uint8_t *d_queries, const uint64_t *d_q_off,
+                               const uint8_t *d_targets, const uint64_t *d_t_off, const int32_t *d_k_hint,
+                               int32_t *d_dist, uint32_t *d_ncols, uint32_t *d_nmatch, uint8_t *d_ops,
+                               const uint64_t *d_ops_off, void *hip_stream) {
+    if (!c || !d_q_off || !d_t_off || !d_k_hint || !d_dist || !d_ncols || !d_nmatch) return BRX_E_ARG;
+    if (!c->scratch) return fail(c, BRX_E_STATE, "scratch arena not set");
+    if (n_pairs == 0) return BRX_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint64_t> qo(n_pairs + 1), to(n_pairs + 1);
+    std::vector<int32_t> kh(n_pairs);
+    HIPCHK(c, hipMemcpy(qo.data(), d_q_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(to.data(), d_t_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(kh.data(), d_k_hint, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    Arena A; A.base = c->scratch; A.cap = c->scratch_bytes; A.used = 0;
+    uint64_t *scr_off = (uint64_t *)A.take((size_t)n_pairs * 8);
+    uint64_t *scr_bytes = (uint64_t *)A.take((size_t)n_pairs * 8);
+    uint32_t *counters = (uint32_t *)A.take(4096 * 4);
+    if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 26));
+    size_t at = (A.used + 255) & ~(size_t)255;
+    size_t cap = c->scratch_bytes - at;
+    std::vector<uint64_t> h_off(n_pairs), h_bytes(n_pairs);
+    std::vector<std::pair<uint32_t, uint32_t>> chunks;
+    uint32_t begin = 0; uint64_t used = 0, biggest = 0;
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        uint64_t Q = qo[i + 1] - qo[i], T = to[i + 1] - to[i];
+        if (Q >= ((uint64_t)1 << 30) || T >= ((uint64_t)1 << 30)) return fail(c, BRX_E_ARG, "sequence %u too long", i);
+        int k = kh[i] >= 0 ? kh[i] : (int)std::max(Q, T);
+        BrxGeom g = brx_make_geom((int)Q, (int)T, k);
+        uint64_t units = (Q && T && g.G) ? brx_align_units(g) : 0;
+        uint64_t need = (((Q + 31) & ~15ull) + ((T + 31) & ~15ull) + (units + 8) * 8 + 255) & ~255ull;
+        biggest = std::max(biggest, need);
+        if (used + need > cap) { chunks.push_back({begin, i}); begin = i; used = 0; }
+        h_off[i] = used; h_bytes[i] = need; used += need;
+    }
+    chunks.push_back({begin, n_pairs});
+    if (biggest > cap) return scratch_short(c, at + (size_t)biggest);
+    if (chunks.size() > 4000) return scratch_short(c, at + (size_t)biggest * 64);
+    HIPCHK(c, hipMemcpyAsync(scr_off, h_off.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(scr_bytes, h_bytes.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(counters, 0, 4096 * 4, st));
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+        uint32_t b = chunks[ci].first, e = chunks[ci].second;
+        if (e == b) continue;
+        uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
+        hipLaunchKernelGGL(k_align_batch, dim3(waves), dim3(64), 0, st, n_pairs, b, e, counters + ci, d_queries, d_q_off,
+                           d_targets, d_t_off, d_k_hint, d_dist, d_ncols, d_nmatch, d_ops, d_ops_off,
+                           c->scratch + at, scr_off, scr_bytes);
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    return BRX_OK;
+}

@@ -1,0 +1,1004 @@
+/*
+ * brx_kernels.h -- HIP kernels of the simulate hot path (gfx950, wave64).  Included once by
+ * brx_hip.hip.  Reference functions each kernel replaces are cited at the kernel.
+ *
+ * Work decomposition ("one read per wavefront"):
+ *   k_plan      1 lane  = 1 read   sequential draws of build_fragment (tiny, divergent)
+ *   k_build     1 wave  = 1 read   fragment bytes from the 2-bit reference, coalesced
+ *   k_mutate    1 wave  = 1 read   64 k-mer proposals per step, survivors applied in lane order,
+ *                                  in-loop windowed Myers alignment by the whole wave
+ *   k_final     1 wave  = 1 read   join -> banded Myers + traceback -> qscore windows -> quals
+ *   k_emit      1 wave  = 1 read   FASTQ bytes
+ * Waves of the heavy kernels are persistent and pull reads (longest first) from a device queue.
+ */
+#ifndef BRX_KERNELS_H
+#define BRX_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/brx.h"
+#include "../../include/brx_spec.h"
+#include "brx_align.h"
+
+#define BRX_ALIGN_INTERVAL 25     /* settings.ALIGNMENT_INTERVAL */
+#define BRX_ALIGN_SIZE 1000       /* settings.ALIGNMENT_SIZE     */
+#define BRX_MAX_BASE_SEGS 64
+
+enum { SEG_REF = 0, SEG_ADAPTER = 1, SEG_RANDOM = 2, SEG_JUNK = 3 };
+enum { PC_JUNK = 0, PC_RANDOM = 1, PC_REAL = 2, PC_HAIRPIN = 3 };
+
+struct PSeg { uint32_t w0, start, len, dst; };                 /* w0 = type | b<<2 (3 bits) | a<<5 */
+struct PPiece { uint32_t w0, left_over; uint64_t start, end; }; /* w0 = type | strand<<2 | contig<<3 */
+
+/* per-read working state, one per read of the batch */
+struct RS {
+    uint32_t status, n_segs, n_pieces, frag_len;
+    uint32_t n, m, ub, start_trim;
+    uint32_t end_trim, seg_off, piece_off, n_cols;
+    uint32_t n_match, loops, changes, naligns;
+    uint32_t seq_len, rec_len, hdr_len, pad_;
+    uint64_t F_off, seq_off, ops_off, units, tb_off, rec_off;
+    double target, qerr;
+};
+
+struct BrxDev {
+    brx_reference ref;
+    brx_error_model em;
+    brx_qscore_model qm;
+    brx_sim_params p;
+    uint64_t seed, first_read;
+    uint32_t n_reads, raw_mode;      /* raw_mode: sequence_fragments (no plan, raw output) */
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ uint32_t wave_bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+__device__ __forceinline__ uint64_t wave_bcast_u64(uint64_t v, int src) {
+    uint32_t lo = wave_bcast_u32((uint32_t)v, src), hi = wave_bcast_u32((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+/* inclusive scan over the 64 lanes */
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
+
+/* =============================================================================================
+ * k_plan: build_fragment (simulate.py:91-115) and everything it draws, one lane per read.
+ * Two passes with identical draws: COUNT sizes the per-read segment/piece lists, FILL writes them.
+ * ========================================================================================== */
+struct CountEmit {
+    uint32_t nseg, npiece; uint64_t len;
+    __device__ void seg(uint32_t type, uint32_t a, uint32_t b, uint32_t start, uint32_t l) { if (l) { nseg++; len += l; } }
+    __device__ void piece(uint32_t type, uint32_t contig, uint32_t strand, uint64_t s, uint64_t e, uint32_t lo) { npiece++; }
+};
+struct WriteEmit {
+    PSeg *segs; PPiece *pieces; uint32_t nseg, npiece; uint64_t len;
+    __device__ void seg(uint32_t type, uint32_t a, uint32_t b, uint32_t start, uint32_t l) {
+        if (!l) return;
+        PSeg s; s.w0 = type | (b << 2) | (a << 5); s.start = start; s.len = l; s.dst = (uint32_t)len;
+        segs[nseg++] = s; len += l;
+    }
+    __device__ void piece(uint32_t type, uint32_t contig, uint32_t strand, uint64_t s, uint64_t e, uint32_t lo) {
+        PPiece p; p.w0 = type | (strand << 2) | (contig << 3); p.left_over = lo; p.start = s; p.end = e;
+        pieces[npiece++] = p;
+    }
+};
+
+struct BaseList {
+    PSeg s[BRX_MAX_BASE_SEGS]; int n; uint64_t len; bool overflow;
+    __device__ void push(uint32_t type, uint32_t a, uint32_t b, uint32_t start, uint32_t l) {
+        if (!l) return;
+        if (n >= BRX_MAX_BASE_SEGS) { overflow = true; return; }
+        s[n].w0 = type | (b << 2) | (a << 5); s[n].start = start; s[n].len = l; s[n].dst = 0;
+        ++n; len += l;
+    }
+};
+
+/* fragment_lengths.py:47-52 */
+__device__ inline uint64_t plan_fragment_length(const brx_sim_params &p, brx_rng *g) {
+    if (p.frag_stdev == 0.0) return (uint64_t)brx_round_half_even(p.frag_mean);
+    double v = brx_std_gamma(g, p.gamma_k) * p.gamma_t;
+    int64_t L = brx_round_half_even(v);
+    return (uint64_t)(L < 1 ? 1 : L);
+}
+
+/* simulate.py:183-246 */
+template <class E>
+__device__ bool plan_real_fragment(const BrxDev &d, brx_rng *g, uint64_t length, BaseList &base, E &em) {
+    const brx_reference &r = d.ref;
+    uint32_t contig = 0;
+    if (r.n_contigs > 1) {
+        double x = brx_next_double(g) * r.total_weight;
+        while (contig < r.n_contigs - 1 && !(r.d_cum_weight[contig] > x)) ++contig;
+    }
+    uint32_t strand = (brx_next_double(g) < 0.5) ? 0u : 1u;
+    brx_contig ct = r.d_contigs[contig];
+    bool circular = ct.flags & 1u;
+    bool hairpin = strand == 0 ? ((ct.flags >> 2) & 1u) : ((ct.flags >> 1) & 1u);
+    uint64_t len_c = ct.length;
+    if (length >= len_c && !circular && !hairpin) {
+        em.piece(PC_REAL, contig, strand, 0, len_c, 0);
+        base.push(SEG_REF, contig, strand, 0, (uint32_t)len_c);
+        return true;
+    }
+    if (length > len_c && circular) return false;
+    uint64_t start = brx_next_below(g, len_c);
+    uint64_t end = start + length;
+    if (circular) {
+        em.piece(PC_REAL, contig, strand, start, end, 0);
+        if (end <= len_c) base.push(SEG_REF, contig, strand, (uint32_t)start, (uint32_t)length);
+        else {
+            base.push(SEG_REF, contig, strand, (uint32_t)start, (uint32_t)(len_c - start));
+            base.push(SEG_REF, contig, strand, 0, (uint32_t)(end - len_c));
+        }
+        return true;
+    }
+    if (end > len_c) {
+        if (hairpin) {
+            uint64_t fwd = len_c - start;
+            uint64_t left_over = length - fwd < fwd ? length - fwd : fwd;
+            em.piece(PC_HAIRPIN, contig, strand, start, len_c, (uint32_t)left_over);
+            base.push(SEG_REF, contig, strand, (uint32_t)start, (uint32_t)fwd);
+            base.push(SEG_REF, contig, strand ^ 1u, 0, (uint32_t)left_over);
+            return true;
+        }
+        end = len_c;
+    }
+    em.piece(PC_REAL, contig, strand, start, end, 0);
+    base.push(SEG_REF, contig, strand, (uint32_t)start, (uint32_t)(end - start));
+    return true;
+}
+
+/* simulate.py:148-165 */
+template <class E>
+__device__ bool plan_get_fragment(const BrxDev &d, brx_rng *g, BaseList &base, E &em, uint32_t *next_serial) {
+    const brx_sim_params &p = d.p;
+    uint64_t length = plan_fragment_length(p, g);
+    double u = brx_next_double(g);
+    if (u < p.junk_rate) {
+        uint32_t unit_len = 1u + (uint32_t)brx_next_below(g, 5);
+        uint32_t unit = 0;
+        for (uint32_t i = 0; i < unit_len; ++i) unit |= (uint32_t)brx_next_below(g, 4) << (2 * i);
+        em.piece(PC_JUNK, 0, 0, 0, 0, 0);
+        base.push(SEG_JUNK, unit, unit_len, 0, (uint32_t)length);
+        return true;
+    }
+    if (u < p.junk_rate + p.random_rate) {
+        em.piece(PC_RANDOM, 0, 0, 0, 0, 0);
+        base.push(SEG_RANDOM, (*next_serial)++, 0, 0, (uint32_t)length);
+        return true;
+    }
+    for (int attempt = 0; attempt < 1000; ++attempt)
+        if (plan_real_fragment(d, g, length, base, em)) return true;
+    return false;
+}
+
+template <class E>
+__device__ void plan_copy_range(const BaseList &base, uint64_t a, uint64_t b, E &em) {
+    uint64_t pos = 0;
+    for (int s = 0; s < base.n && pos < b; ++s) {
+        const PSeg &sg = base.s[s];
+        uint64_t lo = pos, hi = pos + sg.len;
+        pos = hi;
+        if (hi <= a) continue;
+        uint64_t x0 = a > lo ? a : lo, x1 = b < hi ? b : hi;
+        em.seg(sg.w0 & 3u, sg.w0 >> 5, (sg.w0 >> 2) & 7u, sg.start + (uint32_t)(x0 - lo), (uint32_t)(x1 - x0));
+    }
+}
+
+template <class E>
+__device__ void plan_read(const BrxDev &d, uint64_t read, E &em, uint32_t *status, double *target) {
+    const brx_sim_params &p = d.p;
+    brx_rng g;
+    brx_rng_init(&g, d.seed, read, BRX_ST_PLAN);
+    uint32_t next_serial = 2;
+    BaseList base; base.n = 0; base.len = 0; base.overflow = false;
+    *status = 0; *target = 0.0;
+
+    if (p.start_adapter_len > 0 && p.start_rate != 0.0 && p.start_amount != 0.0) {      /* simulate.py:361-370 */
+        if (brx_next_double(&g) < p.start_rate) {
+            if (p.start_amount == 1.0) base.push(SEG_ADAPTER, 0, 0, 0, p.start_adapter_len);
+            else {
+                double f = brx_beta(&g, 2.0 * p.start_amount, 2.0 - 2.0 * p.start_amount);
+                uint32_t L = (uint32_t)((double)p.start_adapter_len * f);
+                base.push(SEG_ADAPTER, 0, 0, p.start_adapter_len - L, L);
+            }
+        }
+    }
+    bool ok = plan_get_fragment(d, &g, base, em, &next_serial);
+    while (ok && brx_next_double(&g) < p.chimera_rate) {                                 /* simulate.py:101-110 */
+        if (brx_next_double(&g) < 0.25) base.push(SEG_ADAPTER, 1, 0, 0, p.end_adapter_len);
+        if (brx_next_double(&g) < 0.25) base.push(SEG_ADAPTER, 0, 0, 0, p.start_adapter_len);
+        ok = plan_get_fragment(d, &g, base, em, &next_serial);
+    }
+    if (!ok) { *status |= BRX_RS_NOFRAG; return; }
+    if (p.end_adapter_len > 0 && p.end_rate != 0.0 && p.end_amount != 0.0) {            /* simulate.py:373-381 */
+        if (brx_next_double(&g) < p.end_rate) {
+            if (p.end_amount == 1.0) base.push(SEG_ADAPTER, 1, 0, 0, p.end_adapter_len);
+            else {
+                double f = brx_beta(&g, 2.0 * p.end_amount, 2.0 - 2.0 * p.end_amount);
+                uint32_t L = (uint32_t)((double)p.end_adapter_len * f);
+                base.push(SEG_ADAPTER, 1, 0, 0, L);
+            }
+        }
+    }
+    if (base.overflow) *status |= BRX_RS_TOO_MANY_SEGS;
+    uint64_t base_len = base.len;
+    if (p.glitch_rate == 0.0) plan_copy_range(base, 0, base_len, em);                   /* simulate.py:459-482 */
+    else {
+        double p_rate = p.glitch_rate > 1.0 ? 1.0 / p.glitch_rate : 1.0;
+        double p_size = p.glitch_size > 1.0 ? 1.0 / p.glitch_size : 1.0;
+        double p_skip = p.glitch_skip > 1.0 ? 1.0 / p.glitch_skip : 1.0;
+        uint64_t i = 0;
+        for (;;) {
+            uint64_t dist = (uint64_t)brx_geometric(&g, p_rate);
+            uint64_t e = i + dist < base_len ? i + dist : base_len;
+            plan_copy_range(base, i, e, em);
+            i += dist;
+            if (i >= base_len) break;
+            if (p.glitch_size > 0.0) {
+                uint64_t sz = (uint64_t)brx_geometric(&g, p_size);
+                em.seg(SEG_RANDOM, next_serial++, 0, 0, (uint32_t)sz);
+            }
+            if (p.glitch_skip > 0.0) i += (uint64_t)brx_geometric(&g, p_skip);
+            if (i >= base_len) break;
+        }
+    }
+    if (p.identity_mode == 0) *target = p.id_max;                                       /* identities.py:76-93 */
+    else if (p.identity_mode == 1) *target = p.id_max * brx_beta(&g, p.id_a, p.id_b);
+    else {
+        for (;;) {
+            double q = p.id_a + p.id_b * brx_normal(&g);
+            double id = 1.0 - brx_exp((-q / 10.0) * 2.302585092994046);
+            if (id >= 0.0 && id <= 100.0) { *target = id; break; }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_plan_count(BrxDev d, RS *rs) {
+    uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= d.n_reads) return;
+    CountEmit em; em.nseg = 0; em.npiece = 0; em.len = 0;
+    uint32_t status; double target;
+    plan_read(d, d.first_read + r, em, &status, &target);
+    RS s; memset(&s, 0, sizeof(s));
+    s.status = status; s.n_segs = em.nseg; s.n_pieces = em.npiece; s.frag_len = (uint32_t)em.len;
+    s.n = (status & BRX_RS_NOFRAG) ? 0u : (uint32_t)em.len + 2u * (uint32_t)d.em.k;
+    s.target = target;
+    rs[r] = s;
+}
+
+__global__ void __launch_bounds__(64) k_plan_fill(BrxDev d, RS *rs, PSeg *segs, PPiece *pieces) {
+    uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= d.n_reads) return;
+    WriteEmit em; em.segs = segs + rs[r].seg_off; em.pieces = pieces + rs[r].piece_off;
+    em.nseg = 0; em.npiece = 0; em.len = 0;
+    uint32_t status; double target;
+    plan_read(d, d.first_read + r, em, &status, &target);
+}
+
+/* exclusive scans after the COUNT pass, one wave.  totals: [0]=segs [1]=pieces [2]=F bytes */
+__global__ void __launch_bounds__(64) k_scan_plan(uint32_t n_reads, RS *rs, uint64_t *totals) {
+    const int lane = lane_id();
+    uint64_t seg_run = 0, piece_run = 0, f_run = 0;
+    for (uint32_t base = 0; base < n_reads; base += 64) {
+        uint32_t r = base + lane;
+        uint32_t ns = 0, np = 0, fb = 0;
+        if (r < n_reads) { ns = rs[r].n_segs; np = rs[r].n_pieces; fb = rs[r].n ? ((rs[r].n + 16u + 15u) & ~15u) : 0u; }
+        uint32_t is = wave_incl_scan(ns), ip = wave_incl_scan(np);
+        /* F bytes can exceed 32 bits over a batch: scan in 16-byte units */
+        uint32_t iff = wave_incl_scan(fb >> 4);
+        if (r < n_reads) {
+            rs[r].seg_off = (uint32_t)(seg_run + is - ns);
+            rs[r].piece_off = (uint32_t)(piece_run + ip - np);
+            rs[r].F_off = f_run + ((uint64_t)(iff - (fb >> 4)) << 4);
+        }
+        seg_run += wave_bcast_u32(is, 63); piece_run += wave_bcast_u32(ip, 63);
+        f_run += (uint64_t)wave_bcast_u32(iff, 63) << 4;
+    }
+    if (lane == 0) { totals[0] = seg_run; totals[1] = piece_run; totals[2] = f_run; }
+}
+
+/* longest-first processing order: counting sort on n/512 (256 buckets), one wave */
+__global__ void __launch_bounds__(64) k_order(uint32_t n_reads, const RS *rs, uint32_t *order) {
+    __shared__ uint32_t hist[256];
+    const int lane = lane_id();
+    for (int b = lane; b < 256; b += 64) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t r = lane; r < n_reads; r += 64) {
+        uint32_t key = rs[r].n >> 9; if (key > 255) key = 255;
+        atomicAdd(&hist[255 - key], 1u);
+    }
+    __syncthreads();
+    if (lane == 0) { uint32_t run = 0; for (int b = 0; b < 256; ++b) { uint32_t c = hist[b]; hist[b] = run; run += c; } }
+    __syncthreads();
+    for (uint32_t r = lane; r < n_reads; r += 64) {
+        uint32_t key = rs[r].n >> 9; if (key > 255) key = 255;
+        uint32_t slot = atomicAdd(&hist[255 - key], 1u);
+        order[slot] = r;
+    }
+}
+
+/* =============================================================================================
+ * k_build: the string slicing of get_real_fragment (simulate.py:206-246), reverse_complement
+ * (misc.py:56-71), junk/random/adapter pieces and the two random pads of sequence_fragment
+ * (simulate.py:260).  One wave per read; consecutive lanes take consecutive bases.
+ * ========================================================================================== */
+__device__ inline uint32_t ref_code_acgt(const brx_reference &r, const brx_contig &ct, uint32_t strand, uint32_t pos) {
+    uint64_t f = strand == 0 ? (uint64_t)pos : (uint64_t)ct.length - 1 - pos;
+    uint64_t gidx = ct.base_off + f;
+    uint32_t code = (r.d_packed[gidx >> 4] >> (2 * (gidx & 15))) & 3u;
+    return strand == 0 ? code : (3u - code);       /* complement of ACGT codes 0..3 */
+}
+
+__global__ void __launch_bounds__(64) k_build(BrxDev d, const RS *rs, const PSeg *segs, uint8_t *Fbuf, uint32_t *repl) {
+    const uint32_t r = blockIdx.x;
+    const int lane = lane_id();
+    const RS s = rs[r];
+    if (s.n == 0) return;
+    const uint64_t read = d.first_read + r;
+    const int k = d.em.k;
+    uint8_t *F = Fbuf + s.F_off;
+    uint32_t *rp = repl + s.F_off;
+    const uint32_t n = s.n;
+    for (uint32_t x = lane; x < n + 16; x += 64) { if (x < n) rp[x] = 0; else F[x] = 0xFF; }
+    if (lane < k) {
+        F[lane] = (uint8_t)brx_random_base(d.seed, read, 0, (uint64_t)lane);
+        F[n - k + lane] = (uint8_t)brx_random_base(d.seed, read, 1, (uint64_t)lane);
+    }
+    if (d.raw_mode) return;                       /* fragment bytes were copied by k_copy_frags */
+    uint8_t *dst0 = F + k;
+    for (uint32_t si = 0; si < s.n_segs; ++si) {
+        const PSeg sg = segs[s.seg_off + si];
+        const uint32_t type = sg.w0 & 3u, b = (sg.w0 >> 2) & 7u, a = sg.w0 >> 5;
+        uint8_t *dst = dst0 + sg.dst;
+        if (type == SEG_REF) {
+            const brx_contig ct = d.ref.d_contigs[a];
+            for (uint32_t x = lane; x < sg.len; x += 64) dst[x] = (uint8_t)ref_code_acgt(d.ref, ct, b, sg.start + x);
+            /* non-ACGT runs overlapping the forward range of this segment */
+            if (d.ref.n_exceptions) {
+                uint64_t g0, g1;
+                if (b == 0) { g0 = ct.base_off + sg.start; g1 = g0 + sg.len; }
+                else { g1 = ct.base_off + ((uint64_t)ct.length - sg.start); g0 = g1 - sg.len; }
+                uint32_t lo = 0, hi = d.ref.n_exceptions;
+                while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.ref.d_exceptions[mid].end > g0) hi = mid; else lo = mid + 1; }
+                for (uint32_t e = lo; e < d.ref.n_exceptions; ++e) {
+                    const brx_exception ex = d.ref.d_exceptions[e];
+                    if (ex.start >= g1) break;
+                    uint64_t o0 = ex.start > g0 ? ex.start : g0, o1 = ex.end < g1 ? ex.end : g1;
+                    uint8_t code = (uint8_t)(b == 0 ? ex.code : d.ref.comp[ex.code & 15u]);
+                    for (uint64_t gg = o0 + lane; gg < o1; gg += 64) {
+                        uint64_t x = b == 0 ? gg - g0 : (g1 - 1 - gg);
+                        dst[x] = code;
+                    }
+                }
+            }
+        } else if (type == SEG_ADAPTER) {
+            const uint8_t *ad = a == 0 ? d.p.d_start_adapter : d.p.d_end_adapter;
+            for (uint32_t x = lane; x < sg.len; x += 64) dst[x] = ad[sg.start + x];
+        } else if (type == SEG_RANDOM) {
+            for (uint32_t x = lane; x < sg.len; x += 64) dst[x] = (uint8_t)brx_random_base(d.seed, read, a, (uint64_t)sg.start + x);
+        } else {                                  /* junk: `a` = repeat unit (2 bits/base), `b` = its length */
+            for (uint32_t x = lane; x < sg.len; x += 64) dst[x] = (uint8_t)((a >> (2 * ((sg.start + x) % b))) & 3u);
+        }
+    }
+}
+
+/* sequence_fragments entry: copy caller fragments behind the start pad */
+__global__ void __launch_bounds__(64) k_copy_frags(BrxDev d, const RS *rs, const uint8_t *frags, const uint64_t *frag_off, uint8_t *Fbuf) {
+    const uint32_t r = blockIdx.x;
+    const RS s = rs[r];
+    uint8_t *F = Fbuf + s.F_off + d.em.k;
+    const uint8_t *src = frags + frag_off[r];
+    for (uint32_t x = lane_id(); x < s.frag_len; x += 64) F[x] = src[x];
+}
+
+__global__ void __launch_bounds__(64) k_init_raw(BrxDev d, RS *rs, const uint64_t *frag_off, const double *target) {
+    uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= d.n_reads) return;
+    RS s; memset(&s, 0, sizeof(s));
+    s.frag_len = (uint32_t)(frag_off[r + 1] - frag_off[r]);
+    s.n = s.frag_len + 2u * (uint32_t)d.em.k;
+    s.target = target[r];
+    rs[r] = s;
+}
+
+/* =============================================================================================
+ * error model lookup: ErrorModel.add_errors_to_kmer / add_one_random_change
+ * (error_model.py:135-176).  rep[j] = 0x80000000 | len<<24 | pool offset, or 0 if unchanged.
+ * ========================================================================================== */
+__device__ inline void dev_random_change(const uint8_t *kmer, int k, uint32_t w3, uint32_t *rep) {
+    uint32_t type = w3 % 3u;
+    uint32_t pos = (w3 / 3u) % (uint32_t)k;
+    uint32_t rest = w3 / (3u * (uint32_t)k);
+    uint32_t o = kmer[pos];
+    uint32_t word;
+    if (type == 0) {
+        uint32_t nb = o < 4 ? ((o + 1u + rest % 3u) & 3u) : (rest & 3u);
+        word = 0x80000000u | (1u << 24) | nb;
+    } else if (type == 1) {
+        uint32_t after = rest & 1u, nb = (rest >> 1) & 3u;
+        uint32_t x = after ? o : nb, y = after ? nb : o;
+        word = 0x80000000u | (2u << 24) | (16u + 2u * (16u * x + y));
+    } else word = 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (j < k) rep[j] = ((uint32_t)j == pos) ? word : 0u;
+}
+
+/* returns false if the k-mer is unchanged */
+__device__ inline bool dev_choose_alt(const brx_error_model &em, const uint8_t *kmer, uint32_t w2, uint32_t w3, uint32_t *rep) {
+    const int k = em.k;
+    if (em.type == 0) { dev_random_change(kmer, k, w3, rep); return true; }
+    uint32_t row = 0; bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (j < k) { bad |= kmer[j] > 3; row = (row << 2) | (kmer[j] & 3u); }
+    if (bad) { dev_random_change(kmer, k, w3, rep); return true; }
+    uint32_t st = em.d_self_thr[row];
+    if (w2 < st) return false;                                   /* the common case: unchanged */
+    uint32_t a0 = em.d_row_off[row], a1 = em.d_row_off[row + 1];
+    if (a0 == a1) { dev_random_change(kmer, k, w3, rep); return true; }
+    uint32_t a = a0;
+    while (a < a1 && !(w2 < em.d_thr[a])) ++a;
+    if (a == a1) {
+        if (em.d_thr[a1 - 1] == 0xFFFFFFFFu) a = a1 - 1;
+        else { dev_random_change(kmer, k, w3, rep); return true; }
+    }
+    uint32_t o = em.d_desc[a];
+    uint32_t diff = (uint32_t)em.d_pool[o] | ((uint32_t)em.d_pool[o + 1] << 8);
+    if (diff == 0) return false;
+    uint32_t coff = o + 2u + (uint32_t)k;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (j < k) {
+        uint32_t len = em.d_pool[o + 2 + (uint32_t)j];
+        rep[j] = ((diff >> j) & 1u) ? (0x80000000u | (len << 24) | coff) : 0u;
+        coff += len;
+    }
+    return true;
+}
+
+__device__ __forceinline__ uint32_t rep_len(uint32_t w) { return w ? ((w >> 24) & 0x7Fu) : 1u; }
+__device__ __forceinline__ uint32_t rep_cost(uint32_t w) { uint32_t l = (w >> 24) & 0x7Fu; return w ? (l ? l : 1u) : 0u; }
+
+__device__ inline uint8_t rep_char(const brx_error_model &em, uint32_t w, uint32_t x) {
+    uint32_t off = w & 0x00FFFFFFu;
+    if (off < 16) return (uint8_t)off;
+    if (off < BRX_POOL_PREAMBLE) { uint32_t v = (off - 16) >> 1; return (uint8_t)(x == 0 ? (v >> 4) : (v & 15u)); }
+    return em.d_pool[off + x];
+}
+
+/* join(new_fragment_bases[a:b]) by the whole wave: writes the characters to out (may be null for
+ * sizing), returns the total length; *cost receives an upper bound on the edit distance between
+ * F[a:b] and the joined string (1 per substitution/deletion, len per insertion string). */
+__device__ inline uint32_t wave_join(const brx_error_model &em, const uint8_t *F, const uint32_t *repl,
+                                     uint32_t a, uint32_t b, uint8_t *out, uint32_t *cost) {
+    const int lane = lane_id();
+    uint32_t run = 0, c = 0;
+    for (uint32_t base = a; base < b; base += 64) {
+        uint32_t p = base + lane;
+        uint32_t w = 0, len = 0;
+        if (p < b) { w = repl[p]; len = rep_len(w); c += rep_cost(w); }
+        uint32_t inc = wave_incl_scan(len);
+        if (out && p < b) {
+            uint32_t o = run + inc - len;
+            if (!w) out[o] = F[p];
+            else for (uint32_t x = 0; x < len; ++x) out[o + x] = rep_char(em, w, x);
+        }
+        run += wave_bcast_u32(inc, 63);
+    }
+    if (cost) *cost = wave_sum(c);
+    return run;
+}
+
+/* =============================================================================================
+ * k_mutate: the while-loop of sequence_fragment (simulate.py:272-346).
+ * 64 iterations of the loop are PROPOSED at once (iteration t = loops + lane draws its k-mer
+ * position and alternative from Philox block t); proposals that leave the k-mer unchanged only
+ * advance loop_count, the others are APPLIED one by one in iteration order with the running
+ * error estimate, so the result equals the sequential loop exactly.
+ * Per-wave scratch (win): [0,4096) query copy, [4096, 4096+tgt_cap) target, then traceback store.
+ * ========================================================================================== */
+struct MutScratch { uint8_t *base; uint64_t bytes; };
+
+__global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t *order, uint32_t *queue,
+                                                uint8_t *Fbuf, uint32_t *repl, uint8_t *win_base, uint64_t win_bytes,
+                                                uint32_t *flags) {
+    const int lane = lane_id();
+    const brx_error_model &em = d.em;
+    const int k = em.k;
+    uint8_t *win = win_base + (uint64_t)blockIdx.x * win_bytes;
+    for (;;) {
+        uint32_t qi = 0;
+        if (lane == 0) qi = atomicAdd(queue, 1u);
+        qi = wave_bcast_u32(qi, 0);
+        if (qi >= d.n_reads) break;
+        const uint32_t r = order[qi];
+        RS s = rs[r];
+        if (s.n == 0) continue;
+        const uint64_t read = d.first_read + r;
+        const uint32_t n = s.n;
+        const uint8_t *F = Fbuf + s.F_off;
+        uint32_t *rp = repl + s.F_off;
+        const double target = s.target;
+        const double dn = (double)n;
+        double errors = 0.0;
+        uint64_t loops = 0;
+        uint32_t change = 0, nalign = 0;
+        const uint64_t max_i = (uint64_t)n - 1 - (uint64_t)k;
+        const double need = dn * (1.0 - target);
+        const uint64_t loop_cap = 100ull * (uint64_t)n;
+        bool done = need < 0.5;
+        while (!done) {
+            if (loops + 1 > loop_cap) { loops += 1; break; }
+            double est = 1.0 - errors / dn;
+            if ((double)change > 0.9 * dn || est <= target) { loops += 1; break; }
+            uint64_t room = loop_cap - loops;
+            uint32_t B = room < 64 ? (uint32_t)room : 64u;
+            /* ---- propose ---- */
+            uint32_t rep[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rep[j] = 0;
+            bool live = false;
+            uint64_t ipos = 0;
+            if ((uint32_t)lane < B) {
+                uint32_t w[4];
+                brx_draw4(d.seed, read, BRX_ST_MUT, loops + (uint64_t)lane, w);
+                ipos = brx_mulhi64(((uint64_t)w[1] << 32) | w[0], max_i + 1);
+                uint8_t kmer[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) kmer[j] = j < k ? F[ipos + j] : 0;
+                live = dev_choose_alt(em, kmer, w[2], w[3], rep);
+            }
+            unsigned long long surv = __ballot(live);
+            /* ---- apply survivors in iteration order ---- */
+            while (surv) {
+                int l = __ffsll((long long)surv) - 1;
+                surv &= surv - 1;
+                const uint64_t i0 = wave_bcast_u64(ipos, l);
+                const double scale = est * brx_sqrt(est);
+                for (int j = 0; j < k; ++j) {
+                    uint32_t mine = 0;
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) mine = (jj == j) ? rep[jj] : mine;
+                    uint32_t w = wave_bcast_u32(mine, l);
+                    if (!w) continue;
+                    uint64_t pos = i0 + (uint64_t)j;
+                    uint32_t cur = rp[pos];
+                    if (cur) continue;
+                    if (lane == 0) rp[pos] = w;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    change += 1;
+                    uint32_t len = (w >> 24) & 0x7Fu;
+                    errors += (double)(len < 2 ? 1u : len - 1u) * scale;
+                    if (change % BRX_ALIGN_INTERVAL == 0) {
+                        uint32_t a = 0, b = n;
+                        if (n > BRX_ALIGN_SIZE) {
+                            uint32_t ww[4];
+                            brx_draw4(d.seed, read, BRX_ST_WIN, (uint64_t)nalign, ww);
+                            a = (uint32_t)brx_mulhi64(((uint64_t)ww[1] << 32) | ww[0], (uint64_t)n - BRX_ALIGN_SIZE + 1);
+                            b = a + BRX_ALIGN_SIZE;
+                        }
+                        nalign += 1;
+                        __builtin_amdgcn_s_waitcnt(0);
+                        uint32_t cost = 0;
+                        uint32_t tl = wave_join(em, F, rp, a, b, nullptr, &cost);
+                        uint32_t ql = b - a;
+                        uint64_t qpad = ((uint64_t)ql + 16 + 15) & ~15ull, tpad = ((uint64_t)tl + 16 + 15) & ~15ull;
+                        int ncols = 0, nmatch = 0; bool nospace = false;
+                        if (qpad + tpad + 64 > win_bytes) nospace = true;
+                        else {
+                            uint8_t *qb = win, *tbuf = win + qpad;
+                            for (uint32_t x = lane; x < ql + 16; x += 64) qb[x] = x < ql ? F[a + x] : 0xFF;
+                            for (uint32_t x = lane; x < 16; x += 64) tbuf[tl + x] = 0xFE;
+                            wave_join(em, F, rp, a, b, tbuf, nullptr);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __builtin_amdgcn_s_waitcnt(0);
+                            uint2 *tb = reinterpret_cast<uint2 *>(win + qpad + tpad);
+                            uint64_t cap = (win_bytes - qpad - tpad) / 8;
+                            bool ok = brx_wave_align(qb, (int)ql, tbuf, (int)tl, (int)cost, tb, cap, nullptr, &ncols, &nmatch, &nospace);
+                            if (!ok && !nospace) s.status |= BRX_RS_BAND;
+                        }
+                        if (nospace) { if (lane == 0) atomicOr(&flags[0], 1u); }
+                        double id = ncols ? (double)nmatch / (double)ncols : 0.0;
+                        if (n <= BRX_ALIGN_SIZE) errors = (1.0 - id) * dn;
+                        else {
+                            double est_err = (1.0 - id) * dn;
+                            double weight = (double)BRX_ALIGN_SIZE / dn;
+                            errors = est_err * weight + errors * (1.0 - weight);
+                        }
+                    }
+                }
+                /* top-of-loop tests of the iteration that follows this survivor */
+                double est2 = 1.0 - errors / dn;
+                if ((double)change > 0.9 * dn || est2 <= target) { loops += (uint64_t)l + 2; done = true; break; }
+                est = est2;
+            }
+            if (done) break;
+            loops += B;
+            if (B < 64) { loops += 1; break; }
+        }
+        /* epilogue: lengths of the mutated read, trims (simulate.py:348-349), proven distance bound */
+        __builtin_amdgcn_s_waitcnt(0);
+        uint32_t cost = 0;
+        uint32_t m = wave_join(em, F, rp, 0, n, nullptr, &cost);
+        uint32_t st = 0, et = 0;
+        if (lane < k) { st = rep_len(rp[lane]); et = rep_len(rp[n - k + lane]); }
+        st = wave_sum(st); et = wave_sum(et);
+        if (lane == 0) {
+            RS *o = &rs[r];
+            o->status = s.status; o->m = m; o->ub = cost; o->start_trim = st; o->end_trim = et;
+            o->loops = (uint32_t)loops; o->changes = change; o->naligns = nalign;
+            BrxGeom g = brx_make_geom((int)m, (int)n, (int)cost);
+            uint64_t units = (m == 0) ? 0 : brx_align_units(g);
+            if (m && g.G == 0) { o->status |= BRX_RS_BAND; units = 0; }
+            o->units = units + ((uint64_t)m * 4 + 7) / 8 + 2;     /* + col_of[] for the qscore stage */
+        }
+    }
+}
+
+/* offsets for the final stage.  totals: [3]=seq bytes [4]=ops bytes */
+__global__ void __launch_bounds__(64) k_scan_mut(uint32_t n_reads, RS *rs, uint64_t *totals) {
+    const int lane = lane_id();
+    uint64_t seq_run = 0, ops_run = 0;
+    for (uint32_t base = 0; base < n_reads; base += 64) {
+        uint32_t r = base + lane;
+        uint32_t sb = 0, ob = 0;
+        if (r < n_reads && rs[r].n) {
+            sb = 2u * ((rs[r].m + 16u + 15u) >> 4);                 /* seq + qual, 16-byte units */
+            ob = (rs[r].m + rs[r].n + 16u + 15u) >> 4;
+        }
+        uint32_t is = wave_incl_scan(sb), io = wave_incl_scan(ob);
+        if (r < n_reads) { rs[r].seq_off = (seq_run + is - sb) << 4; rs[r].ops_off = (ops_run + io - ob) << 4; }
+        seq_run += wave_bcast_u32(is, 63); ops_run += wave_bcast_u32(io, 63);
+    }
+    if (lane == 0) { totals[3] = seq_run << 4; totals[4] = ops_run << 4; }
+}
+
+/* rs[order[i]].tb_off = off[i]: the host lays traceback stores out in processing order */
+__global__ void __launch_bounds__(64) k_set_tboff(uint32_t n, RS *rs, const uint32_t *order, const uint64_t *off) {
+    uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) rs[order[i]].tb_off = off[i];
+}
+
+/* =============================================================================================
+ * k_final: the tail of sequence_fragment (simulate.py:348-356) and get_qscores
+ * (qscore_model.py:32-75): join the mutated read, align it against the perfect fragment, walk the
+ * per-column ops to give every read base its <=k-op cigar window, look the window up with the
+ * centre-preserving fallback of get_qscore (:273-287) and sample a score.
+ * ========================================================================================== */
+__device__ inline int64_t qs_lookup(const brx_qscore_model &qm, uint64_t key) {
+    uint64_t h = key * 0x9E3779B97F4A7C15ull;
+    uint32_t slot = (uint32_t)(h >> 32) & (qm.hash_size - 1);
+    for (;;) {
+        uint64_t kk = qm.d_hash_key[slot];
+        if (kk == key) return (int64_t)qm.d_hash_row[slot];
+        if (kk == ~0ull) return -1;
+        slot = (slot + 1) & (qm.hash_size - 1);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
+                                               uint32_t *queue, const uint8_t *Fbuf, const uint32_t *repl,
+                                               uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base) {
+    __shared__ uint32_t qhist[256];
+    const int lane = lane_id();
+    const brx_error_model &em = d.em;
+    const brx_qscore_model &qm = d.qm;
+    const int k = em.k;
+    for (;;) {
+        uint32_t qi = 0;
+        if (lane == 0) qi = q_begin + atomicAdd(queue, 1u);
+        qi = wave_bcast_u32(qi, 0);
+        if (qi >= q_end) break;
+        const uint32_t r = order[qi];
+        RS s = rs[r];
+        if (s.n == 0) continue;
+        const uint64_t read = d.first_read + r;
+        const uint32_t n = s.n, m = s.m;
+        const uint8_t *F = Fbuf + s.F_off;
+        const uint32_t *rp = repl + s.F_off;
+        uint8_t *seq = seqbuf + s.seq_off;
+        uint8_t *qual = seq + (((uint64_t)m + 16 + 15) & ~15ull);
+        uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
+        uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
+        uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
+        uint32_t *col_of = reinterpret_cast<uint32_t *>(tb + (s.units - col_units));
+
+        wave_join(em, F, rp, 0, n, seq, nullptr);
+        for (uint32_t x = lane; x < 16; x += 64) seq[m + x] = 0xFE;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        int ncols = 0, nmatch = 0; bool nospace = false;
+        bool ok = brx_wave_align(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch, &nospace);
+        if (!ok) s.status |= BRX_RS_BAND;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint8_t *ops = ops_end - ncols;
+
+        /* column of every read base (qscore_model.py:46-52) */
+        uint32_t run = 0;
+        for (uint32_t base = 0; base < (uint32_t)ncols; base += 64) {
+            uint32_t c = base + lane;
+            uint32_t nd = (c < (uint32_t)ncols && ops[c] != BRX_OP_D) ? 1u : 0u;
+            uint32_t inc = wave_incl_scan(nd);
+            if (nd) col_of[run + inc - 1] = c;
+            run += wave_bcast_u32(inc, 63);
+        }
+        for (int b = lane; b < 256; b += 64) qhist[b] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+
+        const uint32_t margin = (uint32_t)(qm.k - 1) / 2;
+        const uint32_t maxrun = (1u << qm.gap_bits) - 1u;
+        bool qmiss = false;
+        if (ok) for (uint32_t sp = lane; sp < m; sp += 64) {
+            uint32_t h = margin;
+            if (sp < h) h = sp;
+            if (m - 1 - sp < h) h = m - 1 - sp;
+            /* ops and D-runs of the widest window, centre at index `margin` of the local arrays */
+            uint32_t c0 = col_of[sp - h], c1 = col_of[sp + h];
+            uint64_t opsbits = 0;     /* 2 bits per op, op i of the widest window at bits 2i  */
+            uint64_t gapbits = 0;     /* 4 bits per gap (saturated), gap after op i at bits 4i */
+            {
+                uint32_t idx = 0, rn = 0;
+                for (uint32_t cc = c0; cc <= c1; ++cc) {
+                    uint32_t op = ops[cc];
+                    if (op == BRX_OP_D) { rn += 1; continue; }
+                    if (idx > 0) { uint32_t code = rn >= maxrun ? maxrun : rn; gapbits |= (uint64_t)code << (4 * (idx - 1)); }
+                    opsbits |= (uint64_t)op << (2 * idx);
+                    rn = 0; idx += 1;
+                }
+            }
+            uint32_t score = 0; bool found = false;
+            uint32_t hh = h;
+            for (;;) {
+                /* sub-window of 2hh+1 ops centred on op index h of the widest window */
+                uint32_t first = h - hh, cnt = 2 * hh + 1;
+                uint64_t key = (uint64_t)cnt << 56;
+                int shift = 0;
+                for (uint32_t x = 0; x < cnt; ++x) {
+                    if (x > 0) { key |= ((gapbits >> (4 * (first + x - 1))) & 15ull) << shift; shift += qm.gap_bits; }
+                    key |= ((opsbits >> (2 * (first + x))) & 3ull) << shift; shift += 2;
+                }
+                int64_t row = qs_lookup(qm, key);
+                if (row >= 0) {
+                    uint32_t e0 = qm.d_row_off[row], e1 = qm.d_row_off[row + 1];
+                    uint32_t w4[4];
+                    brx_draw4(d.seed, read, BRX_ST_QS, (uint64_t)(sp >> 2), w4);
+                    uint32_t u = w4[sp & 3];
+                    uint32_t e = e0;
+                    while (e < e1 - 1 && !(u < qm.d_thr[e])) ++e;
+                    score = qm.d_score[e]; found = true;
+                    break;
+                }
+                if (hh == 0) break;
+                hh -= 1;
+            }
+            if (!found) qmiss = true;
+            qual[sp] = (uint8_t)(score + 33);
+            atomicAdd(&qhist[score & 255u], 1u);
+        }
+        if (__ballot(qmiss)) s.status |= BRX_RS_QMISS;
+        __syncthreads();
+        if (lane == 0) {
+            double qerr = 0.0;
+            for (int q = 0; q < 256; ++q) {
+                uint32_t c = qhist[q];
+                if (c) qerr += (double)c * brx_exp(-(double)q / 10.0 * 2.302585092994046);
+            }
+            uint32_t lo = s.start_trim, hi = m >= s.end_trim ? m - s.end_trim : 0;
+            if (s.end_trim == 0) hi = 0;
+            if (hi < lo) hi = lo;
+            RS *o = &rs[r];
+            o->status = s.status | ((hi - lo) == 0 ? BRX_RS_EMPTY : 0u);
+            o->n_cols = (uint32_t)ncols; o->n_match = (uint32_t)nmatch; o->qerr = qerr;
+            o->seq_len = hi - lo;
+        }
+        __syncthreads();
+    }
+}
+
+/* =============================================================================================
+ * FASTQ record (simulate.py:73-82).  One templated writer is used both to size and to write.
+ * ========================================================================================== */
+struct CountSink { uint32_t n; __device__ void put(uint8_t) { n++; } };
+struct ByteSink { uint8_t *p; uint32_t n; __device__ void put(uint8_t c) { p[n++] = c; } };
+
+template <class S> __device__ void put_str(S &s, const char *t) { while (*t) s.put((uint8_t)*t++); }
+template <class S> __device__ void put_dec(S &s, uint64_t v) {
+    char buf[24]; int n = 0;
+    do { buf[n++] = (char)('0' + (v % 10)); v /= 10; } while (v);
+    while (n) s.put((uint8_t)buf[--n]);
+}
+template <class S> __device__ void put_hex(S &s, uint32_t v, int digits) {
+    for (int i = digits - 1; i >= 0; --i) { uint32_t x = (v >> (4 * i)) & 15u; s.put((uint8_t)(x < 10 ? '0' + x : 'a' + x - 10)); }
+}
+/* round(v*1000) to nearest, ties to even, on the exact binary value of v (what '%.3f' prints) */
+__device__ inline uint64_t milli_round(double v) {
+    uint64_t u = brx_d2u(v);
+    int e = (int)((u >> 52) & 0x7FF);
+    uint64_t mant = u & 0xFFFFFFFFFFFFFull;
+    if (e == 0) return 0;                      /* zero / subnormal */
+    mant |= 1ull << 52;
+    int sh = 1075 - e;                         /* v = mant * 2^-sh */
+    uint64_t scaled = mant * 1000ull;
+    if (sh <= 0) return scaled << (-sh);
+    if (sh >= 64) return 0;
+    uint64_t q = scaled >> sh, rem = scaled & ((1ull << sh) - 1ull), half = 1ull << (sh - 1);
+    if (rem > half || (rem == half && (q & 1ull))) q += 1;
+    return q;
+}
+template <class S>
+__device__ void put_header(S &s, const BrxDev &d, uint64_t read, const RS &r, const PPiece *pieces) {
+    uint32_t w[4];
+    brx_draw4(d.seed, read, BRX_ST_NAME, 0, w);            /* uuid.UUID(int=getrandbits(128)) */
+    s.put('@');
+    put_hex(s, w[0], 8); s.put('-'); put_hex(s, w[1] >> 16, 4); s.put('-'); put_hex(s, w[1] & 0xFFFFu, 4); s.put('-');
+    put_hex(s, w[2] >> 16, 4); s.put('-'); put_hex(s, w[2] & 0xFFFFu, 4); put_hex(s, w[3], 8); s.put(' ');
+    for (uint32_t i = 0; i < r.n_pieces; ++i) {
+        const PPiece pc = pieces[r.piece_off + i];
+        uint32_t type = pc.w0 & 3u, strand = (pc.w0 >> 2) & 1u, contig = pc.w0 >> 3;
+        if (i > 0) put_str(s, "chimera ");
+        if (type == PC_JUNK) put_str(s, "junk_seq ");
+        else if (type == PC_RANDOM) put_str(s, "random_seq ");
+        else {
+            const brx_contig ct = d.ref.d_contigs[contig];
+            for (uint32_t x = 0; x < ct.name_len; ++x) s.put(d.ref.d_names[ct.name_off + x]);
+            s.put(','); s.put(strand ? '-' : '+'); put_str(s, "strand,");
+            put_dec(s, pc.start); s.put('-'); put_dec(s, pc.end);
+            if (type == PC_HAIRPIN) { put_str(s, " (hairpin) 0-"); put_dec(s, pc.left_over); }
+            s.put(' ');
+        }
+    }
+    put_str(s, "length="); put_dec(s, r.seq_len);
+    put_str(s, " error-free_length="); put_dec(s, r.frag_len);
+    put_str(s, " read_identity=");
+    double ident = r.n_cols ? (double)r.n_match / (double)r.n_cols : 0.0;
+    uint64_t mr = milli_round(ident * 100.0);
+    put_dec(s, mr / 1000); s.put('.');
+    uint32_t fr = (uint32_t)(mr % 1000);
+    s.put((uint8_t)('0' + fr / 100)); s.put((uint8_t)('0' + (fr / 10) % 10)); s.put((uint8_t)('0' + fr % 10));
+    s.put('%'); s.put('\n');
+}
+
+__global__ void __launch_bounds__(64) k_recsize(BrxDev d, RS *rs, const PPiece *pieces) {
+    uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= d.n_reads) return;
+    RS s = rs[r];
+    uint32_t len = 0, hl = 0;
+    if (s.n && s.seq_len && !(s.status & BRX_RS_NOFRAG)) {
+        if (d.raw_mode) len = 2 * s.seq_len;
+        else {
+            CountSink c; c.n = 0;
+            put_header(c, d, d.first_read + r, s, pieces);
+            hl = c.n; len = hl + 2 * s.seq_len + 4;
+        }
+    }
+    rs[r].rec_len = len; rs[r].hdr_len = hl;
+}
+
+/* record offsets in read order.  totals[5] = output bytes */
+__global__ void __launch_bounds__(64) k_scan_rec(uint32_t n_reads, RS *rs, uint64_t *totals) {
+    const int lane = lane_id();
+    uint64_t run = 0;
+    for (uint32_t base = 0; base < n_reads; base += 64) {
+        uint32_t r = base + lane;
+        uint32_t len = r < n_reads ? rs[r].rec_len : 0u;
+        /* a 64-read group stays far below 2^32 bytes */
+        uint32_t inc = wave_incl_scan(len);
+        if (r < n_reads) rs[r].rec_off = run + inc - len;
+        run += wave_bcast_u32(inc, 63);
+    }
+    if (lane == 0) totals[5] = run;
+}
+
+__global__ void __launch_bounds__(64) k_emit(BrxDev d, const RS *rs, const PPiece *pieces, const uint8_t *seqbuf, uint8_t *out) {
+    const uint32_t r = blockIdx.x;
+    const int lane = lane_id();
+    const RS s = rs[r];
+    if (s.rec_len == 0) return;
+    uint8_t *o = out + s.rec_off;
+    const uint8_t *seq = seqbuf + s.seq_off + s.start_trim;
+    const uint8_t *qual = seqbuf + s.seq_off + (((uint64_t)s.m + 16 + 15) & ~15ull) + s.start_trim;
+    const uint32_t L = s.seq_len;
+    if (d.raw_mode) {
+        for (uint32_t x = lane; x < L; x += 64) { o[x] = seq[x]; o[L + x] = qual[x]; }
+        return;
+    }
+    if (lane == 0) { ByteSink b; b.p = o; b.n = 0; put_header(b, d, d.first_read + r, s, pieces); }
+    uint8_t *p = o + s.hdr_len;
+    for (uint32_t x = lane; x < L; x += 64) { p[x] = d.ref.sym[seq[x] & 15u]; p[L + 3 + x] = qual[x]; }
+    if (lane == 0) { p[L] = '\n'; p[L + 1] = '+'; p[L + 2] = '\n'; p[2 * L + 3] = '\n'; }
+}
+
+__global__ void __launch_bounds__(64) k_stats(BrxDev d, const RS *rs, brx_read_stats *out) {
+    uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= d.n_reads) return;
+    const RS s = rs[r];
+    brx_read_stats o;
+    o.status = s.status; o.frag_len = s.frag_len; o.seq_len = s.seq_len; o.n_cols = s.n_cols; o.n_match = s.n_match;
+    o.edit_distance = s.n_cols - s.n_match; o.loop_count = s.loops; o.change_count = s.changes; o.n_alignments = s.naligns;
+    o.rec_len = s.rec_len; o.rec_off = s.rec_off; o.target_identity = s.target; o.qerr_sum = s.qerr;
+    out[r] = o;
+}
+
+/* =============================================================================================
+ * brx_align_batch: one pair per wave, band doubling when no bound is given.
+ * Per-pair scratch at scr + off[i]: [query copy][target copy][traceback store].
+ * Bytes are permuted so that A,C,G,T,N become 0..4 (equality is preserved).
+ * ========================================================================================== */
+__device__ __forceinline__ uint8_t perm_byte(uint8_t b) {
+    switch (b) {
+    case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'N': return 4;
+    case 0: return 'A'; case 1: return 'C'; case 2: return 'G'; case 3: return 'T'; case 4: return 'N';
+    default: return b;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_align_batch(uint32_t n_pairs, uint32_t p_begin, uint32_t p_end, uint32_t *queue,
+                                                     const uint8_t *qs, const uint64_t *q_off, const uint8_t *ts, const uint64_t *t_off,
+                                                     const int32_t *k_hint, int32_t *dist, uint32_t *ncols_out, uint32_t *nmatch_out,
+                                                     uint8_t *ops_out, const uint64_t *ops_off,
+                                                     uint8_t *scr, const uint64_t *scr_off, const uint64_t *scr_bytes) {
+    const int lane = lane_id();
+    for (;;) {
+        uint32_t i = 0;
+        if (lane == 0) i = p_begin + atomicAdd(queue, 1u);
+        i = wave_bcast_u32(i, 0);
+        if (i >= p_end) break;
+        const uint32_t Q = (uint32_t)(q_off[i + 1] - q_off[i]), T = (uint32_t)(t_off[i + 1] - t_off[i]);
+        const uint8_t *q = qs + q_off[i], *t = ts + t_off[i];
+        uint8_t *base = scr + scr_off[i];
+        const uint64_t bytes = scr_bytes[i];
+        uint64_t qpad = ((uint64_t)Q + 16 + 15) & ~15ull, tpad = ((uint64_t)T + 16 + 15) & ~15ull;
+        uint8_t *qb = base, *tbuf = base + qpad;
+        for (uint32_t x = lane; x < Q + 16; x += 64) qb[x] = x < Q ? perm_byte(q[x]) : 0xFF;
+        for (uint32_t x = lane; x < T + 16; x += 64) tbuf[x] = x < T ? perm_byte(t[x]) : 0xFE;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        uint2 *tb = reinterpret_cast<uint2 *>(base + qpad + tpad);
+        uint64_t cap = bytes > qpad + tpad ? (bytes - qpad - tpad) / 8 : 0;
+        uint8_t *ops_end = ops_out ? ops_out + ops_off[i] + Q + T : nullptr;
+        int kh = k_hint[i];
+        int kk = kh >= 0 ? kh : 64;
+        int maxk = (int)(Q > T ? Q : T);
+        int nc = 0, nm = 0; bool ok = false, nospace = false;
+        for (;;) {
+            ok = brx_wave_align(qb, (int)Q, tbuf, (int)T, kk, tb, cap, ops_end, &nc, &nm, &nospace);
+            if (ok || nospace || kh >= 0 || kk >= maxk) break;
+            kk = kk * 2 > maxk ? maxk : kk * 2;
+        }
+        if (ok && ops_end) {
+            /* move the ops (written backwards from the end of the area) to its start */
+            uint8_t *dst = ops_out + ops_off[i];
+            const uint8_t *src = ops_end - nc;
+            if (dst != src) for (uint32_t base2 = 0; base2 < (uint32_t)nc; base2 += 64) {
+                uint32_t x = base2 + lane;
+                uint8_t v = x < (uint32_t)nc ? src[x] : 0;
+                __builtin_amdgcn_s_waitcnt(0);
+                if (x < (uint32_t)nc) dst[x] = v;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+        }
+        if (lane == 0) {
+            dist[i] = ok ? (nc - nm) : (nospace ? -2 : -1);
+            ncols_out[i] = ok ? (uint32_t)nc : 0u;
+            nmatch_out[i] = ok ? (uint32_t)nm : 0u;
+        }
+    }
+}
+
+#endif /* BRX_KERNELS_H */

@@ -1,0 +1,104 @@
+"""Shared fixtures for the parity tests: synthetic references, model tables, engines."""
+import collections
+import io
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from badread_amd.engine import SimParams  # noqa: E402
+from badread_amd.error_model import ErrorModel  # noqa: E402
+from badread_amd.qscore_model import QScoreModel  # noqa: E402
+from badread_amd.reference import PackedReference  # noqa: E402
+
+NULL = io.StringIO()
+_cache = {}
+
+
+def random_dna(rng, n, alphabet='ACGT'):
+    return ''.join(np.array(list(alphabet))[rng.integers(0, len(alphabet), n)])
+
+
+def small_reference(seed=1, with_n=True):
+    """Three contigs: circular chromosome, circular plasmid with depth, linear contig with N/IUPAC runs and hairpins."""
+    key = ('ref', seed, with_n)
+    if key in _cache:
+        return _cache[key]
+    rng = np.random.default_rng(seed)
+    chrom = random_dna(rng, 60000)
+    plasmid = random_dna(rng, 4000)
+    lin = list(random_dna(rng, 30000))
+    if with_n:
+        lin[100:400] = 'N' * 300
+        lin[5000:5003] = 'RYK'
+        lin[29000:29950] = 'N' * 950
+    seqs = collections.OrderedDict([('chrom', chrom), ('plasmid', plasmid), ('lin1', ''.join(lin)),
+                                    ('hp', random_dna(rng, 9000))])
+    depths = {'chrom': 1.0, 'plasmid': 5.0, 'lin1': 1.5, 'hp': 1.0}
+    circ = {'chrom': True, 'plasmid': True, 'lin1': False, 'hp': False}
+    hl = {'chrom': False, 'plasmid': False, 'lin1': False, 'hp': True}
+    hr = {'chrom': False, 'plasmid': False, 'lin1': False, 'hp': True}
+    pref = PackedReference.from_seqs(seqs, depths, circ, hl, hr)
+    _cache[key] = (pref, seqs)
+    return _cache[key]
+
+
+def error_tables(name):
+    key = ('em', name)
+    if key not in _cache:
+        _cache[key] = ErrorModel(name, output=NULL).tables()
+    return _cache[key]
+
+
+def qscore_tables(name):
+    key = ('qm', name)
+    if key not in _cache:
+        _cache[key] = QScoreModel(name, output=NULL).tables()
+    return _cache[key]
+
+
+def configure(engine, pref, em='random', qm='ideal', params=None):
+    engine.set_reference(pref)
+    engine.set_error_model(error_tables(em))
+    engine.set_qscore_model(qscore_tables(qm))
+    engine.set_params(params or SimParams())
+    return engine
+
+
+def oracle_engine():
+    from pyoracle import OracleEngine
+    return OracleEngine()
+
+
+def hip_engine():
+    from badread_amd.engine import default_engine
+    return default_engine()
+
+
+def first_diff(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    n = min(len(a), len(b))
+    d = np.flatnonzero(a[:n] != b[:n])
+    if len(d):
+        return int(d[0])
+    return n if len(a) != len(b) else -1
+
+
+def mutate_seq(rng, s, rate):
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < rate / 3:
+            continue
+        if r < 2 * rate / 3:
+            out.append('ACGT'[rng.integers(0, 4)])
+            continue
+        out.append(ch)
+        if r < rate:
+            out.append('ACGT'[rng.integers(0, 4)])
+    return ''.join(out)

@@ -1,0 +1,85 @@
+"""
+GPU parity: the full per-read path (brx_simulate_batch, brx_sequence_fragments) against the CPU
+oracle on the same seeds -- FASTQ bytes and every per-read statistic must be identical.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from badread_amd.engine import SimParams
+
+pytestmark = pytest.mark.gpu
+
+STAT_FIELDS = ('status', 'frag_len', 'seq_len', 'n_cols', 'n_match', 'edit_distance', 'loop_count',
+               'change_count', 'n_alignments', 'rec_len', 'rec_off', 'target_identity', 'qerr_sum')
+
+
+def _compare(em, qm, params, seed, first, n, with_n=True):
+    pref, _ = H.small_reference(with_n=with_n)
+    hip = H.configure(H.hip_engine(), pref, em, qm, params)
+    orc = H.configure(H.oracle_engine(), pref, em, qm, params)
+    out_h, st_h = hip.simulate_batch(seed, first, n)
+    out_o, st_o = orc.simulate_batch(seed, first, n)
+    for f in STAT_FIELDS:
+        bad = np.flatnonzero(st_h[f] != st_o[f])
+        assert len(bad) == 0, f'{f} differs for reads {bad[:8]}: hip {st_h[f][bad[:4]]} oracle {st_o[f][bad[:4]]}'
+    fd = H.first_diff(out_h, out_o)
+    assert fd < 0, f'FASTQ bytes differ at offset {fd}'
+    return out_h, st_h
+
+
+def test_random_ideal_small_reads():
+    p = SimParams(frag_mean=1500, frag_stdev=1200, identity_mode=1, id_a=20.0, id_b=2.0, id_max=0.98)
+    _compare('random', 'ideal', p, seed=42, first=0, n=200)
+
+
+def test_random_random_models_constant_identity():
+    p = SimParams(frag_mean=800, frag_stdev=0, identity_mode=0, id_max=0.9, glitch_rate=500, glitch_size=10, glitch_skip=10,
+                  chimera_rate=0.2, junk_rate=0.1, random_rate=0.1)
+    _compare('random', 'random', p, seed=7, first=1000, n=200)
+
+
+def test_nanopore2023_default_parameters():
+    p = SimParams(frag_mean=6000, frag_stdev=5000)
+    _compare('nanopore2023', 'nanopore2023', p, seed=42, first=0, n=150)
+
+
+def test_pacbio2021_qscore_identity():
+    p = SimParams(frag_mean=5000, frag_stdev=4000, identity_mode=2, id_a=30.0, id_b=3.0)
+    _compare('pacbio2021', 'pacbio2021', p, seed=3, first=50, n=100)
+
+
+def test_low_identity_and_no_adapters():
+    p = SimParams(frag_mean=2000, frag_stdev=1500, identity_mode=1, id_a=8.0, id_b=3.0, id_max=0.9,
+                  start_adapter='', end_adapter='', glitch_rate=0)
+    _compare('nanopore2018', 'nanopore2018', p, seed=11, first=0, n=80)
+
+
+def test_batch_split_invariance():
+    pref, _ = H.small_reference()
+    p = SimParams(frag_mean=1500, frag_stdev=1200)
+    hip = H.configure(H.hip_engine(), pref, 'nanopore2023', 'nanopore2023', p)
+    whole, st = hip.simulate_batch(5, 0, 96)
+    whole = whole.copy()
+    a, _ = hip.simulate_batch(5, 0, 40)
+    a = a.copy()
+    b, _ = hip.simulate_batch(5, 40, 56)
+    assert bytes(whole) == bytes(a) + bytes(b)
+
+
+def test_sequence_fragments_matches_oracle():
+    rng = np.random.default_rng(3)
+    pref, _ = H.small_reference()
+    hip = H.configure(H.hip_engine(), pref, 'nanopore2023', 'nanopore2023')
+    orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023')
+    frags = [rng.integers(0, 4, int(L)).astype(np.uint8) for L in (60, 1, 999, 1000, 1001, 3000, 12000)]
+    targets = [1.0, 0.9, 0.95, 0.8, 0.9, 0.97, 0.93]
+    res_h, st_h = hip.sequence_fragments(9, 100, frags, targets)
+    res_o, st_o = orc.sequence_fragments(9, 100, frags, targets)
+    for i, ((sh, qh), (so, qo)) in enumerate(zip(res_h, res_o)):
+        assert H.first_diff(sh, so) < 0, f'fragment {i}: sequence differs'
+        assert H.first_diff(qh, qo) < 0, f'fragment {i}: qualities differ'
+    for f in ('seq_len', 'n_cols', 'n_match', 'loop_count', 'change_count', 'n_alignments', 'qerr_sum'):
+        assert (st_h[f] == st_o[f]).all(), f
+    # identity 1.0 returns the fragment untouched (test_simulate.py:45-51)
+    assert H.first_diff(res_h[0][0], frags[0]) < 0
