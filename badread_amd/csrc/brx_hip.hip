@@ -62,23 +62,39 @@ struct Arena {
 
 extern "C" const char *brx_version(void) { return "brx-hip 0.1 (gfx950)"; }
 
+static char g_create_err[512] = "";
+
+static int create_fail(brx_ctx *c, const char *what, hipError_t e) {
+    snprintf(g_create_err, sizeof(g_create_err), "brx_create: %s failed: %s (%d)", what, hipGetErrorString(e), (int)e);
+    if (c) {
+        for (int i = 0; i <= BRX_STAGE_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+        if (c->h_totals) hipHostFree(c->h_totals);
+        free(c);
+    }
+    return BRX_E_HIP;
+}
+
 extern "C" int brx_create(int device_id, brx_ctx **out) {
     if (!out) return BRX_E_ARG;
+    g_create_err[0] = 0;
     brx_ctx *c = (brx_ctx *)calloc(1, sizeof(brx_ctx));
     if (!c) return BRX_E_ARG;
     c->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess) { free(c); return BRX_E_HIP; }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { free(c); return BRX_E_HIP; }
-    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e;
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return create_fail(c, "hipSetDevice", e);
+    int n_cu = 0;
+    if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device_id)) != hipSuccess)
+        return create_fail(c, "hipDeviceGetAttribute(MultiprocessorCount)", e);
+    c->n_cu = n_cu > 0 ? n_cu : 256;
     const char *w = getenv("BRX_WAVES_PER_CU");
     c->waves_per_cu = w ? atoi(w) : 16;
     if (c->waves_per_cu < 1) c->waves_per_cu = 1;
     const char *wb = getenv("BRX_WIN_KB");
     c->win_bytes = (uint64_t)(wb ? atoi(wb) : 256) << 10;
-    if (hipHostMalloc((void **)&c->h_totals, 16 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { free(c); return BRX_E_HIP; }
+    if ((e = hipHostMalloc((void **)&c->h_totals, 16 * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess)
+        return create_fail(c, "hipHostMalloc", e);
     for (int i = 0; i <= BRX_STAGE_COUNT; ++i)
-        if (hipEventCreate(&c->ev[i]) != hipSuccess) { free(c); return BRX_E_HIP; }
+        if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     c->err[0] = 0;
     *out = c;
     return BRX_OK;
@@ -91,7 +107,7 @@ extern "C" void brx_destroy(brx_ctx *c) {
     free(c);
 }
 
-extern "C" const char *brx_last_error(const brx_ctx *c) { return c ? c->err : "null context"; }
+extern "C" const char *brx_last_error(const brx_ctx *c) { return c ? c->err : g_create_err; }
 
 extern "C" int brx_set_reference(brx_ctx *c, const brx_reference *r) {
     if (!c || !r) return BRX_E_ARG;

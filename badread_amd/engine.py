@@ -257,7 +257,7 @@ class HipEngine(EngineBase):
         ctx = ctypes.c_void_p()
         rc = self.lib.brx_create(device, ctypes.byref(ctx))
         if rc != 0:
-            raise BrxError(rc, 'brx_create failed')
+            raise BrxError(rc, self.lib.brx_last_error(None).decode('latin-1', 'replace') or 'brx_create failed')
         self.ctx = ctx
         self._scratch = None
         self._out = None

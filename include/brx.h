@@ -177,7 +177,7 @@ typedef struct brx_ctx brx_ctx;
 /* ------------------------------------------------------------------ entry points */
 int brx_create(int device_id, brx_ctx **out);
 void brx_destroy(brx_ctx *ctx);
-const char *brx_last_error(const brx_ctx *ctx);
+const char *brx_last_error(const brx_ctx *ctx);   /* ctx == NULL: why the last brx_create failed */
 const char *brx_version(void);
 
 int brx_set_reference(brx_ctx *ctx, const brx_reference *ref);
