@@ -38,6 +38,12 @@
 #define BRX_OP_I 2
 #define BRX_OP_D 3
 
+/* debug progress words (pinned host memory, system-scope stores); prog == nullptr in normal runs */
+#define BRX_PROG(prog, slot, val)                                                                   \
+    do { if ((prog) && (threadIdx.x & 63) == 0 && blockIdx.x < 8)                                    \
+             __hip_atomic_store((prog) + 8 * blockIdx.x + (slot), (uint32_t)(val), __ATOMIC_RELAXED,  \
+                                __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+
 struct BrxGeom {
     int Q, T;          /* query rows, target columns                              */
     int dlo, dhi;      /* band of diagonals i-j                                   */
@@ -110,7 +116,7 @@ __device__ inline uint32_t brx_eq_slow(const uint8_t *Qs, int Q, int w, uint32_t
  * ------------------------------------------------------------------------------------------- */
 template <int G>
 __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
-                                  const BrxGeom g, uint2 *__restrict__ tb) {
+                                  const BrxGeom g, uint2 *__restrict__ tb, uint32_t *prog = nullptr) {
     constexpr bool REGPEQ = true;
     constexpr int PG = G;
     const int lane = threadIdx.x & 63;
@@ -132,6 +138,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
     uint32_t cbuf = 0, cnext = 0;
 
     for (int t = 1; t <= g.t_end; ++t) {
+        BRX_PROG(prog, 4, t);
         int packed = (s_last << 3) | (active_last ? 4 : 0) | (hout_last + 1);
         int nb = __shfl(packed, (lane + 63) & 63, 64);
         int j = t - s;
@@ -224,13 +231,16 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
  * ------------------------------------------------------------------------------------------- */
 __device__ inline bool brx_align_traceback(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                            const BrxGeom g, const uint2 *__restrict__ tb,
-                                           uint8_t *ops_end, int *n_cols, int *n_match) {
+                                           uint8_t *ops_end, int *n_cols, int *n_match, uint32_t *prog = nullptr) {
     const int lane = threadIdx.x & 63;
     int i = g.Q, j = g.T;
     int pos = 0, nmatch = 0;
     bool ok = true;
     const int shiftR = 31 - __clz(g.R);          /* R is a power of two */
+    long long guard = (long long)g.Q + (long long)g.T + 8;   /* every round retires >= 1 column */
     while (i > 0 && j > 0) {
+        if (--guard < 0) { ok = false; break; }
+        BRX_PROG(prog, 5, (uint32_t)guard);
         int ci = i - lane, cj = j - lane;
         bool valid = ci >= 1 && cj >= 1;
         bool inband = false, up = false, left = false, eq = false;
@@ -349,7 +359,8 @@ __device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32
     }
 }
 
-__device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *Ts, const BrxGeom &g, uint2 *tb) {
+__device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *Ts, const BrxGeom &g, uint2 *tb,
+                                             uint32_t *prog = nullptr) {
     if (g.G > BRX_REGPEQ_MAXG) {
         uint32_t *peq = reinterpret_cast<uint32_t *>(tb + brx_tb_units(g));
         uint2 *st = tb + brx_tb_units(g) + ((uint64_t)5 * (uint64_t)g.NW * 4 + 7) / 8;
@@ -360,9 +371,9 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
         return;
     }
     switch (g.G) {
-    case 1: brx_align_forward<1>(Qs, Ts, g, tb); break;
-    case 2: brx_align_forward<2>(Qs, Ts, g, tb); break;
-    default: brx_align_forward<4>(Qs, Ts, g, tb); break;
+    case 1: brx_align_forward<1>(Qs, Ts, g, tb, prog); break;
+    case 2: brx_align_forward<2>(Qs, Ts, g, tb, prog); break;
+    default: brx_align_forward<4>(Qs, Ts, g, tb, prog); break;
     }
 }
 
@@ -370,7 +381,7 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
  * Handles empty inputs.  All lanes of the wave must call; results are wave-uniform. */
 __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *Ts, int T, int k,
                                       uint2 *tb, uint64_t tb_cap_units, uint8_t *ops_end,
-                                      int *n_cols, int *n_match, bool *no_space) {
+                                      int *n_cols, int *n_match, bool *no_space, uint32_t *prog = nullptr) {
     const int lane = threadIdx.x & 63;
     *no_space = false;
     if (Q == 0 || T == 0) {
@@ -383,10 +394,14 @@ __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *T
     }
     BrxGeom g = brx_make_geom(Q, T, k);
     if (g.G == 0 || brx_align_units(g) > tb_cap_units) { *no_space = true; *n_cols = 0; *n_match = 0; return false; }
-    brx_align_forward_any(Qs, Ts, g, tb);
+    BRX_PROG(prog, 3, 1);
+    BRX_PROG(prog, 6, (uint32_t)g.t_end);
+    brx_align_forward_any(Qs, Ts, g, tb, prog);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);      /* stores of this wave visible to its own later loads */
-    bool ok = brx_align_traceback(Qs, Ts, g, tb, ops_end, n_cols, n_match);
+    BRX_PROG(prog, 3, 2);
+    bool ok = brx_align_traceback(Qs, Ts, g, tb, ops_end, n_cols, n_match, prog);
+    BRX_PROG(prog, 3, 3);
     if (ok && (*n_cols - *n_match) > k) ok = false;
     return ok;
 }

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <vector>
@@ -30,9 +31,11 @@ struct brx_ctx {
     size_t scratch_bytes;
     size_t scratch_needed, output_needed;
     uint64_t win_bytes;
-    uint64_t *h_totals;          /* pinned, 16 x u64 */
-    hipEvent_t ev[BRX_STAGE_COUNT + 1];
+    uint64_t *h_totals;          /* pinned, 16 x u64 followed by 64 x u32 debug progress words */
+    uint32_t *h_prog, *d_prog;   /* host / device views of the progress words */
+    hipEvent_t ev_b[BRX_STAGE_COUNT], ev_e[BRX_STAGE_COUNT];   /* begin / end of each stage on the launch stream */
     float stage_ms[BRX_STAGE_COUNT];
+    uint32_t final_launches;
     char err[512];
 };
 
@@ -49,6 +52,9 @@ static int fail(brx_ctx *c, int code, const char *fmt, ...) {
         hipError_t e_ = (call);                                                                      \
         if (e_ != hipSuccess) return fail((c), BRX_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+
+static bool brx_debug() { static int v = -1; if (v < 0) { const char *e = getenv("BRX_DEBUG"); v = (e && *e && *e != '0') ? 1 : 0; } return v == 1; }
+#define DBG(...) do { if (brx_debug()) { fprintf(stderr, "[brx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 struct Arena {
     uint8_t *base; size_t cap; size_t used;
@@ -67,8 +73,11 @@ static char g_create_err[512] = "";
 static int create_fail(brx_ctx *c, const char *what, hipError_t e) {
     snprintf(g_create_err, sizeof(g_create_err), "brx_create: %s failed: %s (%d)", what, hipGetErrorString(e), (int)e);
     if (c) {
-        for (int i = 0; i <= BRX_STAGE_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
-        if (c->h_totals) hipHostFree(c->h_totals);
+        for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
+            if (c->ev_b[i]) (void)hipEventDestroy(c->ev_b[i]);
+            if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]);
+        }
+        if (c->h_totals) (void)hipHostFree(c->h_totals);
         free(c);
     }
     return BRX_E_HIP;
@@ -91,10 +100,17 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     if (c->waves_per_cu < 1) c->waves_per_cu = 1;
     const char *wb = getenv("BRX_WIN_KB");
     c->win_bytes = (uint64_t)(wb ? atoi(wb) : 256) << 10;
-    if ((e = hipHostMalloc((void **)&c->h_totals, 16 * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess)
+    if ((e = hipHostMalloc((void **)&c->h_totals, 16 * sizeof(uint64_t) + 64 * sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess)
         return create_fail(c, "hipHostMalloc", e);
-    for (int i = 0; i <= BRX_STAGE_COUNT; ++i)
-        if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    c->h_prog = (uint32_t *)(c->h_totals + 16);
+    memset(c->h_prog, 0, 64 * sizeof(uint32_t));
+    void *dp = nullptr;
+    if ((e = hipHostGetDevicePointer(&dp, c->h_prog, 0)) != hipSuccess) return create_fail(c, "hipHostGetDevicePointer", e);
+    c->d_prog = (uint32_t *)dp;
+    for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
+        if ((e = hipEventCreate(&c->ev_b[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+        if ((e = hipEventCreate(&c->ev_e[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    }
     c->err[0] = 0;
     *out = c;
     return BRX_OK;
@@ -102,8 +118,11 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
 
 extern "C" void brx_destroy(brx_ctx *c) {
     if (!c) return;
-    for (int i = 0; i <= BRX_STAGE_COUNT; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
-    if (c->h_totals) hipHostFree(c->h_totals);
+    for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
+        if (c->ev_b[i]) (void)hipEventDestroy(c->ev_b[i]);
+        if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]);
+    }
+    if (c->h_totals) (void)hipHostFree(c->h_totals);
     free(c);
 }
 
@@ -141,10 +160,31 @@ extern "C" int brx_last_stage_ms(const brx_ctx *c, float ms[BRX_STAGE_COUNT]) {
     return BRX_OK;
 }
 
+/* wait for the stream; with BRX_DEBUG set, poll instead and on a stall print the kernel's progress
+ * words and leave the process (a hung kernel must not take the GPU box down with it) */
+static int wait_stream(brx_ctx *c, hipStream_t st, const char *what) {
+    if (!brx_debug()) { HIPCHK(c, hipStreamSynchronize(st)); return BRX_OK; }
+    const char *w = getenv("BRX_WATCHDOG_S");
+    int limit_ms = (w ? atoi(w) : 15) * 1000;
+    for (int ms = 0;; ms += 20) {
+        hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return BRX_OK;
+        if (e != hipErrorNotReady) return fail(c, BRX_E_HIP, "%s: %s", what, hipGetErrorString(e));
+        if (ms >= limit_ms) {
+            fprintf(stderr, "[brx] WATCHDOG: %s stalled; progress words:", what);
+            for (int i = 0; i < 64; ++i) fprintf(stderr, "%s%u", (i % 8) ? " " : " | ", c->h_prog[i]);
+            fprintf(stderr, "\n"); fflush(stderr);
+            _exit(99);
+        }
+        usleep(20000);
+    }
+}
+
+extern "C" uint32_t brx_last_final_launches(const brx_ctx *c) { return c ? c->final_launches : 0; }
+
 static int read_totals(brx_ctx *c, hipStream_t st, const uint64_t *d_totals, int n) {
     HIPCHK(c, hipMemcpyAsync(c->h_totals, d_totals, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    return BRX_OK;
+    return wait_stream(c, st, "pipeline stage");
 }
 
 static int scratch_short(brx_ctx *c, size_t needed) {
@@ -181,7 +221,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, st));
 
     /* ---- stage: plan ---- */
-    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_PLAN], st));
     if (raw) hipLaunchKernelGGL(k_init_raw, dim3(nb64), dim3(64), 0, st, dev, rs, d_frag_off, d_target);
     else hipLaunchKernelGGL(k_plan_count, dim3(nb64), dim3(64), 0, st, dev, rs);
     hipLaunchKernelGGL(k_scan_plan, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
@@ -195,19 +235,23 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     uint8_t *win = (uint8_t *)A.take((size_t)n_waves * c->win_bytes);
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
     if (!raw) hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces);
-    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_PLAN], st));
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_BUILD], st));
 
     /* ---- stage: build ---- */
     if (raw) hipLaunchKernelGGL(k_copy_frags, dim3(n_reads), dim3(64), 0, st, dev, rs, d_frags, d_frag_off, Fbuf);
     hipLaunchKernelGGL(k_build, dim3(n_reads), dim3(64), 0, st, dev, rs, segs, Fbuf, repl);
     hipLaunchKernelGGL(k_order, dim3(1), dim3(64), 0, st, n_reads, rs, order);
-    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_BUILD], st));
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_MUTATE], st));
 
     /* ---- stage: mutate ---- */
     hipLaunchKernelGGL(k_mutate, dim3(n_waves), dim3(64), 0, st, dev, rs, order, counters + 0, Fbuf, repl, win,
                        (uint64_t)c->win_bytes, counters + 1);
+    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_MUTATE], st));
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_SCAN], st));
     hipLaunchKernelGGL(k_scan_mut, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
-    HIPCHK(c, hipEventRecord(c->ev[3], st));
+    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_SCAN], st));
     rc = read_totals(c, st, totals, 5);
     if (rc) return rc;
     {
@@ -253,6 +297,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     HIPCHK(c, hipMemcpyAsync(tboff_sorted, h_tboff.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, st));
     (void)units_sorted;
     hipLaunchKernelGGL(k_set_tboff, dim3(nb64), dim3(64), 0, st, n_reads, rs, order, tboff_sorted);
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_FINAL], st));
     if (chunks.size() > 60) return scratch_short(c, tb_at + (size_t)std::min<uint64_t>((sum_units + 64ull * n_reads) * 8 / 8 + 1, (uint64_t)64 << 30));
     for (size_t ci = 0; ci < chunks.size(); ++ci) {
         uint32_t b = chunks[ci].first, e = chunks[ci].second;
@@ -261,8 +306,8 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         hipLaunchKernelGGL(k_final, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 2 + ci, Fbuf, repl,
                            seqbuf, opsbuf, tb_base);
     }
-    HIPCHK(c, hipEventRecord(c->ev[4], st));
-    HIPCHK(c, hipEventRecord(c->ev[5], st));
+    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_FINAL], st));
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_EMIT], st));
 
     /* ---- stage: records ---- */
     hipLaunchKernelGGL(k_recsize, dim3(nb64), dim3(64), 0, st, dev, rs, pieces);
@@ -276,14 +321,15 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     }
     hipLaunchKernelGGL(k_emit, dim3(n_reads), dim3(64), 0, st, dev, rs, pieces, seqbuf, d_out);
     hipLaunchKernelGGL(k_stats, dim3(nb64), dim3(64), 0, st, dev, rs, d_stats);
-    HIPCHK(c, hipEventRecord(c->ev[6], st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_EMIT], st));
+    { int rcw = wait_stream(c, st, "k_final/k_emit"); if (rcw) return rcw; }
     HIPCHK(c, hipGetLastError());
     for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
         float ms = 0.f;
-        hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+        (void)hipEventElapsedTime(&ms, c->ev_b[i], c->ev_e[i]);
         c->stage_ms[i] = ms;
     }
+    c->final_launches = (uint32_t)chunks.size();
     if (out_bytes) *out_bytes = (size_t)rec_bytes;
     /* a read that exhausted its 1000 tries is fatal in the reference (simulate.py:164) */
     if (!raw) {
@@ -322,11 +368,13 @@ extern "C" int brx_align_batch(brx_ctx *c, uint32_t n_pairs, const uint8_t *d_qu
     if (n_pairs == 0) return BRX_OK;
     hipStream_t st = (hipStream_t)hip_stream;
     HIPCHK(c, hipSetDevice(c->device));
+    DBG("align_batch: %u pairs", n_pairs);
     std::vector<uint64_t> qo(n_pairs + 1), to(n_pairs + 1);
     std::vector<int32_t> kh(n_pairs);
     HIPCHK(c, hipMemcpy(qo.data(), d_q_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(to.data(), d_t_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(kh.data(), d_k_hint, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    DBG("align_batch: offsets copied");
     Arena A; A.base = c->scratch; A.cap = c->scratch_bytes; A.used = 0;
     uint64_t *scr_off = (uint64_t *)A.take((size_t)n_pairs * 8);
     uint64_t *scr_bytes = (uint64_t *)A.take((size_t)n_pairs * 8);
@@ -340,9 +388,19 @@ extern "C" int brx_align_batch(brx_ctx *c, uint32_t n_pairs, const uint8_t *d_qu
     for (uint32_t i = 0; i < n_pairs; ++i) {
         uint64_t Q = qo[i + 1] - qo[i], T = to[i + 1] - to[i];
         if (Q >= ((uint64_t)1 << 30) || T >= ((uint64_t)1 << 30)) return fail(c, BRX_E_ARG, "sequence %u too long", i);
-        int k = kh[i] >= 0 ? kh[i] : (int)std::max(Q, T);
-        BrxGeom g = brx_make_geom((int)Q, (int)T, k);
-        uint64_t units = (Q && T && g.G) ? brx_align_units(g) : 0;
+        /* the band-doubling rounds of the kernel (k = 64, 128, ... capped at max(Q,T)) do not need
+           monotonically more traceback store: size the pair for the largest of them */
+        uint64_t units = 0;
+        if (Q && T) {
+            const int maxk = (int)std::max(Q, T);
+            int k = kh[i] >= 0 ? kh[i] : std::min(maxk, 64);
+            for (;;) {
+                BrxGeom g = brx_make_geom((int)Q, (int)T, k);
+                if (g.G) units = std::max(units, brx_align_units(g));
+                if (kh[i] >= 0 || k >= maxk) break;
+                k = k * 2 > maxk ? maxk : k * 2;
+            }
+        }
         uint64_t need = (((Q + 31) & ~15ull) + ((T + 31) & ~15ull) + (units + 8) * 8 + 255) & ~255ull;
         biggest = std::max(biggest, need);
         if (used + need > cap) { chunks.push_back({begin, i}); begin = i; used = 0; }
@@ -358,11 +416,14 @@ extern "C" int brx_align_batch(brx_ctx *c, uint32_t n_pairs, const uint8_t *d_qu
         uint32_t b = chunks[ci].first, e = chunks[ci].second;
         if (e == b) continue;
         uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
+        DBG("align_batch: chunk %zu pairs [%u,%u) waves %u", ci, b, e, waves);
         hipLaunchKernelGGL(k_align_batch, dim3(waves), dim3(64), 0, st, n_pairs, b, e, counters + ci, d_queries, d_q_off,
                            d_targets, d_t_off, d_k_hint, d_dist, d_ncols, d_nmatch, d_ops, d_ops_off,
-                           c->scratch + at, scr_off, scr_bytes);
+                           c->scratch + at, scr_off, scr_bytes, brx_debug() ? c->d_prog : (uint32_t *)nullptr);
     }
-    HIPCHK(c, hipStreamSynchronize(st));
+    DBG("align_batch: launched, waiting");
+    { int rcw = wait_stream(c, st, "k_align_batch"); if (rcw) return rcw; }
     HIPCHK(c, hipGetLastError());
+    DBG("align_batch: done");
     return BRX_OK;
 }

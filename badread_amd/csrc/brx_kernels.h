@@ -58,6 +58,28 @@ __device__ __forceinline__ uint64_t wave_bcast_u64(uint64_t v, int src) {
     uint32_t lo = wave_bcast_u32((uint32_t)v, src), hi = wave_bcast_u32((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
 }
+/* A value every lane of the wave holds identically (queue index, lengths, loop flags): moving it
+ * to an SGPR lets the compiler keep the control flow that depends on it scalar (s_cbranch) instead
+ * of exec-masked, and frees the VGPRs.  Lane 0 must be active. */
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+__device__ __forceinline__ uint64_t uni(uint64_t v) {
+    uint32_t lo = uni((uint32_t)v), hi = uni((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+/* Pop one index from a device work queue for the whole wave.  Deliberately NOT written as
+ * `if (lane == 0) v = atomicAdd(q, 1); v = broadcast(v)`: hipcc threads the lane-0 branch through
+ * the enclosing persistent loop, after which lanes 1..63 run the loop body on their own with a
+ * stale index and every wave-level operation (shuffles, ballots) sees a partial exec mask --
+ * observed as a hang of k_align_batch on gfx950.  Every lane takes part in the atomic instead
+ * (lanes 1..63 add zero; the backend's atomic optimizer folds it into one atomic per wave). */
+__device__ __forceinline__ uint32_t wave_pop(uint32_t *queue) {
+    uint32_t old = atomicAdd(queue, lane_id() == 0 ? 1u : 0u);
+    return uni(old);
+}
+
 /* inclusive scan over the 64 lanes */
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     const int lane = lane_id();
@@ -519,9 +541,7 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
     const int k = em.k;
     uint8_t *win = win_base + (uint64_t)blockIdx.x * win_bytes;
     for (;;) {
-        uint32_t qi = 0;
-        if (lane == 0) qi = atomicAdd(queue, 1u);
-        qi = wave_bcast_u32(qi, 0);
+        const uint32_t qi = wave_pop(queue);
         if (qi >= d.n_reads) break;
         const uint32_t r = order[qi];
         RS s = rs[r];
@@ -697,9 +717,7 @@ __global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *
     const brx_qscore_model &qm = d.qm;
     const int k = em.k;
     for (;;) {
-        uint32_t qi = 0;
-        if (lane == 0) qi = q_begin + atomicAdd(queue, 1u);
-        qi = wave_bcast_u32(qi, 0);
+        const uint32_t qi = q_begin + wave_pop(queue);
         if (qi >= q_end) break;
         const uint32_t r = order[qi];
         RS s = rs[r];
@@ -929,7 +947,7 @@ __global__ void __launch_bounds__(64) k_stats(BrxDev d, const RS *rs, brx_read_s
     const RS s = rs[r];
     brx_read_stats o;
     o.status = s.status; o.frag_len = s.frag_len; o.seq_len = s.seq_len; o.n_cols = s.n_cols; o.n_match = s.n_match;
-    o.edit_distance = s.n_cols - s.n_match; o.loop_count = s.loops; o.change_count = s.changes; o.n_alignments = s.naligns;
+    o.padded_len = s.m; o.loop_count = s.loops; o.change_count = s.changes; o.n_alignments = s.naligns;
     o.rec_len = s.rec_len; o.rec_off = s.rec_off; o.target_identity = s.target; o.qerr_sum = s.qerr;
     out[r] = o;
 }
@@ -951,12 +969,12 @@ __global__ void __launch_bounds__(64) k_align_batch(uint32_t n_pairs, uint32_t p
                                                      const uint8_t *qs, const uint64_t *q_off, const uint8_t *ts, const uint64_t *t_off,
                                                      const int32_t *k_hint, int32_t *dist, uint32_t *ncols_out, uint32_t *nmatch_out,
                                                      uint8_t *ops_out, const uint64_t *ops_off,
-                                                     uint8_t *scr, const uint64_t *scr_off, const uint64_t *scr_bytes) {
+                                                     uint8_t *scr, const uint64_t *scr_off, const uint64_t *scr_bytes,
+                                                     uint32_t *prog) {
     const int lane = lane_id();
     for (;;) {
-        uint32_t i = 0;
-        if (lane == 0) i = p_begin + atomicAdd(queue, 1u);
-        i = wave_bcast_u32(i, 0);
+        const uint32_t i = p_begin + wave_pop(queue);
+        BRX_PROG(prog, 0, i + 1);
         if (i >= p_end) break;
         const uint32_t Q = (uint32_t)(q_off[i + 1] - q_off[i]), T = (uint32_t)(t_off[i + 1] - t_off[i]);
         const uint8_t *q = qs + q_off[i], *t = ts + t_off[i];
@@ -972,14 +990,18 @@ __global__ void __launch_bounds__(64) k_align_batch(uint32_t n_pairs, uint32_t p
         uint64_t cap = bytes > qpad + tpad ? (bytes - qpad - tpad) / 8 : 0;
         uint8_t *ops_end = ops_out ? ops_out + ops_off[i] + Q + T : nullptr;
         int kh = k_hint[i];
-        int kk = kh >= 0 ? kh : 64;
         int maxk = (int)(Q > T ? Q : T);
+        int kk = kh >= 0 ? kh : (maxk < 64 ? maxk : 64);
         int nc = 0, nm = 0; bool ok = false, nospace = false;
-        for (;;) {
-            ok = brx_wave_align(qb, (int)Q, tbuf, (int)T, kk, tb, cap, ops_end, &nc, &nm, &nospace);
+        BRX_PROG(prog, 1, 1);
+        for (int round = 0; round < 40; ++round) {
+            BRX_PROG(prog, 2, round + 1);
+            ok = uni(brx_wave_align(qb, (int)Q, tbuf, (int)T, kk, tb, cap, ops_end, &nc, &nm, &nospace, prog));
+            nc = uni(nc); nm = uni(nm); nospace = uni(nospace);
             if (ok || nospace || kh >= 0 || kk >= maxk) break;
             kk = kk * 2 > maxk ? maxk : kk * 2;
         }
+        BRX_PROG(prog, 1, 2);
         if (ok && ops_end) {
             /* move the ops (written backwards from the end of the area) to its start */
             uint8_t *dst = ops_out + ops_off[i];
@@ -993,6 +1015,7 @@ __global__ void __launch_bounds__(64) k_align_batch(uint32_t n_pairs, uint32_t p
                 __builtin_amdgcn_s_waitcnt(0);
             }
         }
+        BRX_PROG(prog, 1, 3);
         if (lane == 0) {
             dist[i] = ok ? (nc - nm) : (nospace ? -2 : -1);
             ncols_out[i] = ok ? (uint32_t)nc : 0u;

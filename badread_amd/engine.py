@@ -71,14 +71,14 @@ class BrxSimParams(ctypes.Structure):
 
 
 READ_STATS_DTYPE = np.dtype([('status', '<u4'), ('frag_len', '<u4'), ('seq_len', '<u4'), ('n_cols', '<u4'),
-                             ('n_match', '<u4'), ('edit_distance', '<u4'), ('loop_count', '<u4'),
+                             ('n_match', '<u4'), ('padded_len', '<u4'), ('loop_count', '<u4'),
                              ('change_count', '<u4'), ('n_alignments', '<u4'), ('rec_len', '<u4'),
                              ('rec_off', '<u8'), ('target_identity', '<f8'), ('qerr_sum', '<f8')])
 assert READ_STATS_DTYPE.itemsize == 64
 
 RS_NOFRAG, RS_TOO_MANY_SEGS, RS_BAND, RS_QMISS, RS_EMPTY = 1, 2, 4, 8, 16
 E_SCRATCH, E_OUTPUT, E_NOFRAG = -3, -4, -5
-STAGE_NAMES = ('plan', 'build', 'mutate', 'align', 'qscore', 'emit')
+STAGE_NAMES = ('plan', 'build', 'mutate', 'scan', 'final', 'emit')
 
 
 class SimParams(object):
@@ -121,6 +121,8 @@ def acgt_codes(seq):
 
 class EngineBase(object):
     """Interface shared by HipEngine and the tests' oracle-backed checker."""
+
+    stats_dtype = READ_STATS_DTYPE
 
     def __init__(self):
         self._keep = {}
@@ -232,6 +234,8 @@ def load_library():
     lib.brx_align_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 11
     lib.brx_last_stage_ms.restype = ctypes.c_int
     lib.brx_last_stage_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float * 6)]
+    lib.brx_last_final_launches.restype = ctypes.c_uint32
+    lib.brx_last_final_launches.argtypes = [ctypes.c_void_p]
     _lib = lib
     return lib
 
@@ -324,8 +328,11 @@ class HipEngine(EngineBase):
         self._check(self.lib.brx_set_params(self.ctx, ctypes.byref(s)))
 
     # ------------------------------------------------------------------ calls
-    def _retry(self, call, n_reads, out_guess):
-        """Run `call(out_ptr, out_cap, stats_ptr, out_bytes)` growing scratch/output as the library asks."""
+    def _retry(self, call, n_reads, out_guess, allow_nofrag=False):
+        """Run `call(out_ptr, out_cap, stats_ptr, out_bytes)` growing scratch/output as the library asks.
+        With allow_nofrag, BRX_E_NOFRAG is not raised: the batch is complete and the failing reads
+        carry RS_NOFRAG in their stats, so the caller can apply the reference's fatal-exit rule
+        (simulate.py:159-165) only to reads that precede the stop point."""
         self._ensure_out(out_guess, n_reads)
         for _ in range(8):
             out_bytes = ctypes.c_size_t(0)
@@ -337,20 +344,22 @@ class HipEngine(EngineBase):
             if rc == E_OUTPUT:
                 self._ensure_out(int(self.lib.brx_output_needed(self.ctx) * 1.1) + (1 << 16), n_reads)
                 continue
+            if rc == E_NOFRAG and allow_nofrag:
+                return out_bytes.value
             self._check(rc)
             return out_bytes.value
         raise BrxError(E_SCRATCH, 'could not size scratch/output buffers after 8 attempts')
 
-    def simulate_batch_device(self, seed, first_read, n_reads, expected_bytes=None):
+    def simulate_batch_device(self, seed, first_read, n_reads, expected_bytes=None, allow_nofrag=False):
         """Returns (device uint8 tensor view of the FASTQ bytes, stats as numpy structured array)."""
         guess = expected_bytes or (n_reads * 34000 + (1 << 16))
         nbytes = self._retry(lambda o, cap, st, ob: self.lib.brx_simulate_batch(
-            self.ctx, seed, first_read, n_reads, o, cap, st, ob, self._stream()), n_reads, guess)
+            self.ctx, seed, first_read, n_reads, o, cap, st, ob, self._stream()), n_reads, guess, allow_nofrag)
         stats = self._stats[:n_reads * READ_STATS_DTYPE.itemsize].cpu().numpy().view(READ_STATS_DTYPE)
         return self._out[:nbytes], stats
 
-    def simulate_batch(self, seed, first_read, n_reads):
-        out, stats = self.simulate_batch_device(seed, first_read, n_reads)
+    def simulate_batch(self, seed, first_read, n_reads, allow_nofrag=False):
+        out, stats = self.simulate_batch_device(seed, first_read, n_reads, allow_nofrag=allow_nofrag)
         return out.cpu().numpy(), stats
 
     def sequence_fragments(self, seed, first_read, frags, targets):
@@ -422,6 +431,9 @@ class HipEngine(EngineBase):
         arr = (ctypes.c_float * 6)()
         self._check(self.lib.brx_last_stage_ms(self.ctx, ctypes.byref(arr)))
         return dict(zip(STAGE_NAMES, [float(x) for x in arr]))
+
+    def final_launches(self):
+        return int(self.lib.brx_last_final_launches(self.ctx))
 
 
 _default_engine = None

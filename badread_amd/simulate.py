@@ -1,0 +1,421 @@
+"""
+Host side of `badread simulate` for the MI355X path.
+
+The reference runs one read at a time in a Python loop (/root/reference/badread/simulate.py:63-86).
+Here the loop body -- build_fragment (:91-115), Identities.get_identity, sequence_fragment
+(:256-358) with get_qscores, and the FASTQ record (:73-82) -- is one C-ABI call per batch of
+read indices (brx_simulate_batch, include/brx.h); this module keeps what stays on the host:
+
+  * start-up in the reference's order: load reference, FragmentLengths, adjust_depths (:516-536),
+    Identities, models, adapters (:412-430), target size (:124-145), the same banner text;
+  * the stop rule: reads are keyed by index, the host prefix-sums the read lengths of each batch
+    in index order and cuts after the first read that reaches the target (:63,84), so the output
+    is independent of batch size and of the number of GPUs;
+  * sharding: rank r of N takes the r-th slice of every super-batch (no collective on the data
+    path; the per-read lengths and, for an ordered stdout, the record bytes are gathered);
+  * `sequence_fragment(fragment, target_identity, error_model, qscore_model)`: the narrow Python
+    boundary the reference's tests use (test/test_simulate.py:47,83), as a batch of one.
+
+Randomness: every draw on the device is Philox4x32-10 keyed by (seed, read index, stream)
+(include/brx_spec.h), so a seed fixes the output bytes, but not to the reference's MT19937 stream.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+
+from . import settings
+from .engine import RS_NOFRAG, SimParams
+from .error_model import ErrorModel
+from .fragment_lengths import FragmentLengths
+from .identities import Identities
+from .misc import float_to_str, get_random_sequence, load_fasta, str_is_int
+from .qscore_model import QScoreModel
+from .reference import PackedReference
+from .version import __version__
+
+NOFRAG_MESSAGE = ('Error: failed to generate any sequence fragments - are your read lengths '
+                  'incompatible with your reference contig lengths?')
+ADJUST_SAMPLES = 100000
+DEFAULT_MAX_BATCH = 16384
+
+
+# ---------------------------------------------------------------------------------------------
+# start-up pieces (host only)
+# ---------------------------------------------------------------------------------------------
+def print_intro(output):
+    print(f'\nBadread v{__version__}\nlong read simulation', file=output)
+
+
+def load_reference(reference, output):
+    """FASTA -> PackedReference, with the reference's summary lines (simulate.py:494-507)."""
+    print(f'\nLoading reference from {reference}', file=output)
+    seqs, depths, circular, hp_left, hp_right = load_fasta(reference)
+    print(f'  {len(seqs):,} contig{"" if len(seqs) == 1 else "s"}:', file=output)
+    for name, seq in seqs.items():
+        shape = 'circular' if circular[name] else 'linear'
+        print(f'    {name}: {len(seq):,} bp, {shape}, {depths[name]:.2f}x depth', file=output)
+    if len(seqs) > 1:
+        print(f'  total size: {sum(len(s) for s in seqs.values()):,} bp', file=output)
+    return PackedReference.from_seqs(seqs, depths, circular, hp_left, hp_right)
+
+
+def adjust_depths(pref, frag_lengths, small_plasmid_bias, rng):
+    """
+    Depth compensation for fragments that cannot come from a short contig (simulate.py:516-536):
+    circular contigs (unless --small_plasmid_bias) are scaled by total / sum(L for L <= len),
+    linear contigs by total / sum(min(len, L)), over 100,000 sampled fragment lengths.
+    Returns the adjusted {name: depth}; exits like the reference when no length fits a circular contig.
+    """
+    lengths = np.sort(frag_lengths.sample_many(ADJUST_SAMPLES, rng))
+    prefix = np.concatenate(([0], np.cumsum(lengths)))
+    total = int(prefix[-1])
+    depths = dict(pref.depths)
+    for name, ref_len in zip(pref.names, pref.lengths):
+        n_fit = int(np.searchsorted(lengths, ref_len, side='right'))     # lengths <= ref_len
+        if pref.circular[name]:
+            if small_plasmid_bias:
+                continue
+            passing = int(prefix[n_fit])
+            if passing == 0:
+                sys.exit('Error: fragment length distribution incompatible with reference lengths '
+                         '- try running with --small_plasmid_bias to avoid this error')
+        else:
+            passing = int(prefix[n_fit]) + ref_len * (len(lengths) - n_fit)
+        depths[name] *= total / passing
+    return depths
+
+
+def get_target_size(ref_size, quantity):
+    """'250M' / '25x' / plain integer -> bases (simulate.py:124-145)."""
+    text = str(quantity)
+    if str_is_int(text):
+        return int(text)
+    scale = {'x': ref_size, 'g': 1000000000, 'm': 1000000, 'k': 1000}.get(text[-1:].lower())
+    if scale is not None:
+        try:
+            return int(round(float(text[:-1]) * scale))
+        except ValueError:
+            pass
+    sys.exit('Error: could not parse quantity\n'
+             '--quantity must be either an absolute value (e.g. 250M) or a relative depth '
+             '(e.g. 25x)')
+
+
+def adapter_parameters(param_str):
+    fields = param_str.split(',')
+    try:
+        if len(fields) == 2:
+            return [float(f) / 100 for f in fields]
+    except ValueError:
+        pass
+    sys.exit('Error: adapter parameters must be two comma-separated values between 0 and 1')
+
+
+def build_random_adapters(args):
+    """An integer adapter 'sequence' means a random adapter of that length (simulate.py:422-432)."""
+    made = []
+    for attr in ('start_adapter_seq', 'end_adapter_seq'):
+        value = getattr(args, attr)
+        if str_is_int(value):
+            setattr(args, attr, get_random_sequence(int(value)))
+            made.append(True)
+        else:
+            made.append(False)
+    return tuple(made)
+
+
+def _print_adapter(label, seq, rate, amount, was_random, output):
+    if seq and rate > 0.0 and amount > 0.0:
+        print(f'{label} adapter:', file=output)
+        print(f'  seq: {seq}{" (randomly generated)" if was_random else ""}', file=output)
+        print(f'  rate:   {rate * 100.0:.1f}%', file=output)
+        print(f'  amount: {amount * 100.0:.1f}%', file=output)
+    else:
+        print(f'{label} adapter: none', file=output)
+
+
+def print_adapter_summary(start_rate, start_amount, start_seq, end_rate, end_amount, end_seq,
+                          random_start, random_end, output):
+    print('', file=output)
+    _print_adapter('Start', start_seq, start_rate, start_amount, random_start, output)
+    print('', file=output)
+    _print_adapter('End', end_seq, end_rate, end_amount, random_end, output)
+
+
+def print_glitch_summary(glitch_rate, glitch_size, glitch_skip, output):
+    print('', file=output)
+    if glitch_rate == 0:
+        print('Reads will have no glitches', file=output)
+        return
+    print('Read glitches:', file=output)
+    for text, value in (('rate (mean distance between glitches)', glitch_rate),
+                        ('size (mean length of random sequence)', glitch_size),
+                        ('skip (mean sequence lost per glitch) ', glitch_skip)):
+        print(f'  {text} = {float_to_str(value):>5}', file=output)
+
+
+def print_other_problem_summary(args, output):
+    print('\nOther problems:', file=output)
+    print(f'  chimera join rate: {args.chimeras}%', file=output)
+    print(f'  junk read rate:    {args.junk_reads}%', file=output)
+    print(f'  random read rate:  {args.random_reads}%', file=output)
+
+
+def print_progress(count, bp, target, output):
+    percent = min(int(1000.0 * bp / target) / 10, 100.0) if target else 100.0
+    print(f'\rSimulating: {count:,} read{" " if count == 1 else "s"}  {bp:,} bp  {percent:.1f}%',
+          file=output, flush=True, end='')
+
+
+def sim_params_from_args(args, frag_lengths, identities, start_rate, start_amount, end_rate, end_amount):
+    mode, id_a, id_b, id_max = identities.device_mode()
+    return SimParams(frag_mean=frag_lengths.mean, frag_stdev=frag_lengths.stdev,
+                     identity_mode=mode, id_a=id_a, id_b=id_b, id_max=id_max,
+                     start_rate=start_rate, start_amount=start_amount, end_rate=end_rate, end_amount=end_amount,
+                     start_adapter=args.start_adapter_seq, end_adapter=args.end_adapter_seq,
+                     junk_rate=args.junk_reads / 100, random_rate=args.random_reads / 100,
+                     chimera_rate=args.chimeras / 100,
+                     glitch_rate=args.glitch_rate, glitch_size=args.glitch_size, glitch_skip=args.glitch_skip)
+
+
+# ---------------------------------------------------------------------------------------------
+# sharding and the stop rule
+# ---------------------------------------------------------------------------------------------
+class Shard(object):
+    """This process's place among the ranks of one node: rank r of world N (torch.distributed or single)."""
+
+    def __init__(self, rank=0, world=1, dist=None):
+        self.rank, self.world, self.dist = rank, world, dist
+
+    @classmethod
+    def from_env(cls):
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        if world <= 1:
+            return cls()
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            import torch
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            if backend == 'nccl':
+                torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+            dist.init_process_group(backend=backend)
+        return cls(dist.get_rank(), dist.get_world_size(), dist)
+
+    def slice_of(self, first, count):
+        """Contiguous slice of the super-batch [first, first+count) owned by this rank."""
+        per = -(-count // self.world)
+        lo = min(self.rank * per, count)
+        hi = min(lo + per, count)
+        return first + lo, hi - lo
+
+    def gather_arrays(self, arr):
+        """Every rank's uint8/uint32 numpy array, in rank order, on every rank (sizes may differ)."""
+        if self.world == 1:
+            return [arr]
+        import torch
+        dist = self.dist
+        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+        size = torch.tensor([arr.size], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(size) for _ in range(self.world)]
+        dist.all_gather(sizes, size)
+        sizes = [int(s.item()) for s in sizes]
+        cap = max(max(sizes), 1)
+        mine = torch.zeros(cap, dtype=torch.from_numpy(arr[:0].copy()).dtype, device=dev)
+        mine[:arr.size] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+        parts = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        return [p[:n].cpu().numpy() for p, n in zip(parts, sizes)]
+
+
+def cut_point(seq_lens, running_total, target_size):
+    """
+    Index (within this batch) of the read at which the reference's loop stops, or None.  Empty
+    reads (seq_len 0) are skipped and never stop the loop (simulate.py:70-71).
+    """
+    seq_lens = np.asarray(seq_lens, dtype=np.int64)
+    reached = np.flatnonzero((running_total + np.cumsum(seq_lens) >= target_size) & (seq_lens > 0))
+    return int(reached[0]) if len(reached) else None
+
+
+def plan_batch(remaining_bases, mean_length, world, max_batch):
+    """Reads in the next super-batch: a little over the expected need, rounded to 64 per rank."""
+    expect = remaining_bases / max(mean_length, 1.0)
+    want = int(expect * 1.05) + 8 * world
+    per_rank = min(max(-(-want // world), 1), max_batch)
+    per_rank = -(-per_rank // 64) * 64 if per_rank >= 64 else per_rank
+    return per_rank * world
+
+
+def run_batches(engine, seed, target_size, mean_length, write, output, shard=None, max_batch=DEFAULT_MAX_BATCH):
+    """
+    The `while total_size < target_size` loop over super-batches.  `write(bytes_like)` receives the
+    FASTQ bytes in read order on rank 0 only.  Returns (read count, total bases).
+    """
+    shard = shard or Shard()
+    count = total = 0
+    next_read = 0
+    expected_mean = float(mean_length)
+    if shard.rank == 0:
+        print_progress(count, total, target_size, output)
+    while total < target_size:
+        n_super = plan_batch(target_size - total, expected_mean, shard.world, max_batch)
+        first, n_mine = shard.slice_of(next_read, n_super)
+        if n_mine:
+            out, stats = engine.simulate_batch(seed, first, n_mine, allow_nofrag=True)
+        else:
+            out, stats = np.zeros(0, np.uint8), np.zeros(0, dtype=engine.stats_dtype)
+        lens = np.concatenate(shard.gather_arrays(stats['seq_len'].astype(np.uint32) * (stats['rec_len'] > 0)))
+        failed = np.concatenate(shard.gather_arrays((stats['status'] & RS_NOFRAG).astype(np.uint8)))
+        cut = cut_point(lens, total, target_size)
+        bad = np.flatnonzero(failed)
+        fatal = len(bad) and (cut is None or bad[0] < cut)
+        last = int(bad[0]) - 1 if fatal else (cut if cut is not None else n_super - 1)
+        # bytes of my reads with global batch position <= last
+        my_lo = first - next_read
+        keep = int(np.clip(last - my_lo + 1, 0, n_mine))
+        my_bytes = out[:int(stats['rec_off'][keep - 1] + stats['rec_len'][keep - 1])] if keep else out[:0]
+        parts = shard.gather_arrays(np.ascontiguousarray(my_bytes))
+        if shard.rank == 0:
+            for part in parts:
+                if len(part):
+                    write(part)
+        used = lens[:last + 1]
+        count += int((used > 0).sum())
+        total += int(used.sum())
+        if shard.rank == 0:
+            print_progress(count, total, target_size, output)
+        if fatal:
+            if shard.rank == 0:
+                print('\n', file=output)
+            sys.exit(NOFRAG_MESSAGE)
+        if count:
+            expected_mean = max(total / count, 1.0)
+        next_read += n_super
+    if shard.rank == 0:
+        print('\n', file=output)
+    return count, total
+
+
+# ---------------------------------------------------------------------------------------------
+# the driver
+# ---------------------------------------------------------------------------------------------
+def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
+    """Same contract as badread.simulate.simulate(args, output): FASTQ to stdout, the rest to `output`."""
+    shard = shard or Shard.from_env()
+    quiet = _Null() if shard.rank != 0 else output
+    print_intro(quiet)
+    seed = args.seed if args.seed is not None else int.from_bytes(os.urandom(7), 'little')
+    if shard.world > 1 and args.seed is None:
+        seed = _broadcast_seed(shard, seed)
+    random.seed(seed)
+    host_rng = np.random.RandomState(seed % (2 ** 32))
+    pref = load_reference(args.reference, quiet)
+    frag_lengths = FragmentLengths(args.mean_frag_length, args.frag_length_stdev, quiet)
+    depths = adjust_depths(pref, frag_lengths, args.small_plasmid_bias, host_rng)
+    identities = Identities(args.mean_identity, args.identity_stdev, args.max_identity, quiet)
+    if engine is None:
+        from .engine import default_engine
+        engine = default_engine()
+    error_model = ErrorModel(args.error_model, quiet)
+    qscore_model = QScoreModel(args.qscore_model, quiet)
+    print_glitch_summary(args.glitch_rate, args.glitch_size, args.glitch_skip, quiet)
+    start_rate, start_amount = adapter_parameters(args.start_adapter)
+    end_rate, end_amount = adapter_parameters(args.end_adapter)
+    random_start, random_end = build_random_adapters(args)
+    print_adapter_summary(start_rate, start_amount, args.start_adapter_seq, end_rate, end_amount,
+                          args.end_adapter_seq, random_start, random_end, quiet)
+    print_other_problem_summary(args, quiet)
+    target_size = get_target_size(pref.n_bases, args.quantity)
+    print(f'\nTarget read set size: {target_size:,} bp\n', file=quiet)
+
+    _, cum_weight = pref.contig_weights(depths)
+    engine.set_reference(pref, cum_weight)
+    engine.set_error_model(error_model.tables())
+    engine.set_qscore_model(qscore_model.tables())
+    engine.set_params(sim_params_from_args(args, frag_lengths, identities, start_rate, start_amount,
+                                           end_rate, end_amount))
+    sink = stdout if stdout is not None else getattr(sys.stdout, 'buffer', None)
+    if sink is not None:
+        def write(part):
+            sink.write(memoryview(part))
+    else:                                   # a text-only stdout (e.g. captured in tests)
+        def write(part):
+            sys.stdout.write(bytes(part).decode('latin-1'))
+    result = run_batches(engine, seed, target_size, float(args.mean_frag_length), write, quiet, shard)
+    if sink is not None and hasattr(sink, 'flush'):
+        sink.flush()
+    return result
+
+
+class _Null(object):
+    def write(self, *_):
+        return 0
+
+    def flush(self):
+        pass
+
+
+def _broadcast_seed(shard, seed):
+    import torch
+    dev = torch.device('cuda', torch.cuda.current_device()) if shard.dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([seed], dtype=torch.int64, device=dev)
+    shard.dist.broadcast(t, src=0)
+    return int(t.item())
+
+
+# ---------------------------------------------------------------------------------------------
+# sequence_fragment: the narrow Python boundary (simulate.py:256-358)
+# ---------------------------------------------------------------------------------------------
+_seq_engine_state = {}
+
+
+def _fragment_alphabet(fragment):
+    """ACGT -> 0..3, N -> 4, other symbols of this fragment -> 5.. (all treated as 'not in the model')."""
+    sym = bytearray(b'ACGTN' + b'N' * 11)
+    lut = np.full(256, 4, dtype=np.uint8)
+    for code, ch in enumerate(b'ACGT'):
+        lut[ch] = code
+    raw = np.frombuffer(fragment.encode('latin-1'), dtype=np.uint8)
+    nxt = 5
+    for b in np.unique(raw):
+        if chr(b) not in 'ACGTN':
+            if nxt < 16:
+                lut[b], sym[nxt] = nxt, b
+                nxt += 1
+    return lut[raw], np.frombuffer(bytes(sym), dtype=np.uint8)
+
+
+def sequence_fragment(fragment, target_identity, error_model, qscore_model, engine=None, seed=None, read_index=0):
+    """
+    Drop-in for badread.simulate.sequence_fragment: returns (seq, quals, actual_identity,
+    identity_by_qscores).  Runs brx_sequence_fragments on a batch of one; the random streams are
+    keyed by `seed` (default: 64 bits from Python's `random`, so random.seed() still fixes the result).
+    """
+    if engine is None:
+        from .engine import default_engine
+        engine = default_engine()
+    key = (id(engine), id(error_model), id(qscore_model))
+    if _seq_engine_state.get('key') != key:
+        engine.set_error_model(error_model.tables())
+        engine.set_qscore_model(qscore_model.tables())
+        _seq_engine_state['key'] = key
+        _seq_engine_state['keep'] = (error_model, qscore_model)
+    if seed is None:
+        seed = random.getrandbits(64)
+    if len(fragment) == 0:
+        return '', '', 0.0, 0.0
+    codes, sym = _fragment_alphabet(fragment)
+    res, stats = engine.sequence_fragments(seed, read_index, [codes], [float(target_identity)])
+    seq_codes, quals = res[0]
+    st = stats[0]
+    seq = sym[seq_codes].tobytes().decode('latin-1')
+    n_cols, padded_len = int(st['n_cols']), int(st['padded_len'])
+    actual_identity = int(st['n_match']) / n_cols if n_cols else 0.0
+    # identity_by_qscores averages over the PADDED read, like get_qscores (qscore_model.py:71-73)
+    identity_by_qscores = 1.0 - float(st['qerr_sum']) / padded_len if padded_len else 0.0
+    return seq, quals.tobytes().decode('latin-1'), actual_identity, identity_by_qscores
+
+
+assert settings.ALIGNMENT_INTERVAL == 25 and settings.ALIGNMENT_SIZE == 1000     # hard-coded in csrc/brx_kernels.h

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""
+bench.py -- simulated bases per second of the HIP hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on that fits one GPU):
+a synthetic "K. pneumoniae-like" reference -- one circular 5.3 Mb chromosome plus two circular
+plasmids (200 kb depth=2, 5 kb depth=10), uniform ACGT from numpy default_rng(1) -- default
+`badread simulate` parameters (length 15000,13000; identity 95,99,2.5; nanopore2023 error and
+qscore models; default adapters, junk/random/chimera 1 %, glitches 10000,25,25), seed 42.
+A "step" is ONE pass of the whole hot path (plan -> fragments -> mutate -> align -> qscores ->
+FASTQ bytes) over one batch of `--reads-per-step` read indices per GPU through the C-ABI
+(brx_simulate_batch); the default 8192 reads x 15 kb is ~45 % of the 50x job per step.  Inputs
+(packed reference, model tables) are resident in HBM before the timed region; the FASTQ bytes stay
+in HBM (the PCIe-inclusive rate is reported separately as `value_incl_d2h`).  Weak scaling: every
+rank processes its own slice [step*N*R + rank*R, +R) of the read-index space, no collective on the
+data path.
+
+The JSON line carries `roofline` (dominant kernel, HBM bound, algorithmic bytes = 2.26 B per
+simulated base) and `cpu_baseline` (the C oracle -- a single-threaded port of
+the same algorithm -- run on all host cores of this box on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+ALGO_BYTES_PER_BASE = 2.26          # 0.25 B packed reference read + 2 B FASTQ written + header share
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+SEED = 42
+
+
+def kpneumoniae_like():
+    """configs[1] reference: names, sequences, depths, circular flags."""
+    import collections
+    rng = np.random.default_rng(1)
+    seqs = collections.OrderedDict()
+    depths, circular = {}, {}
+    for name, length, depth in (('chromosome', 5300000, 1.0), ('plasmid_1', 200000, 2.0), ('plasmid_2', 5000, 10.0)):
+        seqs[name] = np.frombuffer(b'ACGT', dtype=np.uint8)[rng.integers(0, 4, length)].tobytes().decode()
+        depths[name], circular[name] = depth, True
+    return seqs, depths, circular
+
+
+def build_workload(io_null):
+    from badread_amd.engine import SimParams
+    from badread_amd.error_model import ErrorModel
+    from badread_amd.fragment_lengths import FragmentLengths
+    from badread_amd.identities import Identities
+    from badread_amd.qscore_model import QScoreModel
+    from badread_amd.reference import PackedReference
+    from badread_amd.simulate import adjust_depths
+    seqs, depths, circular = kpneumoniae_like()
+    pref = PackedReference.from_seqs(seqs, depths, circular)
+    frag = FragmentLengths(15000, 13000, io_null)
+    ident = Identities(95, 2.5, 99, io_null)
+    depths = adjust_depths(pref, frag, False, np.random.RandomState(SEED))
+    _, cum = pref.contig_weights(depths)
+    mode, a, b, mx = ident.device_mode()
+    params = SimParams(frag_mean=15000, frag_stdev=13000, identity_mode=mode, id_a=a, id_b=b, id_max=mx)
+    em = ErrorModel('nanopore2023', io_null).tables()
+    qm = QScoreModel('nanopore2023', io_null).tables()
+    return pref, cum, em, qm, params
+
+
+def configure(engine, wl):
+    pref, cum, em, qm, params = wl
+    engine.set_reference(pref, cum)
+    engine.set_error_model(em)
+    engine.set_qscore_model(qm)
+    engine.set_params(params)
+    return engine
+
+
+def cpu_baseline(wl, first_read, budget_s):
+    """The oracle (oracle/brx_oracle.c, a scalar C port of the same path) on every host core: threads pull
+    16-read chunks of the same read-index stream until `budget_s` seconds have passed."""
+    sys.path.insert(0, os.path.join(REPO, 'oracle'))
+    import pyoracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    chunk = 16
+    lock = threading.Lock()
+    state = {'next': 0, 'bases': 0, 'reads': 0}
+    t0 = time.perf_counter()
+
+    def worker():
+        eng = configure(pyoracle.OracleEngine(), wl)
+        while time.perf_counter() - t0 < budget_s:
+            with lock:
+                idx = state['next']
+                state['next'] += 1
+            _, st = eng.simulate_batch(SEED, first_read + idx * chunk, chunk)     # ctypes releases the GIL
+            with lock:
+                state['bases'] += int(st['seq_len'].sum())
+                state['reads'] += chunk
+
+    threads = [threading.Thread(target=worker) for _ in range(cores)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {'value': state['bases'] / dt, 'unit': 'bases/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{state["reads"]} reads / {state["bases"]} bases of the same workload and seed in {dt:.1f} s, '
+                      f'oracle/brx_oracle.c (gcc -O2), one thread per host core'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--reads-per-step', type=int, default=8192, help='read indices per GPU per step')
+    ap.add_argument('--scratch-gb', type=float, default=64.0)
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline leg (0 = skip)')
+    ap.add_argument('--d2h', action='store_true', help='also time steps that copy the FASTQ bytes to pinned host memory')
+    args = ap.parse_args()
+
+    import io
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a ROCm device: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from badread_amd.engine import HipEngine
+    wl = build_workload(io.StringIO())
+    eng = configure(HipEngine(local, scratch_bytes=int(args.scratch_gb * (1 << 30))), wl)
+    R = args.reads_per_step
+
+    def step(index):
+        first = (index * world + rank) * R
+        out, stats = eng.simulate_batch_device(SEED, first, R, expected_bytes=R * 36000)
+        return out, stats
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w)
+    bases = 0
+    stage_sum = {}
+    final_launches = 0
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        _, stats = step(args.warmup + k)
+        bases += int(stats['seq_len'].sum())
+        for name, ms in eng.stage_ms().items():
+            stage_sum[name] = stage_sum.get(name, 0.0) + ms
+        final_launches += eng.final_launches()
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, float(bases)], dtype=torch.float64, device='cuda')
+    if dist is not None:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, bases = float(tmax[0].item()), float(t[1].item())
+    value = bases / elapsed
+
+    d2h = None
+    if args.d2h and rank == 0:
+        host = torch.empty(R * 40000, dtype=torch.uint8).pin_memory()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        b2 = 0
+        for k in range(args.steps):
+            out, stats = step(args.warmup + k)
+            host[:out.numel()].copy_(out, non_blocking=False)
+            b2 += int(stats['seq_len'].sum())
+        torch.cuda.synchronize()
+        d2h = b2 / (time.perf_counter() - t1)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    stages = {k: v / args.steps for k, v in stage_sum.items()}
+    dominant = max(('mutate', 'final'), key=lambda k: stages.get(k, 0.0))
+    kernel = {'mutate': 'k_mutate', 'final': 'k_final'}[dominant]
+    launches = 1.0 if dominant == 'mutate' else final_launches / args.steps
+    bases_per_step_rank0 = bases / (args.steps * world)
+    launch_ms = stages[dominant] / launches
+    achieved = ALGO_BYTES_PER_BASE * (bases_per_step_rank0 / launches) / (launch_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
+    if os.path.isfile(tfile):
+        try:
+            rec = json.load(open(tfile))
+            if rec.get('reads_per_step') == R and rec.get('kernel') == kernel:
+                traffic = rec.get('hbm_bytes_per_launch')
+        except (OSError, ValueError):
+            pass
+    result = {
+        'metric': 'simulated bases/sec', 'value': value, 'unit': 'bases/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u64', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: 5.5 Mb K. pneumoniae-like synthetic reference (3 circular contigs), '
+                               'nanopore2023 error+qscore models, default badread simulate parameters, seed 42',
+                   'reads_per_step_per_gpu': R, 'bases_per_step_per_gpu': bases_per_step_rank0,
+                   'parallelism': f'reads sharded by index over {world} GPU(s), reference replicated, no collectives'},
+        'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                     'algorithmic_bytes_per_launch': ALGO_BYTES_PER_BASE * bases_per_step_rank0 / launches,
+                     'launch_ms': launch_ms, 'launches_per_step': launches,
+                     'note': 'integer-ALU / latency bound path: see DESIGN.md section 5'},
+        'stage_ms_per_step': stages,
+    }
+    if d2h is not None:
+        result['value_incl_d2h'] = d2h
+    if world == 1 and args.cpu_seconds > 0:
+        result['cpu_baseline'] = cpu_baseline(wl, 10_000_000, args.cpu_seconds)
+        result['gpu_over_cpu'] = value / result['cpu_baseline']['value']
+    else:
+        result['cpu_baseline'] = None
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

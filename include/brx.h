@@ -162,7 +162,8 @@ typedef struct {
     uint32_t seq_len;          /* length= : trimmed read length                                 */
     uint32_t n_cols;           /* columns of the final alignment (pads included)                */
     uint32_t n_match;          /* '=' columns: read_identity = n_match / n_cols (misc.py:228-240) */
-    uint32_t edit_distance;
+    uint32_t padded_len;       /* bases of the read before trimming the pads (what get_qscores scored);
+                                  edit distance = n_cols - n_match                                */
     uint32_t loop_count;       /* k-mer draws consumed by the mutate loop                       */
     uint32_t change_count;     /* positions changed                                             */
     uint32_t n_alignments;     /* in-loop identity alignments (simulate.py:325-346)             */
@@ -219,11 +220,20 @@ int brx_align_batch(brx_ctx *ctx, uint32_t n_pairs,
                     int32_t *d_dist, uint32_t *d_ncols, uint32_t *d_nmatch,
                     uint8_t *d_ops, const uint64_t *d_ops_off, void *hip_stream);
 
-/* time (ms) the device spent in each pipeline stage during the last brx_simulate_batch call,
- * measured with HIP events on the launch stream: index = BRX_STAGE_* */
-enum { BRX_STAGE_PLAN = 0, BRX_STAGE_BUILD = 1, BRX_STAGE_MUTATE = 2, BRX_STAGE_ALIGN = 3,
-       BRX_STAGE_QSCORE = 4, BRX_STAGE_EMIT = 5, BRX_STAGE_COUNT = 6 };
+/* Device time (ms) of each pipeline stage of the last brx_simulate_batch / brx_sequence_fragments
+ * call, from HIP events recorded on the launch stream immediately before and after the stage's
+ * kernels (host work between stages is not included):
+ *   PLAN    k_plan_count, k_scan_plan, k_plan_fill (includes one small size read-back)
+ *   BUILD   k_build (+ k_copy_frags), k_order
+ *   MUTATE  k_mutate                      -- one launch
+ *   SCAN    k_scan_mut
+ *   FINAL   k_final (alignment + traceback + qscores), one launch per scratch chunk
+ *   EMIT    k_recsize, k_scan_rec, k_emit, k_stats (includes one small size read-back)         */
+enum { BRX_STAGE_PLAN = 0, BRX_STAGE_BUILD = 1, BRX_STAGE_MUTATE = 2, BRX_STAGE_SCAN = 3,
+       BRX_STAGE_FINAL = 4, BRX_STAGE_EMIT = 5, BRX_STAGE_COUNT = 6 };
 int brx_last_stage_ms(const brx_ctx *ctx, float ms[BRX_STAGE_COUNT]);
+/* number of k_final launches (scratch chunks) of the last call */
+uint32_t brx_last_final_launches(const brx_ctx *ctx);
 
 #ifdef __cplusplus
 }

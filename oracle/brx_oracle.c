@@ -443,7 +443,7 @@ static void sequence_padded(const orc_ctx *c, uint64_t seed, uint64_t read, cons
     int64_t dist = orc_align(seq, (int64_t)m, F, (int64_t)n, ops, &nops);          /* :37 */
     uint32_t match, edits;
     count_ops(ops, nops, &match, &edits);
-    st->n_cols = (uint32_t)nops; st->n_match = match; st->edit_distance = (uint32_t)dist;
+    st->n_cols = (uint32_t)nops; st->n_match = match; st->padded_len = (uint32_t)m; (void)dist;
     uint64_t *col_of = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(m + 1));
     { uint64_t s = 0; for (int64_t cidx = 0; cidx < nops; ++cidx) if (ops[cidx] != 3) col_of[s++] = (uint64_t)cidx; }
     uint8_t *qual = (uint8_t *)malloc(m + 16);

@@ -133,7 +133,7 @@ class OracleEngine(EngineBase):
         s = self._fill_params(params)
         self.L.orc_set_params(self.ctx, ctypes.byref(s))
 
-    def simulate_batch(self, seed, first_read, n_reads):
+    def simulate_batch(self, seed, first_read, n_reads, allow_nofrag=False):
         stats = np.zeros(n_reads, dtype=READ_STATS_DTYPE)
         need = self.L.orc_simulate_batch(self.ctx, seed, first_read, n_reads, None, 0, stats.ctypes.data)
         out = np.zeros(max(int(need), 1), dtype=np.uint8)

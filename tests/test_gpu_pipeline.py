@@ -10,7 +10,7 @@ from badread_amd.engine import SimParams
 
 pytestmark = pytest.mark.gpu
 
-STAT_FIELDS = ('status', 'frag_len', 'seq_len', 'n_cols', 'n_match', 'edit_distance', 'loop_count',
+STAT_FIELDS = ('status', 'frag_len', 'seq_len', 'n_cols', 'n_match', 'padded_len', 'loop_count',
                'change_count', 'n_alignments', 'rec_len', 'rec_off', 'target_identity', 'qerr_sum')
 
 
