@@ -381,7 +381,8 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
  * Handles empty inputs.  All lanes of the wave must call; results are wave-uniform. */
 __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *Ts, int T, int k,
                                       uint2 *tb, uint64_t tb_cap_units, uint8_t *ops_end,
-                                      int *n_cols, int *n_match, bool *no_space, uint32_t *prog = nullptr) {
+                                      int *n_cols, int *n_match, bool *no_space, uint32_t *prog = nullptr,
+                                      uint64_t *clk = nullptr) {
     const int lane = threadIdx.x & 63;
     *no_space = false;
     if (Q == 0 || T == 0) {
@@ -396,11 +397,14 @@ __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *T
     if (g.G == 0 || brx_align_units(g) > tb_cap_units) { *no_space = true; *n_cols = 0; *n_match = 0; return false; }
     BRX_PROG(prog, 3, 1);
     BRX_PROG(prog, 6, (uint32_t)g.t_end);
+    const uint64_t c0 = __builtin_amdgcn_s_memtime();
     brx_align_forward_any(Qs, Ts, g, tb, prog);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);      /* stores of this wave visible to its own later loads */
     BRX_PROG(prog, 3, 2);
+    const uint64_t c1 = __builtin_amdgcn_s_memtime();
     bool ok = brx_align_traceback(Qs, Ts, g, tb, ops_end, n_cols, n_match, prog);
+    if (clk) { const uint64_t c2 = __builtin_amdgcn_s_memtime(); clk[0] += c1 - c0; clk[1] += c2 - c1; }
     BRX_PROG(prog, 3, 3);
     if (ok && (*n_cols - *n_match) > k) ok = false;
     return ok;

@@ -36,6 +36,7 @@ struct brx_ctx {
     hipEvent_t ev_b[BRX_STAGE_COUNT], ev_e[BRX_STAGE_COUNT];   /* begin / end of each stage on the launch stream */
     float stage_ms[BRX_STAGE_COUNT];
     uint32_t final_launches;
+    uint64_t *d_clk; uint32_t clk_reads;
     char err[512];
 };
 
@@ -180,6 +181,13 @@ static int wait_stream(brx_ctx *c, hipStream_t st, const char *what) {
     }
 }
 
+extern "C" int brx_last_read_cycles(brx_ctx *c, uint64_t *h_out, uint32_t n_reads) {
+    if (!c || !h_out) return BRX_E_ARG;
+    if (!c->d_clk || n_reads > c->clk_reads) return fail(c, BRX_E_STATE, "no per-read cycle counters for %u reads", n_reads);
+    HIPCHK(c, hipMemcpy(h_out, c->d_clk, (size_t)n_reads * 64, hipMemcpyDeviceToHost));
+    return BRX_OK;
+}
+
 extern "C" uint32_t brx_last_final_launches(const brx_ctx *c) { return c ? c->final_launches : 0; }
 
 static int read_totals(brx_ctx *c, hipStream_t st, const uint64_t *d_totals, int n) {
@@ -216,9 +224,12 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     uint32_t *counters = (uint32_t *)A.take(64 * 4);        /* [0] mutate queue, [1] flags, [2..] final queues */
     uint64_t *units_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *tboff_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
+    uint64_t *clk = (uint64_t *)A.take((size_t)n_reads * 64);     /* per-read cycle counters, brx_last_read_cycles() */
     if (!A.ok()) return scratch_short(c, A.used + (size_t)n_reads * 200000);
     HIPCHK(c, hipMemsetAsync(counters, 0, 64 * 4, st));
     HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, st));
+    HIPCHK(c, hipMemsetAsync(clk, 0, (size_t)n_reads * 64, st));
+    c->d_clk = clk; c->clk_reads = n_reads;
 
     /* ---- stage: plan ---- */
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_PLAN], st));
@@ -247,7 +258,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
 
     /* ---- stage: mutate ---- */
     hipLaunchKernelGGL(k_mutate, dim3(n_waves), dim3(64), 0, st, dev, rs, order, counters + 0, Fbuf, repl, win,
-                       (uint64_t)c->win_bytes, counters + 1);
+                       (uint64_t)c->win_bytes, counters + 1, clk);
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_MUTATE], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_SCAN], st));
     hipLaunchKernelGGL(k_scan_mut, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
@@ -304,7 +315,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         if (e == b) continue;
         uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
         hipLaunchKernelGGL(k_final, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 2 + ci, Fbuf, repl,
-                           seqbuf, opsbuf, tb_base);
+                           seqbuf, opsbuf, tb_base, clk);
     }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_FINAL], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_EMIT], st));

@@ -535,7 +535,7 @@ struct MutScratch { uint8_t *base; uint64_t bytes; };
 
 __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t *order, uint32_t *queue,
                                                 uint8_t *Fbuf, uint32_t *repl, uint8_t *win_base, uint64_t win_bytes,
-                                                uint32_t *flags) {
+                                                uint32_t *flags, uint64_t *clk) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
@@ -546,6 +546,8 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
         const uint32_t r = order[qi];
         RS s = rs[r];
         if (s.n == 0) continue;
+        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        uint64_t aclk[2] = {0, 0};
         const uint64_t read = d.first_read + r;
         const uint32_t n = s.n;
         const uint8_t *F = Fbuf + s.F_off;
@@ -626,7 +628,8 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
                             __builtin_amdgcn_s_waitcnt(0);
                             uint2 *tb = reinterpret_cast<uint2 *>(win + qpad + tpad);
                             uint64_t cap = (win_bytes - qpad - tpad) / 8;
-                            bool ok = brx_wave_align(qb, (int)ql, tbuf, (int)tl, (int)cost, tb, cap, nullptr, &ncols, &nmatch, &nospace);
+                            bool ok = brx_wave_align(qb, (int)ql, tbuf, (int)tl, (int)cost, tb, cap, nullptr, &ncols, &nmatch, &nospace,
+                                                     nullptr, aclk);
                             if (!ok && !nospace) s.status |= BRX_RS_BAND;
                         }
                         if (nospace) { if (lane == 0) atomicOr(&flags[0], 1u); }
@@ -663,6 +666,8 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
             uint64_t units = (m == 0) ? 0 : brx_align_units(g);
             if (m && g.G == 0) { o->status |= BRX_RS_BAND; units = 0; }
             o->units = units + ((uint64_t)m * 4 + 7) / 8 + 2;     /* + col_of[] for the qscore stage */
+            uint64_t *ck = clk + (uint64_t)r * 8;
+            ck[0] = __builtin_amdgcn_s_memtime() - t_begin; ck[1] = aclk[0]; ck[2] = aclk[1];
         }
     }
 }
@@ -710,7 +715,7 @@ __device__ inline int64_t qs_lookup(const brx_qscore_model &qm, uint64_t key) {
 
 __global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                uint32_t *queue, const uint8_t *Fbuf, const uint32_t *repl,
-                                               uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base) {
+                                               uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
     __shared__ uint32_t qhist[256];
     const int lane = lane_id();
     const brx_error_model &em = d.em;
@@ -722,6 +727,8 @@ __global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *
         const uint32_t r = order[qi];
         RS s = rs[r];
         if (s.n == 0) continue;
+        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        uint64_t aclk[2] = {0, 0};
         const uint64_t read = d.first_read + r;
         const uint32_t n = s.n, m = s.m;
         const uint8_t *F = Fbuf + s.F_off;
@@ -738,7 +745,9 @@ __global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         int ncols = 0, nmatch = 0; bool nospace = false;
-        bool ok = brx_wave_align(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch, &nospace);
+        bool ok = brx_wave_align(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch, &nospace,
+                                 nullptr, aclk);
+        const uint64_t t_aligned = __builtin_amdgcn_s_memtime();
         if (!ok) s.status |= BRX_RS_BAND;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
@@ -823,6 +832,10 @@ __global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *
             o->status = s.status | ((hi - lo) == 0 ? BRX_RS_EMPTY : 0u);
             o->n_cols = (uint32_t)ncols; o->n_match = (uint32_t)nmatch; o->qerr = qerr;
             o->seq_len = hi - lo;
+            uint64_t *ck = clk + (uint64_t)r * 8;
+            const uint64_t t_end = __builtin_amdgcn_s_memtime();
+            ck[3] = t_end - t_begin; ck[4] = aclk[0]; ck[5] = aclk[1]; ck[6] = t_end - t_aligned;
+            ck[7] = (uint64_t)brx_make_geom((int)m, (int)n, (int)s.ub).G;
         }
         __syncthreads();
     }

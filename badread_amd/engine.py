@@ -234,6 +234,8 @@ def load_library():
     lib.brx_align_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 11
     lib.brx_last_stage_ms.restype = ctypes.c_int
     lib.brx_last_stage_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float * 6)]
+    lib.brx_last_read_cycles.restype = ctypes.c_int
+    lib.brx_last_read_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
     lib.brx_last_final_launches.restype = ctypes.c_uint32
     lib.brx_last_final_launches.argtypes = [ctypes.c_void_p]
     _lib = lib
@@ -431,6 +433,12 @@ class HipEngine(EngineBase):
         arr = (ctypes.c_float * 6)()
         self._check(self.lib.brx_last_stage_ms(self.ctx, ctypes.byref(arr)))
         return dict(zip(STAGE_NAMES, [float(x) for x in arr]))
+
+    def read_cycles(self, n_reads):
+        """(n_reads, 8) uint64 shader-clock counters of the last pipeline call (see include/brx.h)."""
+        out = np.zeros((n_reads, 8), dtype=np.uint64)
+        self._check(self.lib.brx_last_read_cycles(self.ctx, out.ctypes.data, n_reads))
+        return out
 
     def final_launches(self):
         return int(self.lib.brx_last_final_launches(self.ctx))

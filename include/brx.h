@@ -232,6 +232,12 @@ int brx_align_batch(brx_ctx *ctx, uint32_t n_pairs,
 enum { BRX_STAGE_PLAN = 0, BRX_STAGE_BUILD = 1, BRX_STAGE_MUTATE = 2, BRX_STAGE_SCAN = 3,
        BRX_STAGE_FINAL = 4, BRX_STAGE_EMIT = 5, BRX_STAGE_COUNT = 6 };
 int brx_last_stage_ms(const brx_ctx *ctx, float ms[BRX_STAGE_COUNT]);
+/* Shader-clock cycles (s_memtime) each read of the last pipeline call spent in the two heavy
+ * kernels, 8 x u64 per read, copied to HOST memory h_out (valid until the next call on ctx):
+ *   [0] k_mutate total  [1] in-loop alignment forward  [2] in-loop alignment traceback
+ *   [3] k_final total   [4] final alignment forward    [5] final traceback   [6] qscore lookup
+ *   [7] words per lane (G) of the final alignment's band geometry                                */
+int brx_last_read_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
 /* number of k_final launches (scratch chunks) of the last call */
 uint32_t brx_last_final_launches(const brx_ctx *ctx);
 

@@ -1,0 +1,343 @@
+"""
+Generate tests/golden/*.json by RUNNING THE UNMODIFIED REFERENCE (/root/reference, Badread 0.4.2)
+in this container.  The reference imports the third-party `edlib` wheel, which is absent here, so
+oracle/shim/edlib (our canonical Myers aligner behind edlib's API) stands in for it; everything
+else executed below is the reference's own code.  The fixtures travel to the GPU box, the
+reference does not.
+
+Fixtures written (each records reference version + how it was produced):
+
+  misc.json            known answers of the reference's pure helpers on the path:
+                       reverse_complement, identity_from_edlib_cigar, get_target_size,
+                       align_sequences_from_edlib_cigar, gamma/beta parameterisation, load_fasta.
+  align_kmers.json     error_model.align_kmers(kmer, alt) for every case of
+                       test/test_error_model.py with a unique optimum + sampled rows of the
+                       built-in models, and ErrorModel(...).alternatives for sampled k-mers.
+  fragments.json       get_real_fragment / get_junk_fragment / add_glitches / adapters run with the
+                       reference's random sources replaced by scripted values (the values OUR planner
+                       drew for a set of reads), so the deterministic string logic -- linear clip,
+                       circular wrap, hairpin, strand coordinates, glitch splice -- is the reference's.
+  sequence_fragment.json
+                       the reference's sequence_fragment() + get_qscores() (simulate.py:256-358,
+                       qscore_model.py:32-75) REPLAYED with our counter-based draws: random.randint,
+                       get_random_sequence, ErrorModel.add_errors_to_kmer and the qscore sampling
+                       are scripted from Philox (include/brx_spec.h), every other line -- loop
+                       bounds, est**1.5, the 25-change alignment cadence and blending, trimming,
+                       cigar windows and the fallback rule -- is executed by the reference.  The
+                       oracle (and the HIP path) must reproduce seq / quals / identity exactly.
+
+Run:  python tools/make_golden.py        (needs /root/reference; ~1 minute)
+"""
+import collections
+import gzip
+import io
+import json
+import os
+import random
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = '/root/reference'
+for p in (REPO, os.path.join(REPO, 'oracle'), os.path.join(REPO, 'tests'), os.path.join(REPO, 'oracle', 'shim'), REFERENCE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import badread.error_model as ref_em          # noqa: E402  (the reference)
+import badread.fragment_lengths as ref_fl     # noqa: E402
+import badread.identities as ref_id           # noqa: E402
+import badread.misc as ref_misc               # noqa: E402
+import badread.qscore_model as ref_qm         # noqa: E402
+import badread.simulate as ref_sim            # noqa: E402
+import badread.version as ref_version         # noqa: E402
+
+import pyoracle                               # noqa: E402
+from philox import Draws, random_base         # noqa: E402  (tests/philox.py: Python restatement of brx_spec.h)
+from badread_amd.error_model import ErrorModel          # noqa: E402
+from badread_amd.qscore_model import QScoreModel, cigar_key  # noqa: E402
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+NULL = io.StringIO()
+HEADER = {'reference': f'rrwick/Badread {ref_version.__version__}', 'aligner': 'oracle/shim/edlib (oracle/myers_ref.c)',
+          'generator': 'tools/make_golden.py'}
+
+
+def dump(name, obj):
+    obj = dict(HEADER, **obj)
+    path = os.path.join(GOLDEN, name)
+    data = json.dumps(obj, separators=(',', ':')).encode()
+    if name.endswith('.gz'):
+        with gzip.GzipFile(path, 'wb', mtime=0) as f:
+            f.write(data)
+    else:
+        with open(path, 'wb') as f:
+            f.write(data)
+    print(f'{name}: {os.path.getsize(path)} bytes')
+
+
+# ---------------------------------------------------------------------------------------------
+def make_misc():
+    rng = random.Random(1)
+    revcomp = [''.join(rng.choice('ACGTRYSWKMBVDHNacgtn.-?XZ') for _ in range(rng.randint(0, 40))) for _ in range(40)]
+    cigars = ['5=', '3=1X2=', '2=1I3=2D1X', '', '10=5I5D', '1X', '7=1I7=1D7=1X7=']
+    quantities = ['100', '25x', '2.5x', '250M', '1.5g', '3k', '0.1x', '7K', '1X']
+    expand = [('ACGACTAGCTACG', 'ACGACTAGCTACG', '13='), ('ACGACTGCTACG', 'ACGACTAGCTACG', '6=1D6='),
+              ('ACGACTAGGCTACG', 'ACGACTAGCTACG', '8=1I5='), ('ACGACTTGCTACG', 'ACGACTAGCTACG', '6=1X6='),
+              ('AGCTAGCTAG', 'CTAGCTAGCT', '2I8=2D')]
+    fasta = os.path.join(GOLDEN, 'small_ref.fasta')
+    seqs, depths, circ, hl, hr = ref_misc.load_fasta(fasta)
+    out = {
+        'reverse_complement': [[s, ref_misc.reverse_complement(s)] for s in revcomp],
+        'identity_from_edlib_cigar': [[c, ref_misc.identity_from_edlib_cigar(c)] for c in cigars],
+        'get_target_size': [[q, 123456, ref_sim.get_target_size(123456, q)] for q in quantities],
+        'align_sequences_from_edlib_cigar': [[s, f, c, list(ref_qm.align_sequences_from_edlib_cigar(s, f, c))] for s, f, c in expand],
+        'gamma_parameters': [[m, s, list(ref_fl.gamma_parameters(m, s))] for m, s in ((15000, 13000), (100, 10), (5000, 5000))],
+        'beta_parameters': [[m, s, x, list(ref_id.beta_parameters(m, s, x))] for m, s, x in ((95, 2.5, 99), (85, 5, 95), (90, 4, 100))],
+        'load_fasta': {'file': 'small_ref.fasta', 'seqs': seqs, 'depths': depths, 'circular': circ,
+                       'hairpin_left': hl, 'hairpin_right': hr},
+    }
+    dump('misc.json', out)
+
+
+# ---------------------------------------------------------------------------------------------
+def make_align_kmers():
+    # unique-optimum cases of test/test_error_model.py plus assorted shapes
+    pairs = [('ACGT', 'ACGT'), ('ACGT', 'AGGT'), ('ACGT', 'AGT'), ('ACGT', 'AT'), ('ACGT', 'ACCGT'), ('ACGTA', 'ACCTA'),
+             ('ACGTACG', 'ACGTACG'), ('ACGTACG', 'ACTACG'), ('ACGTACG', 'ACGTTACG'), ('ACGTACG', 'AG'), ('ACGTACG', 'ACGATAACG'),
+             ('GATTACA', 'GATACA'), ('GATTACA', 'GTTTTTTACA'), ('CCCCCCC', 'CC'), ('ACGTACG', 'AGTACCCG')]
+    cases = [[k, a, ref_em.align_kmers(k, a)] for k, a in pairs]
+    rng = random.Random(7)
+    models = {}
+    for name in ('nanopore2023', 'pacbio2021', 'nanopore2018'):
+        path = os.path.join(REFERENCE, 'badread', 'error_models', name + '.gz')
+        rows = []
+        with gzip.open(path, 'rt') as f:
+            lines = f.readlines()
+        for line in rng.sample(lines, 12):
+            kmer = line.split(',', 1)[0]
+            entries = [x.split(',') for x in line.strip().split(';') if x]
+            alts = [e[0] for e in entries]
+            rows.append({'kmer': kmer, 'alts': alts, 'probs': [float(e[1]) for e in entries],
+                         'aligned': [ref_em.align_kmers(kmer, a) for a in alts]})
+        models[name] = rows
+    fixture = os.path.join(REFERENCE, 'test', '4-mer_error_model')
+    m = ref_em.ErrorModel(fixture, NULL)
+    four = {'kmer_size': m.kmer_size, 'n_rows': len(m.alternatives),
+            'rows': {k: {'alts': m.alternatives[k], 'probs': m.probabilities[k]} for k in ('AAAA', 'ACGT', 'TTTT', 'GATC', 'CGCG')},
+            'text': open(fixture).read()}
+    dump('align_kmers.json', {'cases': cases, 'models': models, 'four_mer_model': four})
+
+
+# ---------------------------------------------------------------------------------------------
+class Script(object):
+    """Scripted stand-ins for the reference's random sources while one reference function runs."""
+
+    def __init__(self):
+        self.values = collections.deque()
+
+    def push(self, *vals):
+        self.values.extend(vals)
+
+    def pop(self):
+        return self.values.popleft()
+
+
+def make_fragments():
+    """The reference's fragment/glitch string logic on scripted coordinates (no randomness left)."""
+    fasta = os.path.join(GOLDEN, 'small_ref.fasta')
+    seqs, depths, circ, hl, hr = ref_misc.load_fasta(fasta)
+    rev = {n: ref_misc.reverse_complement(s) for n, s in seqs.items()}
+    names = list(seqs)
+    Args = collections.namedtuple('Args', ['junk_reads', 'random_reads'])
+    rng = random.Random(11)
+    real = []
+    for _ in range(160):
+        contig = rng.choice(names)
+        L = len(seqs[contig])
+        length = rng.choice([1, 2, 10, L // 3, L - 1, L, L + 1, 2 * L, rng.randint(1, 2 * L + 5)])
+        strand_plus = rng.random() < 0.5
+        start = rng.randint(0, L - 1)
+        script = Script()
+        # get_real_fragment draws: random.choices (only if >1 contig), random_chance(0.5), random.randint(0, len-1)
+        orig = (ref_sim.random.choices, ref_sim.random_chance, ref_sim.random.randint)
+        ref_sim.random.choices = lambda pop, weights=None: [contig]
+        ref_sim.random_chance = lambda p: strand_plus
+        ref_sim.random.randint = lambda a, b: start
+        try:
+            seq, info = ref_sim.get_real_fragment(length, seqs, rev, names, [depths[n] * len(seqs[n]) for n in names],
+                                                  circ, hl, hr)
+        finally:
+            ref_sim.random.choices, ref_sim.random_chance, ref_sim.random.randint = orig
+        real.append({'contig': contig, 'length': length, 'strand': '+' if strand_plus else '-', 'start': start,
+                     'seq': seq, 'info': info})
+        del script
+    # glitches: np.random.geometric and get_random_sequence scripted
+    glitches = []
+    for _ in range(30):
+        frag = ''.join(rng.choice('ACGT') for _ in range(rng.randint(1, 400)))
+        rate, size, skip = rng.choice([(50, 5, 5), (20, 0, 3), (30, 4, 0), (1, 1, 1), (0.5, 0.5, 0.5), (100, 10, 10)])
+        draws = [rng.randint(1, 60) for _ in range(200)]
+        fills = [''.join(rng.choice('ACGT') for _ in range(80)) for _ in range(100)]
+        dq, fq = collections.deque(draws), collections.deque(fills)
+        used = []
+
+        def geo(p=None):
+            v = dq.popleft()
+            used.append(v)
+            return v
+
+        def fill(n):
+            s = fq.popleft()[:n]
+            assert len(s) == n
+            return s
+        orig = (ref_sim.np.random.geometric, ref_sim.get_random_sequence)
+        ref_sim.np.random.geometric = geo
+        ref_sim.get_random_sequence = fill
+        try:
+            out = ref_sim.add_glitches(frag, rate, size, skip)
+        finally:
+            ref_sim.np.random.geometric, ref_sim.get_random_sequence = orig
+        glitches.append({'fragment': frag, 'rate': rate, 'size': size, 'skip': skip, 'geometric': used,
+                         'fills': fills[:len(fills) - len(fq)], 'out': out})
+    # adapters: scripted chance + beta
+    adapters = []
+    for _ in range(40):
+        adapter = ''.join(rng.choice('ACGT') for _ in range(rng.randint(1, 40)))
+        rate, amount = rng.choice([(0.9, 0.6), (0.5, 0.2), (1.0, 1.0), (0.3, 0.999)])
+        chance, beta = rng.random(), rng.random()
+        orig = (ref_sim.random_chance, ref_sim.np.random.beta)
+        ref_sim.random_chance = lambda p: chance < p
+        ref_sim.np.random.beta = lambda a, b: beta
+        try:
+            s = ref_sim.get_start_adapter(rate, amount, adapter)
+            e = ref_sim.get_end_adapter(rate, amount, adapter)
+        finally:
+            ref_sim.random_chance, ref_sim.np.random.beta = orig
+        adapters.append({'adapter': adapter, 'rate': rate, 'amount': amount, 'chance': chance, 'beta': beta, 'start': s, 'end': e})
+    junk = []
+    for _ in range(20):
+        unit = ''.join(rng.choice('ACGT') for _ in range(rng.randint(1, 5)))
+        length = rng.randint(1, 300)
+        orig = (ref_sim.random.randint, ref_sim.get_random_sequence)
+        ref_sim.random.randint = lambda a, b: len(unit)
+        ref_sim.get_random_sequence = lambda n: unit
+        try:
+            out = ref_sim.get_junk_fragment(length)
+        finally:
+            ref_sim.random.randint, ref_sim.get_random_sequence = orig
+        junk.append({'unit': unit, 'length': length, 'out': out})
+    dump('fragments.json', {'fasta': 'small_ref.fasta', 'real': real, 'glitches': glitches, 'adapters': adapters, 'junk': junk})
+
+
+# ---------------------------------------------------------------------------------------------
+class ReplayErrorModel(object):
+    """add_errors_to_kmer scripted by the current iteration's Philox words (w2 picks the
+    alternative, w3 drives add_one_random_change), decided by the oracle's table walk."""
+
+    def __init__(self, engine, name, state):
+        self.engine, self.state = engine, state
+        self.type = 'random' if name == 'random' else 'model'
+        self.kmer_size = 1 if name == 'random' else 7
+
+    def add_errors_to_kmer(self, kmer):
+        codes = np.array(['ACGTN'.index(c) if c in 'ACGTN' else 5 for c in kmer], dtype=np.uint8)
+        w = self.state['w']
+        _, parts = self.engine.choose_alt(codes, w[2], w[3])
+        return [''.join('ACGTN'[c] if c < 5 else '?' for c in p) for p in parts]
+
+
+class ReplayQScoreModel(object):
+    """get_qscore with the reference's lookup + fallback loop (qscore_model.py:273-287) on the
+    reference's own dicts; only random.choices is replaced by our threshold walk."""
+
+    def __init__(self, ref_model, tables, draws, state):
+        self.ref, self.t, self.draws, self.state = ref_model, tables, draws, state
+        self.kmer_size, self.type = ref_model.kmer_size, ref_model.type
+        self.row_of = {}
+        keys, rows = tables['hash_key'], tables['hash_row']
+        for slot in np.flatnonzero(keys != np.uint64(0xFFFFFFFFFFFFFFFF)):
+            self.row_of[int(keys[slot])] = int(rows[slot])
+
+    def get_qscore(self, cigar):
+        s = self.state['qpos']
+        self.state['qpos'] += 1
+        while True:
+            assert len(cigar.replace('D', '')) % 2 == 1
+            if cigar in self.ref.scores:
+                row = self.row_of[cigar_key(cigar, self.t['gap_bits'])]
+                e0, e1 = int(self.t['row_off'][row]), int(self.t['row_off'][row + 1])
+                assert list(self.t['score'][e0:e1]) == list(self.ref.scores[cigar])
+                u = self.draws.qs(s)
+                e = e0
+                while e < e1 - 1 and not (u < int(self.t['thr'][e])):
+                    e += 1
+                return ref_qm.qscore_val_to_char(int(self.t['score'][e]))
+            cigar = cigar[1:-1].strip('D')
+
+
+def replay_sequence_fragment(engine, em_name, qm_name, ref_qmodel, qtables, fragment, target, seed, read):
+    draws = Draws(seed, read)
+    state = {'w': None, 'iter': 0, 'naligns': 0, 'qpos': 0, 'pads': 0}
+    em = ReplayErrorModel(engine, em_name, state)
+    qm = ReplayQScoreModel(ref_qmodel, qtables, draws, state)
+    k = em.kmer_size
+    n = len(fragment) + 2 * k
+
+    def fake_randint(a, b):
+        if a == 0 and b == n - 1 - k:                     # k-mer position (simulate.py:294)
+            state['w'] = draws.mut(state['iter'])
+            state['iter'] += 1
+            return draws.below64(state['w'][0], state['w'][1], b + 1)
+        assert a == 0 and b == n - 1000, (a, b, n)        # alignment window (simulate.py:338)
+        w = draws.win(state['naligns'])
+        state['naligns'] += 1
+        return draws.below64(w[0], w[1], b + 1)
+
+    def fake_random_sequence(length):                     # the two pads (simulate.py:260)
+        serial = state['pads']
+        state['pads'] += 1
+        return ''.join('ACGT'[random_base(seed, read, serial, p)] for p in range(length))
+
+    orig = (ref_sim.random.randint, ref_sim.get_random_sequence)
+    ref_sim.random.randint, ref_sim.get_random_sequence = fake_randint, fake_random_sequence
+    try:
+        seq, qual, ident, ident_q = ref_sim.sequence_fragment(fragment, target, em, qm)
+    finally:
+        ref_sim.random.randint, ref_sim.get_random_sequence = orig
+    return {'em': em_name, 'qm': qm_name, 'fragment': fragment, 'target': target, 'seed': seed, 'read': read,
+            'seq': seq, 'qual': qual, 'identity': ident, 'identity_by_qscores': ident_q,
+            'iterations': state['iter'], 'alignments': state['naligns']}
+
+
+def make_sequence_fragment():
+    import helpers as H
+    rng = random.Random(5)
+    cases = []
+    for em_name, qm_name in (('nanopore2023', 'nanopore2023'), ('random', 'ideal'), ('pacbio2021', 'pacbio2021'),
+                             ('random', 'random'), ('nanopore2018', 'nanopore2018')):
+        engine = H.oracle_engine()
+        engine.set_error_model(ErrorModel(em_name, NULL).tables())
+        qtables = QScoreModel(qm_name, NULL).tables()
+        engine.set_qscore_model(qtables)
+        random.seed(12345)                                    # ref 'random'/'ideal' models are deterministic tables
+        ref_qmodel = ref_qm.QScoreModel(qm_name, NULL)
+        specs = [(30, 0.9), (300, 1.0), (700, 0.85), (979, 0.9), (986, 0.93), (987, 0.9), (1500, 0.95), (2600, 0.8), (4000, 0.97)]
+        if em_name != 'nanopore2023':
+            specs = specs[:6] + [(2000, 0.9)]
+        for idx, (L, target) in enumerate(specs):
+            alphabet = 'ACGT' if idx % 4 else 'ACGTN'
+            fragment = ''.join(rng.choice(alphabet) for _ in range(L))
+            cases.append(replay_sequence_fragment(engine, em_name, qm_name, ref_qmodel, qtables, fragment, target,
+                                                  seed=1000 + idx, read=7 * idx + 1))
+            print(f'  {em_name}/{qm_name} L={L} target={target}: {cases[-1]["iterations"]} iterations, '
+                  f'{cases[-1]["alignments"]} alignments, identity {cases[-1]["identity"]:.4f}')
+    dump('sequence_fragment.json.gz', {'cases': cases})
+
+
+if __name__ == '__main__':
+    os.makedirs(GOLDEN, exist_ok=True)
+    make_misc()
+    make_align_kmers()
+    make_fragments()
+    make_sequence_fragment()
