@@ -211,22 +211,23 @@ class Shard(object):
         return first + lo, hi - lo
 
     def gather_arrays(self, arr):
-        """Every rank's uint8/uint32 numpy array, in rank order, on every rank (sizes may differ)."""
+        """Every rank's 1-D numpy array (any fixed-size dtype), in rank order, on every rank; sizes may differ."""
         if self.world == 1:
             return [arr]
         import torch
         dist = self.dist
         dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
-        size = torch.tensor([arr.size], dtype=torch.int64, device=dev)
+        raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)            # collectives move bytes
+        size = torch.tensor([raw.size], dtype=torch.int64, device=dev)
         sizes = [torch.zeros_like(size) for _ in range(self.world)]
         dist.all_gather(sizes, size)
         sizes = [int(s.item()) for s in sizes]
-        cap = max(max(sizes), 1)
-        mine = torch.zeros(cap, dtype=torch.from_numpy(arr[:0].copy()).dtype, device=dev)
-        mine[:arr.size] = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+        mine = torch.zeros(max(max(sizes), 1), dtype=torch.uint8, device=dev)
+        if raw.size:
+            mine[:raw.size] = torch.from_numpy(raw.copy()).to(dev)
         parts = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine)
-        return [p[:n].cpu().numpy() for p, n in zip(parts, sizes)]
+        return [p[:n].cpu().numpy().view(arr.dtype) for p, n in zip(parts, sizes)]
 
 
 def cut_point(seq_lens, running_total, target_size):

@@ -59,6 +59,28 @@ void orc_set_error_model(orc_ctx *c, const brx_error_model *m) { c->em = *m; }
 void orc_set_qscore_model(orc_ctx *c, const brx_qscore_model *m) { c->qm = *m; }
 void orc_set_params(orc_ctx *c, const brx_sim_params *p) { c->p = *p; }
 
+/* ------------------------------------------------------------------ decision trace
+ * Every primitive random decision of plan_read can be logged, so that tools/make_golden.py can feed
+ * the SAME decisions to the reference's build_fragment (simulate.py:91-115) through its random
+ * sources and compare the resulting fragment strings with ours. */
+enum { TR_U = 0,        /* raw uniform behind random.random(): chance tests and get_fragment_type   */
+       TR_LENGTH = 1,   /* FragmentLengths.get_fragment_length()                                    */
+       TR_CONTIG = 2,   /* random.choices(ref_contigs, weights)                                     */
+       TR_START = 3,    /* random.randint(0, len-1)                                                 */
+       TR_JUNKLEN = 4,  /* random.randint(1, 5)                                                     */
+       TR_JUNKUNIT = 5, /* get_random_sequence(repeat_length): 2 bits per base                      */
+       TR_SERIAL = 6,   /* get_random_sequence(n) for a random fragment / glitch insert: our serial */
+       TR_ADAPTLEN = 7, /* int(len(adapter) * beta)                                                 */
+       TR_GEO = 8,      /* np.random.geometric                                                      */
+       TR_IDENTITY = 9  /* Identities.get_identity()                                                */ };
+typedef struct { int32_t *kinds; double *vals; int cap, n; } orc_trace;
+static __thread orc_trace *g_trace = NULL;
+static void tr(int kind, double v) {
+    if (g_trace && g_trace->n < g_trace->cap) { g_trace->kinds[g_trace->n] = kind; g_trace->vals[g_trace->n] = v; }
+    if (g_trace) g_trace->n += 1;
+}
+static double draw_u(brx_rng *g) { double u = brx_next_double(g); tr(TR_U, u); return u; }
+
 /* ------------------------------------------------------------------ plan */
 static void push_seg(oplan *pl, uint32_t type, uint32_t a, uint32_t b, uint64_t start, uint64_t len) {
     if (len == 0) return;
@@ -80,10 +102,14 @@ static void push_piece(oplan *pl, opiece pc) {
 
 /* fragment_lengths.py:47-52 */
 static uint64_t draw_fragment_length(const brx_sim_params *p, brx_rng *g) {
-    if (p->frag_stdev == 0.0) return (uint64_t)brx_round_half_even(p->frag_mean);
-    double v = brx_std_gamma(g, p->gamma_k) * p->gamma_t;
-    int64_t L = brx_round_half_even(v);
-    return (uint64_t)(L < 1 ? 1 : L);
+    int64_t L;
+    if (p->frag_stdev == 0.0) L = brx_round_half_even(p->frag_mean);
+    else {
+        L = brx_round_half_even(brx_std_gamma(g, p->gamma_k) * p->gamma_t);
+        if (L < 1) L = 1;
+    }
+    tr(TR_LENGTH, (double)L);
+    return (uint64_t)L;
 }
 
 /* simulate.py:183-246; returns 0 on failure (the '' return at :213) */
@@ -93,8 +119,9 @@ static int real_fragment(const orc_ctx *c, brx_rng *g, uint64_t length, oplan *b
     if (r->n_contigs > 1) {                                    /* random.choices, :189 */
         double x = brx_next_double(g) * r->total_weight;
         while (contig < r->n_contigs - 1 && !(r->d_cum_weight[contig] > x)) ++contig;
+        tr(TR_CONTIG, (double)contig);
     }
-    uint32_t strand = (brx_next_double(g) < 0.5) ? 0u : 1u;    /* :194 */
+    uint32_t strand = (draw_u(g) < 0.5) ? 0u : 1u;             /* :194 */
     const brx_contig *ct = &r->d_contigs[contig];
     int circular = ct->flags & 1u;
     int hairpin = strand == 0 ? ((ct->flags >> 2) & 1u) : ((ct->flags >> 1) & 1u);   /* :202 */
@@ -108,6 +135,7 @@ static int real_fragment(const orc_ctx *c, brx_rng *g, uint64_t length, oplan *b
     }
     if (length > len_c && circular) return 0;                  /* :212-213 */
     uint64_t start = brx_next_below(g, len_c);                 /* :215 */
+    tr(TR_START, (double)start);
     uint64_t end = start + length;
     if (circular) {                                            /* :219-226 */
         pc.start = start; pc.end = end;
@@ -141,11 +169,12 @@ static int real_fragment(const orc_ctx *c, brx_rng *g, uint64_t length, oplan *b
 static int get_fragment(const orc_ctx *c, brx_rng *g, oplan *base, uint32_t *next_serial) {
     const brx_sim_params *p = &c->p;
     uint64_t length = draw_fragment_length(p, g);
-    double u = brx_next_double(g);                             /* :174 */
+    double u = draw_u(g);                                      /* :174 */
     if (u < p->junk_rate) {                                    /* :249-253 */
         uint32_t unit_len = 1u + (uint32_t)brx_next_below(g, 5);
         uint32_t unit = 0;
         for (uint32_t i = 0; i < unit_len; ++i) unit |= (uint32_t)brx_next_below(g, 4) << (2 * i);
+        tr(TR_JUNKLEN, (double)unit_len); tr(TR_JUNKUNIT, (double)unit);
         opiece pc = { PC_JUNK, 0, 0, 0, 0, 0 };
         push_piece(base, pc);
         push_seg(base, SEG_JUNK, unit, unit_len, 0, length);
@@ -154,6 +183,7 @@ static int get_fragment(const orc_ctx *c, brx_rng *g, oplan *base, uint32_t *nex
     if (u < p->junk_rate + p->random_rate) {
         opiece pc = { PC_RANDOM, 0, 0, 0, 0, 0 };
         push_piece(base, pc);
+        tr(TR_SERIAL, (double)*next_serial);
         push_seg(base, SEG_RANDOM, (*next_serial)++, 0, 0, length);
         return 1;
     }
@@ -187,30 +217,32 @@ static void plan_read(const orc_ctx *c, uint64_t seed, uint64_t read, oplan *out
 
     /* start adapter, simulate.py:361-370 */
     if (p->start_adapter_len > 0 && p->start_rate != 0.0 && p->start_amount != 0.0) {
-        if (brx_next_double(&g) < p->start_rate) {
+        if (draw_u(&g) < p->start_rate) {
             if (p->start_amount == 1.0) push_seg(&base, SEG_ADAPTER, 0, 0, 0, p->start_adapter_len);
             else {
                 double f = brx_beta(&g, 2.0 * p->start_amount, 2.0 - 2.0 * p->start_amount);
                 uint64_t L = (uint64_t)((double)p->start_adapter_len * f);       /* :387 int() */
+                tr(TR_ADAPTLEN, (double)L);
                 push_seg(&base, SEG_ADAPTER, 0, 0, p->start_adapter_len - L, L); /* suffix, :368 */
             }
         }
     }
     int ok = get_fragment(c, &g, &base, &next_serial);
-    while (ok && brx_next_double(&g) < p->chimera_rate) {                       /* :101-110 */
-        if (brx_next_double(&g) < 0.25) push_seg(&base, SEG_ADAPTER, 1, 0, 0, p->end_adapter_len);
-        if (brx_next_double(&g) < 0.25) push_seg(&base, SEG_ADAPTER, 0, 0, 0, p->start_adapter_len);
+    while (ok && draw_u(&g) < p->chimera_rate) {                                /* :101-110 */
+        if (draw_u(&g) < 0.25) push_seg(&base, SEG_ADAPTER, 1, 0, 0, p->end_adapter_len);
+        if (draw_u(&g) < 0.25) push_seg(&base, SEG_ADAPTER, 0, 0, 0, p->start_adapter_len);
         ok = get_fragment(c, &g, &base, &next_serial);
     }
     if (!ok) { out->status |= BRX_RS_NOFRAG; out->pieces = base.pieces; out->n_pieces = base.n_pieces;
                base.pieces = NULL; plan_free(&base); return; }
     /* end adapter, simulate.py:373-381 */
     if (p->end_adapter_len > 0 && p->end_rate != 0.0 && p->end_amount != 0.0) {
-        if (brx_next_double(&g) < p->end_rate) {
+        if (draw_u(&g) < p->end_rate) {
             if (p->end_amount == 1.0) push_seg(&base, SEG_ADAPTER, 1, 0, 0, p->end_adapter_len);
             else {
                 double f = brx_beta(&g, 2.0 * p->end_amount, 2.0 - 2.0 * p->end_amount);
                 uint64_t L = (uint64_t)((double)p->end_adapter_len * f);
+                tr(TR_ADAPTLEN, (double)L);
                 push_seg(&base, SEG_ADAPTER, 1, 0, 0, L);                        /* prefix, :380 */
             }
         }
@@ -229,15 +261,17 @@ static void plan_read(const orc_ctx *c, uint64_t seed, uint64_t read, oplan *out
         uint64_t i = 0;
         for (;;) {
             uint64_t dist = (uint64_t)brx_geometric(&g, p_rate);
+            tr(TR_GEO, (double)dist);
             uint64_t e = i + dist < base_len ? i + dist : base_len;
             copy_range(&base, i, e, out);
             i += dist;
             if (i >= base_len) break;
             if (p->glitch_size > 0.0) {
                 uint64_t sz = (uint64_t)brx_geometric(&g, p_size);
+                tr(TR_GEO, (double)sz); tr(TR_SERIAL, (double)next_serial);
                 push_seg(out, SEG_RANDOM, next_serial++, 0, 0, sz);
             }
-            if (p->glitch_skip > 0.0) i += (uint64_t)brx_geometric(&g, p_skip);
+            if (p->glitch_skip > 0.0) { uint64_t sk = (uint64_t)brx_geometric(&g, p_skip); tr(TR_GEO, (double)sk); i += sk; }
             if (i >= base_len) break;
         }
     }
@@ -255,6 +289,37 @@ static void plan_read(const orc_ctx *c, uint64_t seed, uint64_t read, oplan *out
             double id = 1.0 - brx_exp((-q / 10.0) * 2.302585092994046);
             if (id >= 0.0 && id <= 100.0) { out->target_identity = id; break; }
         }
+    }
+    tr(TR_IDENTITY, out->target_identity);
+}
+
+/* the decisions of plan_read for one read, in order; returns their number (may exceed cap) */
+int orc_plan_trace(const orc_ctx *c, uint64_t seed, uint64_t read, int32_t *kinds, double *vals, int cap) {
+    orc_trace t = { kinds, vals, cap, 0 };
+    oplan pl;
+    g_trace = &t;
+    plan_read(c, seed, read, &pl);
+    g_trace = NULL;
+    plan_free(&pl);
+    return t.n;
+}
+
+/* brx_draw4 and the samplers of include/brx_spec.h, for known-answer and distribution tests */
+void orc_draw4(uint64_t seed, uint64_t read, uint32_t stream, uint64_t index, uint32_t out[4]) {
+    brx_draw4(seed, read, stream, index, out);
+}
+void orc_sample(int kind, double a, double b, uint64_t seed, uint64_t n, double *out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        brx_rng g;
+        brx_rng_init(&g, seed, i, BRX_ST_PLAN);
+        if (kind == 0) out[i] = brx_std_gamma(&g, a) * b;
+        else if (kind == 1) out[i] = brx_beta(&g, a, b);
+        else if (kind == 2) out[i] = a + b * brx_normal(&g);
+        else if (kind == 3) out[i] = (double)brx_geometric(&g, a);
+        else if (kind == 4) out[i] = brx_next_double(&g);
+        else if (kind == 5) out[i] = (double)brx_next_below(&g, (uint64_t)a);
+        else if (kind == 6) out[i] = brx_log(a + (double)i * b);
+        else if (kind == 7) out[i] = brx_exp(a + (double)i * b);
     }
 }
 

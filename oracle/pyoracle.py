@@ -76,8 +76,31 @@ def lib():
                                            ctypes.c_void_p, ctypes.c_void_p]
         L.orc_qscore_rows_probe.restype = ctypes.c_int
         L.orc_qscore_rows_probe.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_plan_trace.restype = ctypes.c_int
+        L.orc_plan_trace.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.orc_draw4.restype = None
+        L.orc_draw4.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p]
+        L.orc_sample.restype = None
+        L.orc_sample.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
         _lib = L
     return _lib
+
+
+TRACE_KINDS = ('U', 'LENGTH', 'CONTIG', 'START', 'JUNKLEN', 'JUNKUNIT', 'SERIAL', 'ADAPTLEN', 'GEO', 'IDENTITY')
+SAMPLE_KINDS = {'gamma': 0, 'beta': 1, 'normal': 2, 'geometric': 3, 'uniform': 4, 'below': 5, 'log': 6, 'exp': 7}
+
+
+def draw4(seed, read, stream, index):
+    out = (ctypes.c_uint32 * 4)()
+    lib().orc_draw4(seed, read, stream, index, out)
+    return list(out)
+
+
+def sample(kind, a, b, seed, n):
+    """n draws of one sampler of include/brx_spec.h (draw i uses read index i of the PLAN stream)."""
+    out = np.zeros(n, dtype=np.float64)
+    lib().orc_sample(SAMPLE_KINDS[kind], float(a), float(b), seed, n, out.ctypes.data)
+    return out
 
 
 def align(query, target, k=-1, want_ops=True, dp=False):
@@ -182,6 +205,15 @@ class OracleEngine(EngineBase):
                               ctypes.byref(npc), ctypes.byref(flen), ctypes.byref(tgt), ctypes.byref(status))
         return dict(segs=segs[:5 * ns.value].reshape(-1, 5).copy(), pieces=pieces[:6 * npc.value].reshape(-1, 6).copy(),
                     frag_len=flen.value, target=tgt.value, status=status.value)
+
+    def plan_trace(self, seed, read):
+        """[(kind name, value), ...]: every primitive random decision plan_read took for this read."""
+        cap = 4096
+        kinds = np.zeros(cap, dtype=np.int32)
+        vals = np.zeros(cap, dtype=np.float64)
+        n = self.L.orc_plan_trace(self.ctx, seed, read, kinds.ctypes.data, vals.ctypes.data, cap)
+        assert n <= cap
+        return [(TRACE_KINDS[k], float(v)) for k, v in zip(kinds[:n], vals[:n])]
 
     def fragment(self, seed, read):
         cap = 1 << 22

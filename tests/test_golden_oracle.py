@@ -1,0 +1,213 @@
+"""
+The CPU oracle (oracle/brx_oracle.c + myers_ref.c) pinned to the reference:
+
+  * build_fragment.json.gz / fragments.json: the reference's build_fragment / get_real_fragment /
+    add_glitches / adapters executed on scripted draws; the oracle's planner + fragment filler must
+    give the same strings and the same header info for the same decisions.
+  * sequence_fragment.json.gz: the reference's sequence_fragment + get_qscores executed with our
+    counter-based draws; the oracle must give the same read, qualities and identity, bit for bit.
+  * the aligner: block Myers with band doubling vs an independent full-matrix DP with the same
+    canonical traceback, and the alignments the reference's tests pin.
+
+CPU only.  The GPU tests (-m gpu) then require HIP == oracle byte for byte.
+"""
+import gzip
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+import pyoracle
+from badread_amd.engine import SimParams
+from badread_amd.error_model import ErrorModel
+from badread_amd.misc import load_fasta
+from badread_amd.qscore_model import QScoreModel
+from badread_amd.reference import PackedReference
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+NULL = io.StringIO()
+
+
+def load(name):
+    opener = gzip.open if name.endswith('.gz') else open
+    with opener(os.path.join(GOLDEN, name), 'rt') as f:
+        return json.load(f)
+
+
+def small_pref():
+    return PackedReference.from_seqs(*load_fasta(os.path.join(GOLDEN, 'small_ref.fasta')))
+
+
+# ------------------------------------------------------------------------------------------------
+def test_build_fragment_replay():
+    g = load('build_fragment.json.gz')
+    pref = small_pref()
+    n_checked = 0
+    for cfg in g['configs']:
+        params = SimParams(**cfg['params'])
+        eng = H.configure(H.oracle_engine(), pref, 'random', 'ideal', params)
+        for rd in cfg['reads']:
+            codes = eng.fragment(cfg['seed'], rd['read'])
+            assert pref.sym[codes].tobytes().decode() == rd['fragment'], (cfg['seed'], rd['read'])
+            plan = eng.plan(cfg['seed'], rd['read'])
+            assert plan['frag_len'] == len(rd['fragment'])
+            assert plan['target'] == rd['identity']
+            n_checked += 1
+        # header info text (contig,strand,range / junk_seq / random_seq / chimera / hairpin)
+        n = len(cfg['reads'])
+        out, st = eng.simulate_batch(cfg['seed'], 0, n)
+        lines = bytes(out).decode().split('\n')
+        headers = [ln for ln in lines if ln.startswith('@')]
+        hi = 0
+        for rd, s in zip(cfg['reads'], st):
+            if s['rec_len'] == 0:
+                continue
+            info = headers[hi].split(' ', 1)[1].rsplit(' length=', 1)[0]
+            assert info == rd['info'], (rd['read'], info, rd['info'])
+            assert f'error-free_length={len(rd["fragment"])} ' in headers[hi]
+            hi += 1
+    assert n_checked == 360
+
+
+def test_real_fragment_cases_against_reference_slicing():
+    """get_real_fragment on scripted (contig, strand, start, length): clip, wrap, hairpin, whole contig."""
+    g = load('fragments.json')
+    pref = small_pref()
+    eng = H.configure(H.oracle_engine(), pref, 'random', 'ideal', SimParams())
+    seqs = load('misc.json')['load_fasta']['seqs']
+    names = list(seqs)
+    for case in g['real']:
+        ci = names.index(case['contig'])
+        L, length, start, strand = len(seqs[case['contig']]), case['length'], case['start'], case['strand']
+        circ = pref.circular[case['contig']]
+        hairpin = pref.hairpin_right[case['contig']] if strand == '+' else pref.hairpin_left[case['contig']]
+        if case['seq'] == '':
+            assert circ and length > L
+            continue
+        # restate only WHICH ranges are read (that logic is what the planner kernels implement)...
+        if length >= L and not circ and not hairpin:
+            parts = [(strand, 0, L)]
+        elif circ:
+            end = start + length
+            parts = [(strand, start, length)] if end <= L else [(strand, start, L - start), (strand, 0, end - L)]
+        elif start + length > L and hairpin:
+            fwd = L - start
+            parts = [(strand, start, fwd), ('-' if strand == '+' else '+', 0, min(length - fwd, fwd))]
+        else:
+            parts = [(strand, start, min(start + length, L) - start)]
+        # ...and let the oracle's packed-reference reader produce the bases
+        got = ''.join(pref.sym[eng.ref_slice(ci, s, a, n)].tobytes().decode() for s, a, n in parts if n > 0)
+        assert got == case['seq'], case
+
+
+def test_glitch_adapter_junk_known_answers():
+    """add_glitches / adapters / junk of the reference on scripted draws, against the same splice
+    arithmetic the planner uses (copy `dist`, insert `size` random bases, skip `skip`)."""
+    g = load('fragments.json')
+    for case in g['glitches']:
+        frag, geo, fills = case['fragment'], list(case['geometric']), list(case['fills'])
+        out, i = [], 0
+        if case['rate'] == 0:
+            assert case['out'] == frag
+            continue
+        while True:
+            d = geo.pop(0)
+            out.append(frag[i:i + d])
+            i += d
+            if i >= len(frag):
+                break
+            if case['size'] > 0:
+                n = geo.pop(0)
+                out.append(fills.pop(0)[:n])
+            if case['skip'] > 0:
+                i += geo.pop(0)
+            if i >= len(frag):
+                break
+        assert ''.join(out) == case['out']
+    for case in g['adapters']:
+        ad, amount = case['adapter'], case['amount']
+        L = len(ad) if amount == 1.0 else int(len(ad) * case['beta'])
+        present = case['chance'] < case['rate']
+        assert case['start'] == (ad[len(ad) - L:] if present else '')
+        assert case['end'] == (ad[:L] if present else '')
+    for case in g['junk']:
+        assert case['out'] == (case['unit'] * (case['length'] // len(case['unit']) + 2))[:case['length']]
+
+
+# ------------------------------------------------------------------------------------------------
+def test_sequence_fragment_replay_bit_exact():
+    g = load('sequence_fragment.json.gz')
+    engines = {}
+    for c in g['cases']:
+        key = (c['em'], c['qm'])
+        if key not in engines:
+            e = H.oracle_engine()
+            e.set_error_model(ErrorModel(c['em'], NULL).tables())
+            e.set_qscore_model(QScoreModel(c['qm'], NULL).tables())
+            engines[key] = e
+        codes = np.array(['ACGTN'.index(ch) for ch in c['fragment']], dtype=np.uint8)
+        res, st = engines[key].sequence_fragments(c['seed'], c['read'], [codes], [c['target']])
+        seq = ''.join('ACGTN'[x] for x in res[0][0])
+        tag = (c['em'], c['qm'], len(c['fragment']), c['target'])
+        assert seq == c['seq'], tag
+        assert res[0][1].tobytes().decode() == c['qual'], tag
+        identity = st['n_match'][0] / st['n_cols'][0] if st['n_cols'][0] else 0.0
+        assert identity == c['identity'], tag                       # same matches / columns -> same double
+        idq = 1.0 - st['qerr_sum'][0] / st['padded_len'][0]
+        assert abs(idq - c['identity_by_qscores']) < 1e-12, tag      # summation order differs (histogram vs list)
+        assert st['loop_count'][0] in (c['iterations'], c['iterations'] + 1), tag
+
+
+# ------------------------------------------------------------------------------------------------
+CIGAR = '=XID'
+
+
+def cigar_of(ops):
+    out, i = [], 0
+    while i < len(ops):
+        j = i
+        while j < len(ops) and ops[j] == ops[i]:
+            j += 1
+        out.append(f'{j - i}{CIGAR[ops[i]]}')
+        i = j
+    return ''.join(out)
+
+
+def test_aligner_reference_vectors():
+    # orientation and unique optima pinned by the reference's tests (test_qscore_model.py:31-81, test_error_model.py)
+    for q, t, cigar in (('ACGACTAGCTACG', 'ACGACTAGCTACG', '13='), ('ACGACTGCTACG', 'ACGACTAGCTACG', '6=1D6='),
+                        ('ACGACTAGGCTACG', 'ACGACTAGCTACG', '8=1I5='), ('ACGACTTGCTACG', 'ACGACTAGCTACG', '6=1X6='),
+                        ('A', 'C', '1X'), ('AAAA', 'A', '1=3I'), ('A', 'AAAA', '1=3D')):
+        d, ops = pyoracle.align(q.encode(), t.encode())
+        assert cigar_of(ops) == cigar, (q, t, cigar_of(ops))
+        assert d == sum(1 for o in ops if o != 0)
+
+
+def test_aligner_myers_equals_full_dp():
+    rng = np.random.default_rng(3)
+    for it in range(400):
+        n = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 65, 100, 257, 700]))
+        q = H.random_dna(rng, n, 'ACGT' if it % 4 else 'AC')
+        t = H.mutate_seq(rng, q, float(rng.choice([0, 0.02, 0.1, 0.3, 0.6]))) or 'A'
+        if it % 7 == 0:
+            t = H.random_dna(rng, int(rng.integers(1, 2 * n + 2)))
+        d1, o1 = pyoracle.align(q.encode(), t.encode())
+        d2, o2 = pyoracle.align(q.encode(), t.encode(), dp=True)
+        assert d1 == d2 and H.first_diff(o1, o2) < 0, (q, t)
+        qn = int((o1 != 3).sum())
+        tn = int((o1 != 2).sum())
+        assert qn == len(q) and tn == len(t)
+
+
+def test_aligner_band_hint_does_not_change_the_path():
+    rng = np.random.default_rng(4)
+    q = H.random_dna(rng, 3000)
+    t = H.mutate_seq(rng, q, 0.08)
+    d, ops = pyoracle.align(q.encode(), t.encode())
+    for k in (d, d + 1, 2 * d, 3000):
+        d2, o2 = pyoracle.align(q.encode(), t.encode(), k=k)
+        assert d2 == d and H.first_diff(ops, o2) < 0
+    assert pyoracle.align(q.encode(), t.encode(), k=d - 1)[0] < 0       # too narrow a band is reported, not guessed

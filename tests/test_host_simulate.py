@@ -1,0 +1,161 @@
+"""
+Host logic of badread_amd.simulate on CPU: start-up pieces, the stop rule, batch-size and
+rank-count independence of the output (world_size 2 over gloo), fatal-exit behaviour.  The engine
+behind the driver here is the tests' oracle-backed checker (same EngineBase interface as HipEngine),
+so no GPU is needed; the product never takes this route.
+"""
+import io
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+from badread_amd import simulate as S
+from badread_amd.fragment_lengths import FragmentLengths
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SMALL_REF = os.path.join(HERE, 'golden', 'small_ref.fasta')
+
+
+class Args(object):
+    def __init__(self, **kw):
+        d = dict(reference=SMALL_REF, quantity='20x', mean_frag_length=400, frag_length_stdev=300,
+                 mean_identity=90, max_identity=98, identity_stdev=4, error_model='random', qscore_model='ideal',
+                 seed=5, start_adapter='90,60', end_adapter='50,20', start_adapter_seq='AATGTACTTCGTTCAGTTACGTATTGCT',
+                 end_adapter_seq='GCAATACGTAACTGAACGAAGT', junk_reads=1, random_reads=1, chimeras=1,
+                 glitch_rate=10000, glitch_size=25, glitch_skip=25, small_plasmid_bias=False)
+        d.update(kw)
+        self.__dict__.update(d)
+
+
+def run(args, max_batch=None, monkeypatch=None):
+    out, err = io.BytesIO(), io.StringIO()
+    if max_batch is not None:
+        monkeypatch.setattr(S, 'DEFAULT_MAX_BATCH', max_batch)
+    count, total = S.simulate(args, output=err, engine=H.oracle_engine(), stdout=out, shard=S.Shard())
+    return out.getvalue(), err.getvalue(), count, total
+
+
+def parse_fastq(data):
+    lines = data.decode().split('\n')
+    assert lines[-1] == ''
+    recs = [lines[i:i + 4] for i in range(0, len(lines) - 1, 4)]
+    for h, s, p, q in recs:
+        assert h.startswith('@') and p == '+' and len(s) == len(q) and len(s) > 0
+    return recs
+
+
+def test_stop_rule_and_format():
+    data, err, count, total = run(Args())
+    recs = parse_fastq(data)
+    target = 20 * 3621
+    assert len(recs) == count and sum(len(r[1]) for r in recs) == total
+    assert total >= target and total - len(recs[-1][1]) < target          # stops at the first read reaching the target
+    for h, s, _, _ in recs:
+        assert f'length={len(s)} ' in h and 'error-free_length=' in h and h.endswith('%')
+    assert f'Target read set size: {target:,} bp' in err and 'Simulating:' in err
+    assert 'Badread v' in err and 'Read glitches:' in err and 'Start adapter:' in err
+
+
+def test_output_independent_of_batch_size(monkeypatch):
+    a, _, _, _ = run(Args())
+    b, _, _, _ = run(Args(), max_batch=7, monkeypatch=monkeypatch)
+    c, _, _, _ = run(Args(), max_batch=64, monkeypatch=monkeypatch)
+    assert a == b == c
+
+
+def test_seed_changes_output_and_none_is_random():
+    a, _, _, _ = run(Args(seed=1, quantity='3x'))
+    b, _, _, _ = run(Args(seed=2, quantity='3x'))
+    c, _, _, _ = run(Args(seed=1, quantity='3x'))
+    assert a != b and a == c
+    d, _, _, _ = run(Args(seed=None, quantity='3x'))
+    e, _, _, _ = run(Args(seed=None, quantity='3x'))
+    assert d != e
+
+
+def test_quantity_forms():
+    for q, target in (('2500', 2500), ('3k', 3000), ('1x', 3621)):
+        _, err, _, total = run(Args(quantity=q))
+        assert f'Target read set size: {target:,} bp' in err and total >= target
+
+
+def test_incompatible_lengths_exit_like_the_reference(tmp_path):
+    # three 30 bp circular contigs with default lengths: adjust_depths cannot help -> fatal (simulate.py:159-165,526)
+    ref = tmp_path / 'tiny.fasta'
+    ref.write_text('>a circular=true\n' + 'ACGT' * 8 + '\n>b circular=true\n' + 'GGCA' * 8 + '\n')
+    with pytest.raises(SystemExit) as ex:
+        run(Args(reference=str(ref), mean_frag_length=15000, frag_length_stdev=13000))
+    assert 'fragment length' in str(ex.value) or 'failed to generate' in str(ex.value)
+    # --small_plasmid_bias skips the depth adjustment; a read whose length never fits still fails 1000 times
+    with pytest.raises(SystemExit) as ex:
+        run(Args(reference=str(ref), mean_frag_length=15000, frag_length_stdev=0, small_plasmid_bias=True,
+                 junk_reads=0, random_reads=0, chimeras=0))
+    assert str(ex.value) == S.NOFRAG_MESSAGE
+    # fragments that fit are fine
+    _, _, count, _ = run(Args(reference=str(ref), mean_frag_length=20, frag_length_stdev=5, quantity='2x',
+                              junk_reads=0, random_reads=0, chimeras=0))
+    assert count >= 1
+
+
+def test_adjust_depths_matches_the_reference_formula():
+    pref = H.small_reference()[0]
+    fl = FragmentLengths(3000, 2500, io.StringIO())
+    rng = np.random.RandomState(3)
+    lengths = fl.sample_many(S.ADJUST_SAMPLES, np.random.RandomState(3))
+    got = S.adjust_depths(pref, fl, False, rng)
+    total = lengths.sum()
+    for name, L in zip(pref.names, pref.lengths):
+        if pref.circular[name]:
+            expect = pref.depths[name] * total / lengths[lengths <= L].sum()
+        else:
+            expect = pref.depths[name] * total / np.minimum(lengths, L).sum()
+        assert abs(got[name] - expect) <= 1e-12 * expect
+    same = S.adjust_depths(pref, fl, True, np.random.RandomState(3))
+    for name in pref.names:
+        if pref.circular[name]:
+            assert same[name] == pref.depths[name]
+
+
+def test_cut_point_and_plan_batch():
+    assert S.cut_point([10, 0, 5, 7], 0, 15) == 2
+    assert S.cut_point([10, 0, 5, 7], 0, 16) == 3
+    assert S.cut_point([10, 0, 5, 7], 0, 23) is None
+    assert S.cut_point([0, 0], 100, 50) is None            # empty reads never stop the loop
+    assert S.plan_batch(1500000, 15000.0, 1, 16384) % 64 == 0
+    assert S.plan_batch(10 ** 12, 15000.0, 8, 16384) == 8 * 16384
+    sh = S.Shard(1, 2)
+    assert sh.slice_of(100, 10) == (105, 5) and S.Shard(0, 2).slice_of(100, 9) == (100, 5) and sh.slice_of(100, 9) == (105, 4)
+
+
+WORKER = r'''
+import io, os, sys
+sys.path[:0] = [{repo!r}, {repo!r} + '/oracle', {repo!r} + '/tests']
+import helpers as H
+from badread_amd import simulate as S
+from test_host_simulate import Args
+S.DEFAULT_MAX_BATCH = 24
+shard = S.Shard.from_env()
+out = io.BytesIO()
+S.simulate(Args(), output=io.StringIO(), engine=H.oracle_engine(), stdout=out, shard=shard)
+if shard.rank == 0:
+    open({outfile!r}, 'wb').write(out.getvalue())
+else:
+    assert out.getvalue() == b''
+'''
+
+
+def test_two_ranks_over_gloo_give_the_single_process_bytes(tmp_path, monkeypatch):
+    single, _, _, _ = run(Args(), max_batch=24, monkeypatch=monkeypatch)
+    outfile = str(tmp_path / 'ranks.fastq')
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER.format(repo=os.path.dirname(HERE), outfile=outfile))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29611')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29611', str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(outfile, 'rb').read() == single

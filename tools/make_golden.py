@@ -17,7 +17,10 @@ Fixtures written (each records reference version + how it was produced):
                        reference's random sources replaced by scripted values (the values OUR planner
                        drew for a set of reads), so the deterministic string logic -- linear clip,
                        circular wrap, hairpin, strand coordinates, glitch splice -- is the reference's.
-  sequence_fragment.json
+  build_fragment.json.gz
+                       the reference's build_fragment (simulate.py:91-115) replayed with the decisions
+                       our planner took (oracle plan_trace) -- see make_build_fragment().
+  sequence_fragment.json.gz
                        the reference's sequence_fragment() + get_qscores() (simulate.py:256-358,
                        qscore_model.py:32-75) REPLAYED with our counter-based draws: random.randint,
                        get_random_sequence, ErrorModel.add_errors_to_kmer and the qscore sampling
@@ -231,6 +234,123 @@ def make_fragments():
 
 
 # ---------------------------------------------------------------------------------------------
+def make_build_fragment():
+    """
+    The reference's build_fragment (simulate.py:91-115: adapters, get_fragment with its 1000-try loop,
+    chimeras, add_glitches) REPLAYED with the decisions our planner took for a set of read indices:
+    oracle.plan_trace() lists every primitive draw, and each of the reference's random sources is
+    replaced by a queue of them.  What the reference then computes -- which contig string is sliced
+    where, wrap/clip/hairpin, strand coordinates, junk repeat, glitch splice, info text -- is its own.
+    """
+    import helpers as H
+    from badread_amd.engine import SimParams
+    from badread_amd.reference import PackedReference
+    fasta = os.path.join(GOLDEN, 'small_ref.fasta')
+    seqs, depths, circ, hl, hr = ref_misc.load_fasta(fasta)
+    rev = {n: ref_misc.reverse_complement(s) for n, s in seqs.items()}
+    names = list(seqs)
+    weights = [depths[n] * len(seqs[n]) for n in names]
+    pref = PackedReference.from_seqs(seqs, depths, circ, hl, hr)
+    configs = [
+        dict(frag_mean=400, frag_stdev=350, junk_rate=0.05, random_rate=0.05, chimera_rate=0.15,
+             glitch_rate=150, glitch_size=6, glitch_skip=5),
+        dict(frag_mean=900, frag_stdev=900, junk_rate=0.0, random_rate=0.0, chimera_rate=0.0,
+             glitch_rate=0, glitch_size=0, glitch_skip=0, start_adapter='', end_adapter=''),
+        dict(frag_mean=120, frag_stdev=0, junk_rate=0.2, random_rate=0.2, chimera_rate=0.3,
+             glitch_rate=40, glitch_size=0.5, glitch_skip=0, start_rate=1.0, start_amount=1.0, end_rate=1.0, end_amount=0.9),
+    ]
+    out_cfgs = []
+    Args = collections.namedtuple('Args', ['junk_reads', 'random_reads', 'chimeras', 'start_adapter_seq', 'end_adapter_seq',
+                                           'glitch_rate', 'glitch_size', 'glitch_skip'])
+    for ci, cfg in enumerate(configs):
+        params = SimParams(**cfg)
+        engine = H.configure(H.oracle_engine(), pref, 'random', 'ideal', params)
+        args = Args(params.junk_rate * 100, params.random_rate * 100, params.chimera_rate * 100, params.start_adapter,
+                    params.end_adapter, params.glitch_rate, params.glitch_size, params.glitch_skip)
+        seed = 900 + ci
+        reads = []
+        for read in range(120):
+            trace = engine.plan_trace(seed, read)
+            q = collections.defaultdict(collections.deque)
+            for kind, val in trace:
+                q[kind].append(val)
+
+            class FL(object):
+                def get_fragment_length(self):
+                    return int(q['LENGTH'].popleft())
+
+            def fake_random():
+                return q['U'].popleft()
+
+            def fake_choices(pop, weights=None):
+                return [pop[int(q['CONTIG'].popleft())]]
+
+            def fake_randint(a, b):
+                if (a, b) == (1, 5):
+                    return int(q['JUNKLEN'].popleft())
+                v = int(q['START'].popleft())
+                assert a <= v <= b
+                return v
+
+            def fake_beta(a, b, _adapters=(params.start_adapter, params.end_adapter)):
+                L = q['ADAPTLEN'].popleft()
+                n_ad = fake_beta.next_len
+                return (L + 0.5) / n_ad
+
+            def fake_geometric(p=None):
+                return int(q['GEO'].popleft())
+
+            def fake_random_sequence(n):
+                if fake_random_sequence.junk_pending:
+                    fake_random_sequence.junk_pending = False
+                    unit = int(q['JUNKUNIT'].popleft())
+                    return ''.join('ACGT'[(unit >> (2 * i)) & 3] for i in range(n))
+                serial = int(q['SERIAL'].popleft())
+                return ''.join('ACGT'[random_base(seed, read, serial, p)] for p in range(n))
+            fake_random_sequence.junk_pending = False
+
+            real_junk = ref_sim.get_junk_fragment
+
+            def junk_wrapper(length):
+                fake_random_sequence.junk_pending = True
+                return real_junk(length)
+
+            real_adapter_len = ref_sim.get_adapter_frag_length
+
+            def adapter_len_wrapper(amount, adapter):
+                fake_beta.next_len = len(adapter)
+                return real_adapter_len(amount, adapter)
+
+            saved = (random.random, ref_sim.random.choices, ref_sim.random.randint, ref_sim.np.random.beta,
+                     ref_sim.np.random.geometric, ref_sim.get_random_sequence, ref_sim.get_junk_fragment,
+                     ref_sim.get_adapter_frag_length)
+            random.random = fake_random
+            ref_sim.random.choices, ref_sim.random.randint = fake_choices, fake_randint
+            ref_sim.np.random.beta, ref_sim.np.random.geometric = fake_beta, fake_geometric
+            ref_sim.get_random_sequence, ref_sim.get_junk_fragment = fake_random_sequence, junk_wrapper
+            ref_sim.get_adapter_frag_length = adapter_len_wrapper
+            failed = False
+            try:
+                fragment, info = ref_sim.build_fragment(FL(), seqs, rev, names, weights, circ, hl, hr, args,
+                                                        params.start_rate, params.start_amount, params.end_rate, params.end_amount)
+            except SystemExit:
+                fragment, info, failed = '', [], True
+            finally:
+                (random.random, ref_sim.random.choices, ref_sim.random.randint, ref_sim.np.random.beta,
+                 ref_sim.np.random.geometric, ref_sim.get_random_sequence, ref_sim.get_junk_fragment,
+                 ref_sim.get_adapter_frag_length) = saved
+            left = {k: len(v) for k, v in q.items() if len(v) and k != 'IDENTITY'}
+            assert failed or not left, (ci, read, left)
+            reads.append({'read': read, 'fragment': fragment, 'info': ' '.join(info), 'failed': failed,
+                          'identity': q['IDENTITY'][0] if q['IDENTITY'] else None})
+        out_cfgs.append({'params': cfg, 'seed': seed, 'reads': reads})
+        n_fail = sum(r['failed'] for r in reads)
+        print(f'  build_fragment config {ci}: {len(reads)} reads, {n_fail} fatal, '
+              f'mean length {np.mean([len(r["fragment"]) for r in reads]):.0f}')
+    dump('build_fragment.json.gz', {'fasta': 'small_ref.fasta', 'configs': out_cfgs})
+
+
+# ---------------------------------------------------------------------------------------------
 class ReplayErrorModel(object):
     """add_errors_to_kmer scripted by the current iteration's Philox words (w2 picks the
     alternative, w3 drives add_one_random_change), decided by the oracle's table walk."""
@@ -340,4 +460,5 @@ if __name__ == '__main__':
     make_misc()
     make_align_kmers()
     make_fragments()
+    make_build_fragment()
     make_sequence_fragment()
