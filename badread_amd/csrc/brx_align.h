@@ -83,7 +83,7 @@ __host__ __device__ inline uint64_t brx_tb_units(const BrxGeom &g) {
 }
 /* lanes holding more than BRX_REGPEQ_MAXG words read their equality masks from a table
    [5][NW] (u32) that the wave builds behind the traceback store */
-#define BRX_REGPEQ_MAXG 4
+#define BRX_REGPEQ_MAXG 0
 __host__ __device__ inline uint64_t brx_peq_units(const BrxGeom &g) {
     return g.G > BRX_REGPEQ_MAXG ? ((uint64_t)5 * (uint64_t)g.NW * 4 + 7) / 8 + (uint64_t)64 * (uint64_t)g.G : 0;
 }
@@ -109,58 +109,108 @@ __device__ inline uint32_t brx_eq_slow(const uint8_t *Qs, int Q, int w, uint32_t
     return m;
 }
 
+/* equality mask of word w for a symbol outside 0..4 (IUPAC codes other than N): rare, kept out of line */
+__device__ __noinline__ uint32_t brx_eq_rare(const uint8_t *Qs, int Q, int w, uint32_t c) {
+    return brx_eq_slow(Qs, Q, w, c);
+}
+
+/* lane i receives the value of lane (i - 1) mod 64: DPP wave_ror:1, two VALU cycles, no LDS traffic */
+__device__ __forceinline__ int brx_from_lane_above(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+}
+
+/* timing experiments only (BRX_VARIANT env, results become invalid): bit0 no traceback stores,
+ * bit1 no query loads at band entry, bit2 no target-window refills */
+__device__ int brx_variant = 0;
+
+#define BRX_RING_BYTES 512          /* per-wave LDS window of target bytes (two 256-byte halves) */
+/* One wave per workgroup, so one window per workgroup.  File scope keeps the LDS address space
+ * visible to the compiler (ds_read_u8 / ds_write_b32); a generic or volatile pointer to it turns
+ * every access into a flat load that waits on vmcnt -- exactly what the window is there to avoid. */
+__shared__ uint32_t brx_ring32[BRX_RING_BYTES / 4];
+
 /* ---------------------------------------------------------------------------------------------
  * forward pass: fills tb[(t*WSp + s%WSp)*G + g] = {Pv after column j, Ph before its shift}
- * Qs and Ts must be readable up to 8 bytes past their ends (buffers are padded by the caller) and
+ * Qs and Ts must be readable up to 16 bytes past their ends (buffers are padded by the caller) and
  * 4-byte aligned.
+ *
+ * Memory discipline of the loop (this is what bounds a step): the only steady-state memory
+ * operations are the traceback STORES.  On gfx9 loads and stores retire through one in-order
+ * counter (vmcnt), so a load inside the loop makes the wave wait for the write acknowledgements
+ * of every store before it; r01a measured ~1700 cycles per step that way.  Target bytes therefore
+ * come from a 512-byte LDS window that the wave refills 256 bytes at a time, split-phase (global
+ * load issued 64 steps before the data is written to LDS), the per-step byte is read from LDS one
+ * step ahead, and the carry between superblocks travels by DPP instead of ds_bpermute.  The
+ * remaining global loads are the 32 query bytes a lane reads when its superblock enters the band
+ * (once per R columns per wave).
  * ------------------------------------------------------------------------------------------- */
 template <int G>
 __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                   const BrxGeom g, uint2 *__restrict__ tb, uint32_t *prog = nullptr) {
-    constexpr bool REGPEQ = true;
-    constexpr int PG = G;
     const int lane = threadIdx.x & 63;
+    const int variant = __builtin_amdgcn_readfirstlane(brx_variant);
     int s = lane;
     bool has = s < g.NS;
     int jf = has ? brx_jfirst(g, s) : 0, jl = has ? brx_jlast(g, s) : -1;
     int slot = has ? s % g.WSp : 0;
     uint32_t Pv[G], Mv[G];
-    uint32_t pe[PG][5];
+    uint32_t pe[G][5];
 #pragma unroll
-    for (int x = 0; x < G; ++x) { Pv[x] = 0xFFFFFFFFu; Mv[x] = 0; }
-#pragma unroll
-    for (int x = 0; x < PG; ++x) {
+    for (int x = 0; x < G; ++x) {
+        Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;
 #pragma unroll
         for (int c = 0; c < 5; ++c) pe[x][c] = 0;
     }
     int hout_last = 0, s_last = -1;
     bool active_last = false;
-    uint32_t cbuf = 0, cnext = 0;
 
-    for (int t = 1; t <= g.t_end; ++t) {
+    /* target window: chunk c = target bytes [256c, 256c+256) lives in ring half c & 1 */
+    auto fetch_chunk = [&](int c) -> uint32_t {
+        const int idx = 256 * c + 4 * lane;
+        return (idx + 4 <= g.T + 16) ? *reinterpret_cast<const uint32_t *>(Ts + idx) : 0xFEFEFEFEu;
+    };
+    brx_ring32[lane] = fetch_chunk(0);
+    brx_ring32[64 + lane] = fetch_chunk(1);
+    uint32_t pending = 0;
+    int s_top = 0;                                   /* first superblock still inside the band (wave-uniform) */
+    int jl_top = brx_jlast(g, 0);
+    uint32_t cnext = 0;
+    cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(0 - s) & (BRX_RING_BYTES - 1)];   /* column j = 1 - s */
+
+    const size_t step_units = (size_t)g.WSp * (size_t)G;
+    uint2 *dst = tb + ((size_t)1 * (size_t)g.WSp + (size_t)slot) * (size_t)G;
+    for (int t = 1; t <= g.t_end; ++t, dst += step_units) {
         BRX_PROG(prog, 4, t);
-        int packed = (s_last << 3) | (active_last ? 4 : 0) | (hout_last + 1);
-        int nb = __shfl(packed, (lane + 63) & 63, 64);
-        int j = t - s;
-        bool active = has && j >= jf && j <= jl;
+        /* ---- refill of the target window, keyed on the newest column in use ---- */
+        while (s_top < g.NS - 1 && t - s_top > jl_top) { s_top += 1; jl_top = brx_jlast(g, s_top); }
+        const int front = t - s_top - 1;             /* 0-based target index of the newest column */
+        if (variant & 4) { }
+        else if ((front & 255) == 128) pending = fetch_chunk((front >> 8) + 1);
+        else if ((front & 255) == 192) brx_ring32[(((front >> 8) + 1) & 1) * 64 + lane] = pending;
+
+        const int packed = (s_last << 3) | (active_last ? 4 : 0) | (hout_last + 1);
+        const int nb = brx_from_lane_above(packed);
+        const int j = t - s;
+        const uint32_t c = cnext;
+        const bool active = has && j >= jf && j <= jl;
         if (active) {
             if (j == jf) {
                 /* superblock enters the band: cells below the band grow by +1 per row */
 #pragma unroll
                 for (int x = 0; x < G; ++x) {
                     Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;
-                    int w = s * G + x;
+                    const int w = s * G + x;
                     uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
-                    if (REGPEQ && w < g.NW) {
+                    if (w < g.NW && !(variant & 2)) {
                         const uint32_t *q4 = reinterpret_cast<const uint32_t *>(Qs + 32 * w);
 #pragma unroll 1
                         for (int d = 0; d < 8; ++d) {
-                            uint32_t v = q4[d];
+                            const uint32_t v = q4[d];
 #pragma unroll
                             for (int b = 0; b < 4; ++b) {
-                                uint32_t code = (v >> (8 * b)) & 0xFFu;
-                                int r = 4 * d + b;
-                                bool ok = (32 * w + r) < g.Q;
+                                const uint32_t code = (v >> (8 * b)) & 0xFFu;
+                                const int r = 4 * d + b;
+                                const bool ok = (32 * w + r) < g.Q;
                                 m0 |= (uint32_t)(ok && code == 0) << r;
                                 m1 |= (uint32_t)(ok && code == 1) << r;
                                 m2 |= (uint32_t)(ok && code == 2) << r;
@@ -169,47 +219,36 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
                             }
                         }
                     }
-                    if (REGPEQ) { pe[x % PG][0] = m0; pe[x % PG][1] = m1; pe[x % PG][2] = m2; pe[x % PG][3] = m3; pe[x % PG][4] = m4; }
+                    pe[x][0] = m0; pe[x][1] = m1; pe[x][2] = m2; pe[x][3] = m3; pe[x][4] = m4;
                 }
-                int a = (j - 1) & ~3;
-                cbuf = *reinterpret_cast<const uint32_t *>(Ts + a);
-                cnext = *reinterpret_cast<const uint32_t *>(Ts + a + 4);
-            } else if (((j - 1) & 3) == 0) {
-                cbuf = cnext;
-                cnext = *reinterpret_cast<const uint32_t *>(Ts + (j - 1) + 4);
             }
-            uint32_t c = (cbuf >> (8 * ((j - 1) & 3))) & 0xFFu;
             int hin = 1;
             if (s > 0 && (nb >> 3) == s - 1 && (nb & 4)) hin = (nb & 3) - 1;
             uint32_t hp = hin > 0 ? 1u : 0u, hm = hin < 0 ? 1u : 0u;
-            uint2 *dst = tb + ((size_t)t * (size_t)g.WSp + (size_t)slot) * (size_t)G;
+            const uint32_t k0 = 0u - (uint32_t)(c == 0), k1 = 0u - (uint32_t)(c == 1), k2 = 0u - (uint32_t)(c == 2),
+                           k3 = 0u - (uint32_t)(c == 3), k4 = 0u - (uint32_t)(c == 4);
 #pragma unroll
             for (int x = 0; x < G; ++x) {
-                int w = s * G + x;
+                const int w = s * G + x;
                 if (w < g.NW) {
-                    uint32_t Eq;
-                    if (c < 5) {
-                        if (REGPEQ) {
-                            Eq = pe[x % PG][0];
-                            Eq = c == 1 ? pe[x % PG][1] : Eq;
-                            Eq = c == 2 ? pe[x % PG][2] : Eq;
-                            Eq = c == 3 ? pe[x % PG][3] : Eq;
-                            Eq = c == 4 ? pe[x % PG][4] : Eq;
-                        } else Eq = 0;
-                    } else Eq = brx_eq_slow(Qs, g.Q, w, c);
+                    /* select by mask arithmetic, NOT by ?: -- hipcc folds a select chain over the
+                       elements of a private array into one dynamically indexed load, which pins the
+                       whole array in scratch memory (a vmcnt-ordered load per column) */
+                    uint32_t Eq = (pe[x][0] & k0) | (pe[x][1] & k1) | (pe[x][2] & k2) | (pe[x][3] & k3) | (pe[x][4] & k4);
+                    if (c > 4) Eq = brx_eq_rare(Qs, g.Q, w, c);
                     uint32_t pv = Pv[x], mv = Mv[x];
-                    uint32_t Xv = Eq | mv;
-                    uint32_t Eq2 = Eq | hm;
-                    uint32_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
-                    uint32_t Ph = mv | ~(Xh | pv);
-                    uint32_t Mh = pv & Xh;
-                    uint32_t op = Ph >> 31, om = Mh >> 31;
-                    uint32_t PhS = (Ph << 1) | hp;
-                    uint32_t MhS = (Mh << 1) | hm;
+                    const uint32_t Xv = Eq | mv;
+                    const uint32_t Eq2 = Eq | hm;
+                    const uint32_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
+                    const uint32_t Ph = mv | ~(Xh | pv);
+                    const uint32_t Mh = pv & Xh;
+                    const uint32_t op = Ph >> 31, om = Mh >> 31;
+                    const uint32_t PhS = (Ph << 1) | hp;
+                    const uint32_t MhS = (Mh << 1) | hm;
                     pv = MhS | ~(Xv | PhS);
                     mv = PhS & Xv;
                     Pv[x] = pv; Mv[x] = mv;
-                    dst[x] = make_uint2(pv, Ph);
+                    if (!(variant & 1)) dst[x] = make_uint2(pv, Ph);
                     hp = op; hm = om;
                 }
             }
@@ -220,8 +259,14 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
         if (has && j >= jl) {
             s += 64;
             has = s < g.NS;
-            if (has) { jf = brx_jfirst(g, s); jl = brx_jlast(g, s); slot = s % g.WSp; }
+            if (has) {
+                jf = brx_jfirst(g, s); jl = brx_jlast(g, s);
+                const int nslot = s % g.WSp;
+                dst += ((ptrdiff_t)nslot - (ptrdiff_t)slot) * (ptrdiff_t)G;
+                slot = nslot;
+            }
         }
+        cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(t - s) & (BRX_RING_BYTES - 1)];   /* column t + 1 - s */
     }
 }
 
@@ -359,9 +404,14 @@ __device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32
     }
 }
 
+/* MAXG: the widest band geometry (32-bit words per lane) compiled with register-resident state.
+ * Register use grows with it (7 VGPRs per word), so kernels that only ever meet narrow bands are
+ * instantiated with a small MAXG and run at a higher occupancy; geometries above MAXG take the
+ * slow memory-resident path below (correct, rare). */
+template <int MAXG>
 __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *Ts, const BrxGeom &g, uint2 *tb,
                                              uint32_t *prog = nullptr) {
-    if (g.G > BRX_REGPEQ_MAXG) {
+    if (g.G > MAXG) {
         uint32_t *peq = reinterpret_cast<uint32_t *>(tb + brx_tb_units(g));
         uint2 *st = tb + brx_tb_units(g) + ((uint64_t)5 * (uint64_t)g.NW * 4 + 7) / 8;
         brx_build_peq(Qs, g, peq);
@@ -370,15 +420,16 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
         brx_align_forward_wide(Qs, Ts, g, tb, peq, st);
         return;
     }
-    switch (g.G) {
-    case 1: brx_align_forward<1>(Qs, Ts, g, tb, prog); break;
-    case 2: brx_align_forward<2>(Qs, Ts, g, tb, prog); break;
-    default: brx_align_forward<4>(Qs, Ts, g, tb, prog); break;
-    }
+    if (g.G == 1) { brx_align_forward<1>(Qs, Ts, g, tb, prog); return; }
+    if constexpr (MAXG >= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 16) { if (g.G == 16) { brx_align_forward<16>(Qs, Ts, g, tb, prog); return; } }
 }
 
 /* Full alignment with a given band bound k.  Returns false if the band was too narrow.
  * Handles empty inputs.  All lanes of the wave must call; results are wave-uniform. */
+template <int MAXG = 16>
 __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *Ts, int T, int k,
                                       uint2 *tb, uint64_t tb_cap_units, uint8_t *ops_end,
                                       int *n_cols, int *n_match, bool *no_space, uint32_t *prog = nullptr,
@@ -398,7 +449,7 @@ __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *T
     BRX_PROG(prog, 3, 1);
     BRX_PROG(prog, 6, (uint32_t)g.t_end);
     const uint64_t c0 = __builtin_amdgcn_s_memtime();
-    brx_align_forward_any(Qs, Ts, g, tb, prog);
+    brx_align_forward_any<MAXG>(Qs, Ts, g, tb, prog);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);      /* stores of this wave visible to its own later loads */
     BRX_PROG(prog, 3, 2);

@@ -36,6 +36,8 @@ struct brx_ctx {
     hipEvent_t ev_b[BRX_STAGE_COUNT], ev_e[BRX_STAGE_COUNT];   /* begin / end of each stage on the launch stream */
     float stage_ms[BRX_STAGE_COUNT];
     uint32_t final_launches;
+    hipStream_t side;            /* second stream: the wide-band k_final runs beside the narrow one */
+    hipEvent_t ev_fork, ev_join;
     uint64_t *d_clk; uint32_t clk_reads;
     char err[512];
 };
@@ -111,6 +113,15 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
         if ((e = hipEventCreate(&c->ev_b[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
         if ((e = hipEventCreate(&c->ev_e[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    }
+    if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    {
+        const char *v = getenv("BRX_VARIANT");
+        int variant = v ? atoi(v) : 0;
+        if ((e = hipMemcpyToSymbol(HIP_SYMBOL(brx_variant), &variant, sizeof(int))) != hipSuccess)
+            return create_fail(c, "hipMemcpyToSymbol(brx_variant)", e);
     }
     c->err[0] = 0;
     *out = c;
@@ -221,12 +232,12 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     RS *rs = (RS *)A.take((size_t)n_reads * sizeof(RS));
     uint64_t *totals = (uint64_t *)A.take(16 * sizeof(uint64_t));
     uint32_t *order = (uint32_t *)A.take((size_t)n_reads * 4);
-    uint32_t *counters = (uint32_t *)A.take(64 * 4);        /* [0] mutate queue, [1] flags, [2..] final queues */
+    uint32_t *counters = (uint32_t *)A.take(128 * 4);       /* [0] mutate queue, [1] flags, [2..] final queues (2 per chunk) */
     uint64_t *units_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *tboff_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *clk = (uint64_t *)A.take((size_t)n_reads * 64);     /* per-read cycle counters, brx_last_read_cycles() */
     if (!A.ok()) return scratch_short(c, A.used + (size_t)n_reads * 200000);
-    HIPCHK(c, hipMemsetAsync(counters, 0, 64 * 4, st));
+    HIPCHK(c, hipMemsetAsync(counters, 0, 128 * 4, st));
     HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, st));
     HIPCHK(c, hipMemsetAsync(clk, 0, (size_t)n_reads * 64, st));
     c->d_clk = clk; c->clk_reads = n_reads;
@@ -267,7 +278,8 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     if (rc) return rc;
     {
         uint32_t flags = 0;
-        HIPCHK(c, hipMemcpy(&flags, counters + 1, 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpyAsync(&flags, counters + 1, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
         if (flags & 1u) {                              /* an in-loop alignment did not fit its window scratch */
             c->win_bytes *= 4;
             return scratch_short(c, c->scratch_bytes + (size_t)n_waves * c->win_bytes);
@@ -281,8 +293,9 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     /* ---- stage: final alignment + qscores, in chunks that fit the remaining arena ---- */
     std::vector<uint32_t> h_order(n_reads);
     std::vector<RS> h_rs(n_reads);
-    HIPCHK(c, hipMemcpy(h_order.data(), order, (size_t)n_reads * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpyAsync(h_order.data(), order, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
     size_t tb_at = (A.used + 255) & ~(size_t)255;
     size_t tb_cap = c->scratch_bytes > tb_at ? c->scratch_bytes - tb_at : 0;
     uint8_t *tb_base = c->scratch + tb_at;
@@ -314,8 +327,15 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         uint32_t b = chunks[ci].first, e = chunks[ci].second;
         if (e == b) continue;
         uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
-        hipLaunchKernelGGL(k_final, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 2 + ci, Fbuf, repl,
-                           seqbuf, opsbuf, tb_base, clk);
+        /* wide reads are few but long: start them first on the side stream, narrow ones fill the rest of the chip */
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        hipLaunchKernelGGL((k_final<16, true>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, c->side,
+                           dev, rs, order, b, e, counters + 2 + 2 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+        hipLaunchKernelGGL((k_final<2, false>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 3 + 2 * ci,
+                           Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
     }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_FINAL], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_EMIT], st));
@@ -344,7 +364,8 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     if (out_bytes) *out_bytes = (size_t)rec_bytes;
     /* a read that exhausted its 1000 tries is fatal in the reference (simulate.py:164) */
     if (!raw) {
-        HIPCHK(c, hipMemcpy(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
         for (uint32_t i = 0; i < n_reads; ++i) if (h_rs[i].status & BRX_RS_NOFRAG) {
             snprintf(c->err, sizeof(c->err), "read %llu failed to generate a sequence fragment", (unsigned long long)(first_read + i));
             return BRX_E_NOFRAG;
@@ -382,9 +403,10 @@ extern "C" int brx_align_batch(brx_ctx *c, uint32_t n_pairs, const uint8_t *d_qu
     DBG("align_batch: %u pairs", n_pairs);
     std::vector<uint64_t> qo(n_pairs + 1), to(n_pairs + 1);
     std::vector<int32_t> kh(n_pairs);
-    HIPCHK(c, hipMemcpy(qo.data(), d_q_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(to.data(), d_t_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(kh.data(), d_k_hint, (size_t)n_pairs * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpyAsync(qo.data(), d_q_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(to.data(), d_t_off, (size_t)(n_pairs + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(kh.data(), d_k_hint, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
     DBG("align_batch: offsets copied");
     Arena A; A.base = c->scratch; A.cap = c->scratch_bytes; A.used = 0;
     uint64_t *scr_off = (uint64_t *)A.take((size_t)n_pairs * 8);
@@ -423,6 +445,7 @@ extern "C" int brx_align_batch(brx_ctx *c, uint32_t n_pairs, const uint8_t *d_qu
     HIPCHK(c, hipMemcpyAsync(scr_off, h_off.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(scr_bytes, h_bytes.data(), (size_t)n_pairs * 8, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(counters, 0, 4096 * 4, st));
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_FINAL], st));
     for (size_t ci = 0; ci < chunks.size(); ++ci) {
         uint32_t b = chunks[ci].first, e = chunks[ci].second;
         if (e == b) continue;
@@ -432,8 +455,12 @@ extern "C" int brx_align_batch(brx_ctx *c, uint32_t n_pairs, const uint8_t *d_qu
                            d_targets, d_t_off, d_k_hint, d_dist, d_ncols, d_nmatch, d_ops, d_ops_off,
                            c->scratch + at, scr_off, scr_bytes, brx_debug() ? c->d_prog : (uint32_t *)nullptr);
     }
+    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_FINAL], st));
     DBG("align_batch: launched, waiting");
     { int rcw = wait_stream(c, st, "k_align_batch"); if (rcw) return rcw; }
+    for (int i = 0; i < BRX_STAGE_COUNT; ++i) c->stage_ms[i] = 0.f;
+    (void)hipEventElapsedTime(&c->stage_ms[BRX_STAGE_FINAL], c->ev_b[BRX_STAGE_FINAL], c->ev_e[BRX_STAGE_FINAL]);
+    c->final_launches = (uint32_t)chunks.size();
     HIPCHK(c, hipGetLastError());
     DBG("align_batch: done");
     return BRX_OK;

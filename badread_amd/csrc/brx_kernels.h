@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
                             __builtin_amdgcn_s_waitcnt(0);
                             uint2 *tb = reinterpret_cast<uint2 *>(win + qpad + tpad);
                             uint64_t cap = (win_bytes - qpad - tpad) / 8;
-                            bool ok = brx_wave_align(qb, (int)ql, tbuf, (int)tl, (int)cost, tb, cap, nullptr, &ncols, &nmatch, &nospace,
+                            bool ok = brx_wave_align<1>(qb, (int)ql, tbuf, (int)tl, (int)cost, tb, cap, nullptr, &ncols, &nmatch, &nospace,
                                                      nullptr, aclk);
                             if (!ok && !nospace) s.status |= BRX_RS_BAND;
                         }
@@ -713,6 +713,10 @@ __device__ inline int64_t qs_lookup(const brx_qscore_model &qm, uint64_t key) {
     }
 }
 
+/* Two instantiations share every queue range: k_final<2, false> takes the reads whose band fits two
+ * words per lane (lean registers, high occupancy), k_final<16, true> the wide ones; each skips the
+ * other's reads.  They run concurrently on two streams. */
+template <int MAXG, bool WIDE>
 __global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                uint32_t *queue, const uint8_t *Fbuf, const uint32_t *repl,
                                                uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
@@ -727,6 +731,10 @@ __global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *
         const uint32_t r = order[qi];
         RS s = rs[r];
         if (s.n == 0) continue;
+        {
+            const int G = s.m ? brx_make_geom((int)s.m, (int)s.n, (int)s.ub).G : 1;
+            if ((G > 2 || G == 0) != WIDE) continue;
+        }
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
         uint64_t aclk[2] = {0, 0};
         const uint64_t read = d.first_read + r;
@@ -745,7 +753,7 @@ __global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         int ncols = 0, nmatch = 0; bool nospace = false;
-        bool ok = brx_wave_align(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch, &nospace,
+        bool ok = brx_wave_align<MAXG>(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch, &nospace,
                                  nullptr, aclk);
         const uint64_t t_aligned = __builtin_amdgcn_s_memtime();
         if (!ok) s.status |= BRX_RS_BAND;
@@ -1009,7 +1017,7 @@ __global__ void __launch_bounds__(64) k_align_batch(uint32_t n_pairs, uint32_t p
         BRX_PROG(prog, 1, 1);
         for (int round = 0; round < 40; ++round) {
             BRX_PROG(prog, 2, round + 1);
-            ok = uni(brx_wave_align(qb, (int)Q, tbuf, (int)T, kk, tb, cap, ops_end, &nc, &nm, &nospace, prog));
+            ok = uni(brx_wave_align<16>(qb, (int)Q, tbuf, (int)T, kk, tb, cap, ops_end, &nc, &nm, &nospace, prog));
             nc = uni(nc); nm = uni(nm); nospace = uni(nospace);
             if (ok || nospace || kh >= 0 || kk >= maxk) break;
             kk = kk * 2 > maxk ? maxk : kk * 2;

@@ -120,7 +120,10 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--reads-per-step', type=int, default=8192, help='read indices per GPU per step')
-    ap.add_argument('--scratch-gb', type=float, default=64.0)
+    ap.add_argument('--scratch-gb', type=float, default=56.0, help='scratch arena per in-flight batch')
+    ap.add_argument('--streams', type=int, default=3,
+                    help='batches in flight per GPU (one context + HIP stream + host thread each): the slowest read '
+                         'of one batch overlaps the bulk of the next')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--d2h', action='store_true', help='also time steps that copy the FASTQ bytes to pinned host memory')
     args = ap.parse_args()
@@ -141,12 +144,19 @@ def main():
 
     from badread_amd.engine import HipEngine
     wl = build_workload(io.StringIO())
-    eng = configure(HipEngine(local, scratch_bytes=int(args.scratch_gb * (1 << 30))), wl)
     R = args.reads_per_step
+    C = max(1, min(args.streams, args.steps))
+    engines = [configure(HipEngine(local, scratch_bytes=int(args.scratch_gb * (1 << 30))), wl) for _ in range(C)]
+    streams = [torch.cuda.Stream(device=local) for _ in range(C)]
+    eng = engines[0]
+    for e, st_ in zip(engines, streams):              # prime every context (lazy module load, buffers) -- not a step
+        with torch.cuda.stream(st_):
+            e.simulate_batch_device(SEED, 2 ** 40, 64, expected_bytes=R * 36000)
+    torch.cuda.synchronize()
 
-    def step(index):
+    def step(index, e=None):
         first = (index * world + rank) * R
-        out, stats = eng.simulate_batch_device(SEED, first, R, expected_bytes=R * 36000)
+        out, stats = (e or eng).simulate_batch_device(SEED, first, R, expected_bytes=R * 36000)
         return out, stats
 
     def sync():
@@ -155,21 +165,46 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        step(w)
-    bases = 0
-    stage_sum = {}
-    final_launches = 0
+    def run_steps(indices):
+        """Steps `indices`, C at a time: worker i owns context i / stream i and takes every C-th step."""
+        acc = [{'bases': 0, 'stages': {}, 'final_launches': 0, 'error': None} for _ in range(C)]
+
+        def worker(i):
+            try:
+                torch.cuda.set_device(local)
+                with torch.cuda.stream(streams[i]):
+                    for idx in indices[i::C]:
+                        _, stats = step(idx, engines[i])
+                        acc[i]['bases'] += int(stats['seq_len'].sum())
+                        for name, ms in engines[i].stage_ms().items():
+                            acc[i]['stages'][name] = acc[i]['stages'].get(name, 0.0) + ms
+                        acc[i]['final_launches'] += engines[i].final_launches()
+                    streams[i].synchronize()
+            except BaseException as ex:          # surfaced on the main thread
+                acc[i]['error'] = ex
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(C)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        for a in acc:
+            if a['error'] is not None:
+                raise a['error']
+        return acc
+
+    run_steps(list(range(args.warmup)) if args.warmup else [])
     sync()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        _, stats = step(args.warmup + k)
-        bases += int(stats['seq_len'].sum())
-        for name, ms in eng.stage_ms().items():
-            stage_sum[name] = stage_sum.get(name, 0.0) + ms
-        final_launches += eng.final_launches()
+    acc = run_steps([args.warmup + k for k in range(args.steps)])
     sync()
     elapsed = time.perf_counter() - t0
+    bases = sum(a['bases'] for a in acc)
+    final_launches = sum(a['final_launches'] for a in acc)
+    stage_sum = {}
+    for a in acc:
+        for name, ms in a['stages'].items():
+            stage_sum[name] = stage_sum.get(name, 0.0) + ms
 
     t = torch.tensor([elapsed, float(bases)], dtype=torch.float64, device='cuda')
     if dist is not None:
@@ -219,12 +254,14 @@ def main():
         'config': {'workload': 'configs[1]: 5.5 Mb K. pneumoniae-like synthetic reference (3 circular contigs), '
                                'nanopore2023 error+qscore models, default badread simulate parameters, seed 42',
                    'reads_per_step_per_gpu': R, 'bases_per_step_per_gpu': bases_per_step_rank0,
+                   'batches_in_flight_per_gpu': C,
                    'parallelism': f'reads sharded by index over {world} GPU(s), reference replicated, no collectives'},
         'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                      'algorithmic_bytes_per_launch': ALGO_BYTES_PER_BASE * bases_per_step_rank0 / launches,
                      'launch_ms': launch_ms, 'launches_per_step': launches,
-                     'note': 'integer-ALU / latency bound path: see DESIGN.md section 5'},
+                     'note': 'integer-ALU / latency bound path: see DESIGN.md section 5; launch_ms is the HIP-event '
+                             'duration of one launch while other batches share the GPU'},
         'stage_ms_per_step': stages,
     }
     if d2h is not None:
