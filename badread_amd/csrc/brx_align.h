@@ -149,10 +149,11 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
                                   const BrxGeom g, uint2 *__restrict__ tb, uint32_t *prog = nullptr) {
     const int lane = threadIdx.x & 63;
     const int variant = __builtin_amdgcn_readfirstlane(brx_variant);
+    constexpr int NEVER = 0x7FFFFFFF;
+    /* a lane works on superblock s during time steps [tf, tl] (column j = t - s), then hops to s + 64 */
     int s = lane;
-    bool has = s < g.NS;
-    int jf = has ? brx_jfirst(g, s) : 0, jl = has ? brx_jlast(g, s) : -1;
-    int slot = has ? s % g.WSp : 0;
+    int tf = NEVER, tl = -1, slot = 0;
+    if (s < g.NS) { tf = brx_jfirst(g, s) + s; tl = brx_jlast(g, s) + s; slot = s % g.WSp; }
     uint32_t Pv[G], Mv[G];
     uint32_t pe[G][5];
 #pragma unroll
@@ -161,8 +162,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
 #pragma unroll
         for (int c = 0; c < 5; ++c) pe[x][c] = 0;
     }
-    int hout_last = 0, s_last = -1;
-    bool active_last = false;
+    int packed = -8;                                 /* (superblock << 3) | active << 2 | (hout + 1) of the previous step */
 
     /* target window: chunk c = target bytes [256c, 256c+256) lives in ring half c & 1 */
     auto fetch_chunk = [&](int c) -> uint32_t {
@@ -174,31 +174,29 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
     uint32_t pending = 0;
     int s_top = 0;                                   /* first superblock still inside the band (wave-uniform) */
     int jl_top = brx_jlast(g, 0);
-    uint32_t cnext = 0;
-    cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(0 - s) & (BRX_RING_BYTES - 1)];   /* column j = 1 - s */
+    uint32_t cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(0 - s) & (BRX_RING_BYTES - 1)];   /* column 1 - s */
 
     const size_t step_units = (size_t)g.WSp * (size_t)G;
     uint2 *dst = tb + ((size_t)1 * (size_t)g.WSp + (size_t)slot) * (size_t)G;
     for (int t = 1; t <= g.t_end; ++t, dst += step_units) {
         BRX_PROG(prog, 4, t);
-        /* ---- refill of the target window, keyed on the newest column in use ---- */
-        while (s_top < g.NS - 1 && t - s_top > jl_top) { s_top += 1; jl_top = brx_jlast(g, s_top); }
+        /* ---- refill of the target window, keyed on the newest column in use (scalar code) ---- */
+        while (__builtin_expect(s_top < g.NS - 1 && t - s_top > jl_top, 0)) { s_top += 1; jl_top = brx_jlast(g, s_top); }
         const int front = t - s_top - 1;             /* 0-based target index of the newest column */
-        if (variant & 4) { }
+        if (__builtin_expect((front & 63) != 0 || (variant & 4), 1)) { }
         else if ((front & 255) == 128) pending = fetch_chunk((front >> 8) + 1);
         else if ((front & 255) == 192) brx_ring32[(((front >> 8) + 1) & 1) * 64 + lane] = pending;
 
-        const int packed = (s_last << 3) | (active_last ? 4 : 0) | (hout_last + 1);
         const int nb = brx_from_lane_above(packed);
-        const int j = t - s;
         const uint32_t c = cnext;
-        const bool active = has && j >= jf && j <= jl;
-        if (active) {
-            if (j == jf) {
-                /* superblock enters the band: cells below the band grow by +1 per row */
+        const bool active = t >= tf && t <= tl;
+
+        /* ---- a superblock enters the band (one lane every R steps): build its equality masks ---- */
+        if (__builtin_expect(__ballot(t == tf) != 0ull, 0)) {
+            if (t == tf) {
 #pragma unroll
                 for (int x = 0; x < G; ++x) {
-                    Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;
+                    Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;          /* cells below the band grow by +1 per row */
                     const int w = s * G + x;
                     uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
                     if (w < g.NW && !(variant & 2)) {
@@ -222,48 +220,52 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
                     pe[x][0] = m0; pe[x][1] = m1; pe[x][2] = m2; pe[x][3] = m3; pe[x][4] = m4;
                 }
             }
-            int hin = 1;
-            if (s > 0 && (nb >> 3) == s - 1 && (nb & 4)) hin = (nb & 3) - 1;
-            uint32_t hp = hin > 0 ? 1u : 0u, hm = hin < 0 ? 1u : 0u;
-            const uint32_t k0 = 0u - (uint32_t)(c == 0), k1 = 0u - (uint32_t)(c == 1), k2 = 0u - (uint32_t)(c == 2),
-                           k3 = 0u - (uint32_t)(c == 3), k4 = 0u - (uint32_t)(c == 4);
-#pragma unroll
-            for (int x = 0; x < G; ++x) {
-                const int w = s * G + x;
-                if (w < g.NW) {
-                    /* select by mask arithmetic, NOT by ?: -- hipcc folds a select chain over the
-                       elements of a private array into one dynamically indexed load, which pins the
-                       whole array in scratch memory (a vmcnt-ordered load per column) */
-                    uint32_t Eq = (pe[x][0] & k0) | (pe[x][1] & k1) | (pe[x][2] & k2) | (pe[x][3] & k3) | (pe[x][4] & k4);
-                    if (c > 4) Eq = brx_eq_rare(Qs, g.Q, w, c);
-                    uint32_t pv = Pv[x], mv = Mv[x];
-                    const uint32_t Xv = Eq | mv;
-                    const uint32_t Eq2 = Eq | hm;
-                    const uint32_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
-                    const uint32_t Ph = mv | ~(Xh | pv);
-                    const uint32_t Mh = pv & Xh;
-                    const uint32_t op = Ph >> 31, om = Mh >> 31;
-                    const uint32_t PhS = (Ph << 1) | hp;
-                    const uint32_t MhS = (Mh << 1) | hm;
-                    pv = MhS | ~(Xv | PhS);
-                    mv = PhS & Xv;
-                    Pv[x] = pv; Mv[x] = mv;
-                    if (!(variant & 1)) dst[x] = make_uint2(pv, Ph);
-                    hp = op; hm = om;
-                }
-            }
-            hout_last = (int)hp - (int)hm;
         }
-        active_last = active;
-        s_last = s;
-        if (has && j >= jl) {
-            s += 64;
-            has = s < g.NS;
-            if (has) {
-                jf = brx_jfirst(g, s); jl = brx_jlast(g, s);
-                const int nslot = s % g.WSp;
-                dst += ((ptrdiff_t)nslot - (ptrdiff_t)slot) * (ptrdiff_t)G;
-                slot = nslot;
+
+        /* ---- the column update, executed by every lane; lanes outside the band discard the result ---- */
+        const bool fed = s > 0 && (nb >> 3) == s - 1 && (nb & 4);      /* the superblock above handed a carry over */
+        uint32_t hp = fed ? (uint32_t)((nb & 3) == 2) : 1u;
+        uint32_t hm = fed ? (uint32_t)((nb & 3) == 0) : 0u;
+        const uint32_t k0 = 0u - (uint32_t)(c == 0), k1 = 0u - (uint32_t)(c == 1), k2 = 0u - (uint32_t)(c == 2),
+                       k3 = 0u - (uint32_t)(c == 3), k4 = 0u - (uint32_t)(c == 4);
+        const bool rare = __builtin_expect(__ballot(active && c > 4) != 0ull, 0);   /* IUPAC symbol other than N in the target */
+#pragma unroll
+        for (int x = 0; x < G; ++x) {
+            /* select by mask arithmetic, NOT by ?: -- hipcc folds a select chain over the elements of a
+               private array into one dynamically indexed load, which pins the whole array in scratch
+               memory (a vmcnt-ordered load per column) */
+            uint32_t Eq = (pe[x][0] & k0) | (pe[x][1] & k1) | (pe[x][2] & k2) | (pe[x][3] & k3) | (pe[x][4] & k4);
+            if (rare) { if (active && c > 4 && s * G + x < g.NW) Eq = brx_eq_rare(Qs, g.Q, s * G + x, c); }
+            uint32_t pv = Pv[x], mv = Mv[x];
+            const uint32_t Xv = Eq | mv;
+            const uint32_t Eq2 = Eq | hm;
+            const uint32_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
+            const uint32_t Ph = mv | ~(Xh | pv);
+            const uint32_t Mh = pv & Xh;
+            const uint32_t op = Ph >> 31, om = Mh >> 31;
+            const uint32_t PhS = (Ph << 1) | hp;
+            const uint32_t MhS = (Mh << 1) | hm;
+            pv = MhS | ~(Xv | PhS);
+            mv = PhS & Xv;
+            const bool live = active && (G == 1 || s * G + x < g.NW);   /* words past the last query row do not exist */
+            if (live) {
+                Pv[x] = pv; Mv[x] = mv;
+                if (!(variant & 1)) dst[x] = make_uint2(pv, Ph);
+                hp = op; hm = om;
+            }
+        }
+        packed = (s << 3) | (active ? (4 | (int)(hp + 1u - hm)) : 0);
+
+        /* ---- a superblock leaves the band: its lane takes superblock s + 64 ---- */
+        if (__builtin_expect(__ballot(t >= tl && tf != NEVER) != 0ull, 0)) {
+            if (t >= tl && tf != NEVER) {
+                s += 64;
+                if (s < g.NS) {
+                    tf = brx_jfirst(g, s) + s; tl = brx_jlast(g, s) + s;
+                    const int nslot = s % g.WSp;
+                    dst += ((ptrdiff_t)nslot - (ptrdiff_t)slot) * (ptrdiff_t)G;
+                    slot = nslot;
+                } else { tf = NEVER; tl = -1; }
             }
         }
         cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(t - s) & (BRX_RING_BYTES - 1)];   /* column t + 1 - s */
