@@ -35,7 +35,7 @@ struct brx_ctx {
     uint32_t *h_prog, *d_prog;   /* host / device views of the progress words */
     hipEvent_t ev_b[BRX_STAGE_COUNT], ev_e[BRX_STAGE_COUNT];   /* begin / end of each stage on the launch stream */
     float stage_ms[BRX_STAGE_COUNT];
-    uint32_t final_launches;
+    uint32_t final_launches, mutate_passes;
     hipStream_t side;            /* second stream: the wide-band k_final runs beside the narrow one */
     hipEvent_t ev_fork, ev_join;
     uint64_t *d_clk; uint32_t clk_reads;
@@ -254,7 +254,18 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     PPiece *pieces = (PPiece *)A.take((size_t)(tot_pieces + 1) * sizeof(PPiece));
     uint8_t *Fbuf = (uint8_t *)A.take((size_t)f_bytes + 64);
     uint32_t *repl = (uint32_t *)A.take(((size_t)f_bytes + 64) * 4);
-    uint8_t *win = (uint8_t *)A.take((size_t)n_waves * c->win_bytes);
+    const uint32_t side_waves = std::min<uint32_t>(n_reads, 256u);                  /* wave-level window aligner / legacy */
+    const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, 512u);      /* lane-level window aligner          */
+    uint8_t *win = (uint8_t *)A.take((size_t)side_waves * c->win_bytes);
+    MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
+    uint32_t *mctr = (uint32_t *)A.take(4 * MC_WORDS * sizeof(uint32_t));
+    uint32_t *active_a = (uint32_t *)A.take((size_t)n_reads * 4);
+    uint32_t *active_b = (uint32_t *)A.take((size_t)n_reads * 4);
+    uint32_t *req_easy = (uint32_t *)A.take((size_t)n_reads * 4);
+    uint32_t *req_hard = (uint32_t *)A.take((size_t)n_reads * 4);
+    uint32_t *req_legacy = (uint32_t *)A.take((size_t)n_reads * 4);
+    uint8_t *winbuf = (uint8_t *)A.take((size_t)n_reads * BRX_WIN_STRIDE + 64);
+    uint2 *lane_tb = (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
     if (!raw) hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces);
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_PLAN], st));
@@ -267,9 +278,45 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_BUILD], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_MUTATE], st));
 
-    /* ---- stage: mutate ---- */
-    hipLaunchKernelGGL(k_mutate, dim3(n_waves), dim3(64), 0, st, dev, rs, order, counters + 0, Fbuf, repl, win,
-                       (uint64_t)c->win_bytes, counters + 1, clk);
+    /* ---- stage: mutate (multi-pass: segments of the loop, parked window alignments; brx_mutate.h) ---- */
+    {
+        const uint32_t seg_waves = std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 8u);
+        HIPCHK(c, hipMemsetAsync(msv, 0, (size_t)n_reads * sizeof(MS), st));
+        HIPCHK(c, hipMemsetAsync(mctr, 0, 4 * MC_WORDS * sizeof(uint32_t), st));
+        uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
+        memset(h_ctr, 0, MC_WORDS * sizeof(uint32_t));
+        h_ctr[MC_OUT] = n_reads;
+        HIPCHK(c, hipMemcpyAsync(mctr + 2 * MC_WORDS, h_ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;                                 /* [0] count, [1] queue; not reset per pass */
+        const uint32_t *n_in = mctr + 2 * MC_WORDS + MC_OUT;
+        const uint32_t *act_in = order;
+        uint32_t n_up = n_reads, pass = 0;
+        for (; n_up > 0 && pass < (1u << 20); ++pass) {
+            uint32_t *ctr = mctr + (pass & 1u) * MC_WORDS;
+            uint32_t *act_out = (pass & 1u) ? active_b : active_a;
+            HIPCHK(c, hipMemsetAsync(ctr, 0, MC_WORDS * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_mutate_seg, dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out, ctr,
+                               req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk);
+            hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64)), dim3(64), 0, st, msv, req_easy,
+                               ctr + MC_EASY, winbuf, lane_tb);
+            hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
+                               ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1);
+            HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            { int rcw = wait_stream(c, st, "mutate pass"); if (rcw) return rcw; }
+            n_up = h_ctr[MC_OUT];
+            n_in = ctr + MC_OUT;
+            act_in = act_out;
+        }
+        c->mutate_passes = pass;
+        if (n_up > 0) return fail(c, BRX_E_INTERNAL, "mutate pipeline did not converge after %u passes", pass);
+        /* reads whose window did not fit a slot: the whole-read kernel with the inline wave aligner */
+        HIPCHK(c, hipMemcpyAsync(h_ctr, legacy_ctr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (h_ctr[0] > 0)
+            hipLaunchKernelGGL(k_mutate, dim3(std::min(side_waves, h_ctr[0])), dim3(64), 0, st, dev, rs, req_legacy, legacy_ctr,
+                               legacy_ctr + 1, Fbuf, repl, win, (uint64_t)c->win_bytes, counters + 1, clk);
+    }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_MUTATE], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_SCAN], st));
     hipLaunchKernelGGL(k_scan_mut, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
@@ -282,7 +329,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         HIPCHK(c, hipStreamSynchronize(st));
         if (flags & 1u) {                              /* an in-loop alignment did not fit its window scratch */
             c->win_bytes *= 4;
-            return scratch_short(c, c->scratch_bytes + (size_t)n_waves * c->win_bytes);
+            return scratch_short(c, c->scratch_bytes + (size_t)side_waves * c->win_bytes);
         }
     }
     const uint64_t seq_bytes = c->h_totals[3], ops_bytes = c->h_totals[4];

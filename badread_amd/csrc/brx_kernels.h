@@ -533,19 +533,24 @@ __device__ inline uint32_t wave_join(const brx_error_model &em, const uint8_t *F
  * ========================================================================================== */
 struct MutScratch { uint8_t *base; uint64_t bytes; };
 
-__global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t *order, uint32_t *queue,
+__global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t *list, const uint32_t *n_list_ptr, uint32_t *queue,
                                                 uint8_t *Fbuf, uint32_t *repl, uint8_t *win_base, uint64_t win_bytes,
                                                 uint32_t *flags, uint64_t *clk) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
     uint8_t *win = win_base + (uint64_t)blockIdx.x * win_bytes;
+    const uint32_t n_list = uni(*n_list_ptr);
     for (;;) {
         const uint32_t qi = wave_pop(queue);
-        if (qi >= d.n_reads) break;
-        const uint32_t r = order[qi];
+        if (qi >= n_list) break;
+        const uint32_t r = list[qi];
         RS s = rs[r];
         if (s.n == 0) continue;
+        /* whole-read fallback of the multi-pass pipeline (brx_mutate.h): start the read over */
+        for (uint32_t x = lane; x < s.n; x += 64) repl[s.F_off + x] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
         uint64_t aclk[2] = {0, 0};
         const uint64_t read = d.first_read + r;
@@ -671,6 +676,8 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
         }
     }
 }
+
+#include "brx_mutate.h"
 
 /* offsets for the final stage.  totals: [3]=seq bytes [4]=ops bytes */
 __global__ void __launch_bounds__(64) k_scan_mut(uint32_t n_reads, RS *rs, uint64_t *totals) {

@@ -1,0 +1,424 @@
+/*
+ * brx_mutate.h -- the mutate loop of sequence_fragment (/root/reference/badread/simulate.py:272-346)
+ * as a multi-pass pipeline, included by brx_kernels.h.
+ *
+ * The reference re-estimates the identity every 25 applied changes by aligning a 1000-base window
+ * of the fragment against its mutated version (simulate.py:325-346).  Doing that alignment with a
+ * whole wavefront (k_mutate, kept as the fallback) occupies a wave for ~1000 dependent column steps
+ * with 3-4 of its 64 lanes busy -- r01 profiles: 80 % of the mutate stage.  Here the loop is cut at
+ * every alignment:
+ *
+ *   k_mutate_seg   1 wave = 1 read.  Runs the loop until the read finishes or reaches an alignment;
+ *                  there it writes the window pair to the read's slot, saves the loop state (MS) and
+ *                  parks the read.  On the next pass it resumes in the middle of the same k-mer.
+ *   k_win_lane     1 LANE = 1 parked window (64 windows per wave): banded block Myers over the
+ *                  window with the query as 2-bit planes, the target planes and the band state in
+ *                  LDS, traceback words to global memory in a lane-interleaved layout, then a
+ *                  per-lane canonical traceback that prefetches 8 columns per memory round trip.
+ *   k_win_wave     1 wave = 1 parked window, for windows the lane kernel does not take (non-ACGT
+ *                  symbols, very wide bands, very long targets): the wave-systolic aligner.
+ *
+ * The host repeats {k_mutate_seg, k_win_lane, k_win_wave} until no read is left.  Results are
+ * identical to the sequential loop: proposals are pure functions of (seed, read, iteration), the
+ * alignment result is applied exactly where the inline alignment was, and both aligners produce
+ * the canonical path (distance, columns and matches are all that is used here).
+ */
+#ifndef BRX_MUTATE_H
+#define BRX_MUTATE_H
+
+#define BRX_WIN_Q 1024                                   /* slot bytes reserved for the window of F           */
+#define BRX_WIN_STRIDE 5120                              /* slot bytes per read: [0,1024) query, then target  */
+#define BRX_WIN_TMAX (BRX_WIN_STRIDE - BRX_WIN_Q - 16)   /* longer joined windows go to the legacy kernel     */
+#define BRX_LANE_TMAX 1536                               /* lane kernel: target columns held in LDS planes    */
+#define BRX_LANE_W 8                                     /* lane kernel: band blocks alive in one column      */
+#define BRX_LANE_TB_UNITS ((uint64_t)(BRX_LANE_TMAX + 1) * BRX_LANE_W * 64)   /* uint2 units per wave       */
+
+struct MS {                       /* loop state of a parked read */
+    double errors, est;
+    uint64_t round_loops;         /* loop_count at the start of the 64-proposal round being applied */
+    uint32_t change, nalign;
+    uint32_t phase;               /* 0 not started, 1 waiting for an alignment, 2 done, 3 needs k_mutate */
+    uint32_t surv_lane, j_next;   /* proposal (lane of the round) and k-mer position to resume at     */
+    uint32_t win_a, win_b, tl, cost;
+    uint32_t res_ncols, res_nmatch;
+    uint32_t status, passes;
+};
+
+enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WORDS = 8 };
+
+/* -------------------------------------------------------------------------------------------------
+ * k_mutate_seg
+ * ----------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
+                                                    const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,
+                                                    uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
+                                                    const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk) {
+    const int lane = lane_id();
+    const brx_error_model &em = d.em;
+    const int k = em.k;
+    const uint32_t n_in = uni(*n_in_ptr);
+    for (;;) {
+        const uint32_t qi = wave_pop(&ctr[MC_QUEUE]);
+        if (qi >= n_in) break;
+        const uint32_t r = active_in[qi];
+        const RS s = rs[r];
+        if (s.n == 0) continue;
+        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        const MS ms = msv[r];
+        const uint64_t read = d.first_read + r;
+        const uint32_t n = s.n;
+        const uint8_t *F = Fbuf + s.F_off;
+        uint32_t *rp = repl + s.F_off;
+        const double target = s.target;
+        const double dn = (double)n;
+        const uint64_t max_i = (uint64_t)n - 1 - (uint64_t)k;
+        const double need = dn * (1.0 - target);
+        const uint64_t loop_cap = 100ull * (uint64_t)n;
+
+        double errors = 0.0;
+        uint64_t loops = 0;
+        uint32_t change = 0, nalign = 0;
+        bool resume = ms.phase == 1u;
+        if (resume) {
+            errors = ms.errors; loops = ms.round_loops; change = ms.change; nalign = ms.nalign;
+            const double id = ms.res_ncols ? (double)ms.res_nmatch / (double)ms.res_ncols : 0.0;     /* misc.py:228-240 */
+            if (n <= BRX_ALIGN_SIZE) errors = (1.0 - id) * dn;                                       /* simulate.py:333 */
+            else {
+                const double est_err = (1.0 - id) * dn;
+                const double weight = (double)BRX_ALIGN_SIZE / dn;
+                errors = est_err * weight + errors * (1.0 - weight);                                 /* simulate.py:344-346 */
+            }
+        }
+        bool done = !resume && need < 0.5;
+        bool parked = false;
+        while (!done) {
+            double est;
+            if (resume) est = ms.est;
+            else {
+                if (loops + 1 > loop_cap) { loops += 1; break; }
+                est = 1.0 - errors / dn;
+                if ((double)change > 0.9 * dn || est <= target) { loops += 1; break; }
+            }
+            const uint64_t room = loop_cap - loops;
+            const uint32_t B = room < 64 ? (uint32_t)room : 64u;
+            /* ---- propose (identical draws on a resumed round) ---- */
+            uint32_t rep[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rep[j] = 0;
+            bool live = false;
+            uint64_t ipos = 0;
+            if ((uint32_t)lane < B) {
+                uint32_t w[4];
+                brx_draw4(d.seed, read, BRX_ST_MUT, loops + (uint64_t)lane, w);
+                ipos = brx_mulhi64(((uint64_t)w[1] << 32) | w[0], max_i + 1);
+                uint8_t kmer[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) kmer[j] = j < k ? F[ipos + j] : 0;
+                live = dev_choose_alt(em, kmer, w[2], w[3], rep);
+            }
+            unsigned long long surv = __ballot(live);
+            int j0 = 0;
+            if (resume) { surv &= ~((1ull << ms.surv_lane) - 1ull); j0 = (int)ms.j_next; }
+            bool first = resume;
+            resume = false;
+            /* ---- apply survivors in iteration order ---- */
+            while (surv) {
+                const int l = __ffsll((long long)surv) - 1;
+                surv &= surv - 1;
+                const uint64_t i0 = wave_bcast_u64(ipos, l);
+                const double scale = est * brx_sqrt(est);
+                for (int j = first ? j0 : 0; j < k; ++j) {
+                    uint32_t mine = 0;
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) mine = (jj == j) ? rep[jj] : mine;
+                    const uint32_t w = wave_bcast_u32(mine, l);
+                    if (!w) continue;
+                    const uint64_t pos = i0 + (uint64_t)j;
+                    const uint32_t cur = rp[pos];
+                    if (cur) continue;
+                    if (lane == 0) rp[pos] = w;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    change += 1;
+                    const uint32_t len = (w >> 24) & 0x7Fu;
+                    errors += (double)(len < 2 ? 1u : len - 1u) * scale;
+                    if (change % BRX_ALIGN_INTERVAL == 0) {
+                        /* ---- park the read: the window pair goes to its slot, the loop state to MS ---- */
+                        uint32_t a = 0, b = n;
+                        if (n > BRX_ALIGN_SIZE) {
+                            uint32_t ww[4];
+                            brx_draw4(d.seed, read, BRX_ST_WIN, (uint64_t)nalign, ww);
+                            a = (uint32_t)brx_mulhi64(((uint64_t)ww[1] << 32) | ww[0], (uint64_t)n - BRX_ALIGN_SIZE + 1);
+                            b = a + BRX_ALIGN_SIZE;
+                        }
+                        nalign += 1;
+                        __builtin_amdgcn_s_waitcnt(0);
+                        uint32_t cost = 0;
+                        const uint32_t tl = wave_join(em, F, rp, a, b, nullptr, &cost);
+                        const uint32_t ql = b - a;
+                        uint32_t klass = MC_LEGACY;
+                        if (tl <= BRX_WIN_TMAX) {
+                            uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+                            bool odd = false;                       /* a symbol outside ACGT anywhere in the pair */
+                            for (uint32_t x = lane; x < ql + 16; x += 64) {
+                                const uint8_t c = x < ql ? F[a + x] : 0xFF;
+                                qb[x] = c;
+                                odd |= x < ql && c > 3;
+                            }
+                            for (uint32_t x = lane; x < 16; x += 64) tbuf[tl + x] = 0xFE;
+                            wave_join(em, F, rp, a, b, tbuf, nullptr);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __builtin_amdgcn_s_waitcnt(0);
+                            for (uint32_t x = lane; x < tl; x += 64) odd |= tbuf[x] > 3;
+                            const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
+                            const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
+                            const bool easy = __ballot(odd) == 0ull && g.G == 1 && band_blocks <= BRX_LANE_W &&
+                                              tl <= BRX_LANE_TMAX && ql > 0 && tl > 0;
+                            klass = easy ? MC_EASY : MC_HARD;
+                        }
+                        if (lane == 0) {
+                            MS o = ms;
+                            o.errors = errors; o.est = est; o.round_loops = loops; o.change = change; o.nalign = nalign;
+                            o.phase = klass == MC_LEGACY ? 3u : 1u;
+                            o.surv_lane = (uint32_t)l; o.j_next = (uint32_t)(j + 1);
+                            o.win_a = a; o.win_b = b; o.tl = tl; o.cost = cost; o.res_ncols = 0; o.res_nmatch = 0;
+                            o.passes = ms.passes + 1;
+                            msv[r] = o;
+                            uint32_t *list = klass == MC_EASY ? req_easy : klass == MC_HARD ? req_hard : req_legacy;
+                            list[atomicAdd(klass == MC_LEGACY ? legacy_ctr : &ctr[klass], 1u)] = r;
+                            if (klass != MC_LEGACY) active_out[atomicAdd(&ctr[MC_OUT], 1u)] = r;
+                        }
+                        parked = true;
+                        break;
+                    }
+                }
+                if (parked) break;
+                first = false;
+                /* top-of-loop tests of the iteration that follows this survivor */
+                const double est2 = 1.0 - errors / dn;
+                if ((double)change > 0.9 * dn || est2 <= target) { loops += (uint64_t)l + 2; done = true; break; }
+                est = est2;
+            }
+            if (parked || done) break;
+            loops += B;
+            if (B < 64) { loops += 1; break; }
+        }
+        uint64_t *ck = clk + (uint64_t)r * 8;
+        if (parked) {
+            if (lane == 0) ck[0] += __builtin_amdgcn_s_memtime() - t_begin;
+            continue;
+        }
+        /* epilogue: lengths of the mutated read, trims (simulate.py:348-349), proven distance bound */
+        __builtin_amdgcn_s_waitcnt(0);
+        uint32_t cost = 0;
+        const uint32_t m = wave_join(em, F, rp, 0, n, nullptr, &cost);
+        uint32_t st = 0, et = 0;
+        if (lane < k) { st = rep_len(rp[lane]); et = rep_len(rp[n - k + lane]); }
+        st = wave_sum(st); et = wave_sum(et);
+        if (lane == 0) {
+            RS *o = &rs[r];
+            o->status = s.status | ms.status; o->m = m; o->ub = cost; o->start_trim = st; o->end_trim = et;
+            o->loops = (uint32_t)loops; o->changes = change; o->naligns = nalign;
+            const BrxGeom g = brx_make_geom((int)m, (int)n, (int)cost);
+            uint64_t units = (m == 0) ? 0 : brx_align_units(g);
+            if (m && g.G == 0) { o->status |= BRX_RS_BAND; units = 0; }
+            o->units = units + ((uint64_t)m * 4 + 7) / 8 + 2;     /* + col_of[] for the qscore stage */
+            msv[r].phase = 2u;
+            ck[0] += __builtin_amdgcn_s_memtime() - t_begin; ck[1] = ms.passes;
+        }
+    }
+}
+
+/* -------------------------------------------------------------------------------------------------
+ * k_win_wave: one parked window per wave (the windows k_win_lane does not take)
+ * ----------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(64) k_win_wave(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr, uint32_t *queue,
+                                                  const uint8_t *winbuf, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags) {
+    const int lane = lane_id();
+    const uint32_t n_req = uni(*n_req_ptr);
+    uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)blockIdx.x * scr_bytes);
+    for (;;) {
+        const uint32_t qi = wave_pop(queue);
+        if (qi >= n_req) break;
+        const uint32_t r = req[qi];
+        const MS ms = msv[r];
+        const uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+        int ncols = 0, nmatch = 0; bool nospace = false;
+        const bool ok = brx_wave_align<1>(qb, (int)(ms.win_b - ms.win_a), tbuf, (int)ms.tl, (int)ms.cost, tb, scr_bytes / 8,
+                                          nullptr, &ncols, &nmatch, &nospace);
+        if (lane == 0) {
+            msv[r].res_ncols = (uint32_t)ncols; msv[r].res_nmatch = (uint32_t)nmatch;
+            if (!ok && !nospace) msv[r].status = ms.status | BRX_RS_BAND;
+            if (nospace) atomicOr(&flags[0], 1u);
+        }
+    }
+}
+
+/* -------------------------------------------------------------------------------------------------
+ * k_win_lane: one parked window per LANE
+ * ----------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, dd, 64); v = o > v ? o : v; }
+    return v;
+}
+
+__global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr,
+                                                  const uint8_t *winbuf, uint2 *tbw_base) {
+    __shared__ uint32_t q_lo[32][64], q_hi[32][64];                       /* query planes, block x lane  */
+    __shared__ uint32_t t_lo[BRX_LANE_TMAX / 32][64], t_hi[BRX_LANE_TMAX / 32][64];
+    __shared__ uint32_t st_pv[BRX_LANE_W][64], st_mv[BRX_LANE_W][64];     /* band state, slot x lane     */
+    const int lane = lane_id();
+    const uint32_t n_req = uni(*n_req_ptr);
+    uint2 *tbw = tbw_base + (uint64_t)blockIdx.x * BRX_LANE_TB_UNITS;
+    for (uint32_t base = blockIdx.x * 64u; base < n_req; base += gridDim.x * 64u) {
+        const uint32_t idx = base + (uint32_t)lane;
+        const bool valid = idx < n_req;
+        const uint32_t r = valid ? req[idx] : 0u;
+        MS ms;
+        if (valid) ms = msv[r];
+        const int Q = valid ? (int)(ms.win_b - ms.win_a) : 0, T = valid ? (int)ms.tl : 0, kb = valid ? (int)ms.cost : 0;
+
+        /* ---- pack the 64 window pairs into bit planes, one request at a time, all lanes helping ---- */
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t ri = wave_bcast_u32(r, i);
+            const int Qi = (int)wave_bcast_u32((uint32_t)Q, i), Ti = (int)wave_bcast_u32((uint32_t)T, i);
+            if (Qi == 0) continue;
+            const uint8_t *qb = winbuf + (uint64_t)ri * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+            for (int p = 0; 64 * p < Qi; ++p) {
+                const int x = 64 * p + lane;
+                const uint32_t c = x < Qi ? qb[x] : 0u;
+                const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
+                if (lane < 2) {
+                    q_lo[2 * p + lane][i] = (uint32_t)(lo >> (32 * lane));
+                    q_hi[2 * p + lane][i] = (uint32_t)(hi >> (32 * lane));
+                }
+            }
+            for (int p = 0; 64 * p < Ti; ++p) {
+                const int x = 64 * p + lane;
+                const uint32_t c = x < Ti ? tbuf[x] : 0u;
+                const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
+                if (lane < 2) {
+                    t_lo[2 * p + lane][i] = (uint32_t)(lo >> (32 * lane));
+                    t_hi[2 * p + lane][i] = (uint32_t)(hi >> (32 * lane));
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+
+        /* ---- forward: banded block Myers, one window per lane ---- */
+        const BrxGeom g = brx_make_geom(Q > 0 ? Q : 1, T > 0 ? T : 1, kb);
+        const int NS = (Q + 31) >> 5;
+        const uint32_t lastmask = (Q & 31) ? ((1u << (Q & 31)) - 1u) : 0xFFFFFFFFu;
+        const int Tmax = (int)wave_max_u32((uint32_t)T);
+        const int Wb = (int)wave_max_u32(valid ? (uint32_t)((g.dhi - g.dlo) / 32 + 2) : 0u);
+        int s_hi = -1;
+        for (int j = 1; j <= Tmax; ++j) {
+            const bool act = j <= T;
+            /* blocks entering the band at this column: cells below the band grow by +1 per row */
+            int new_hi = (j + g.dhi - 1) >> 5;
+            if (new_hi > NS - 1) new_hi = NS - 1;
+            if (!act) new_hi = s_hi;
+            while (__ballot(s_hi < new_hi) != 0ull) {
+                if (s_hi < new_hi) { s_hi += 1; st_pv[s_hi & (BRX_LANE_W - 1)][lane] = 0xFFFFFFFFu; st_mv[s_hi & (BRX_LANE_W - 1)][lane] = 0u; }
+            }
+            int s_lo = (j + g.dlo - 1) >> 5;
+            if (s_lo < 0) s_lo = 0;
+            const int w = (j - 1) >> 5, bit = (j - 1) & 31;
+            const uint32_t c0 = (t_lo[w][lane] >> bit) & 1u, c1 = (t_hi[w][lane] >> bit) & 1u;
+            const uint32_t m0 = 0u - c0, m1 = 0u - c1;
+            uint32_t hp = 1u, hm = 0u;
+            uint2 *dstj = tbw + ((uint64_t)j * BRX_LANE_W) * 64u + (uint32_t)lane;
+            for (int x = 0; x < Wb; ++x) {
+                const int sb = s_lo + x;
+                const bool on = act && sb <= s_hi;
+                const int sbc = on ? sb : 0;
+                const int slot = sbc & (BRX_LANE_W - 1);
+                uint32_t pv = st_pv[slot][lane], mv = st_mv[slot][lane];
+                uint32_t Eq = ~((q_lo[sbc][lane] ^ m0) | (q_hi[sbc][lane] ^ m1));
+                if (sbc == NS - 1) Eq &= lastmask;
+                const uint32_t Xv = Eq | mv;
+                const uint32_t Eq2 = Eq | hm;
+                const uint32_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
+                const uint32_t Ph = mv | ~(Xh | pv);
+                const uint32_t Mh = pv & Xh;
+                const uint32_t op = Ph >> 31, om = Mh >> 31;
+                const uint32_t PhS = (Ph << 1) | hp;
+                const uint32_t MhS = (Mh << 1) | hm;
+                pv = MhS | ~(Xv | PhS);
+                mv = PhS & Xv;
+                if (on) {
+                    st_pv[slot][lane] = pv; st_mv[slot][lane] = mv;
+                    dstj[(uint32_t)slot * 64u] = make_uint2(pv, Ph);
+                    hp = op; hm = om;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+
+        /* ---- traceback, canonical (up, left, diagonal), 8 columns fetched per round trip ---- */
+        int i = Q, j = T;
+        uint32_t ncols = 0, nmatch = 0;
+        bool ok = valid;
+        bool go = valid && i > 0 && j > 0;
+        while (__ballot(go) != 0ull) {
+            const int s0 = go ? ((i - 1) >> 5) : 0;           /* block of the current row; rows may cross into s0 - 1 */
+            const int jst = j;
+            uint2 A[8], Bv[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int col = jst - x;
+                A[x] = make_uint2(0u, 0u); Bv[x] = make_uint2(0u, 0u);
+                if (go && col >= 1) {
+                    A[x] = tbw[((uint64_t)col * BRX_LANE_W + (uint32_t)(s0 & (BRX_LANE_W - 1))) * 64u + (uint32_t)lane];
+                    if (s0 > 0) Bv[x] = tbw[((uint64_t)col * BRX_LANE_W + (uint32_t)((s0 - 1) & (BRX_LANE_W - 1))) * 64u + (uint32_t)lane];
+                }
+            }
+            bool walk = go;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                /* column jst - x: climb while the vertical delta is +1, then leave leftwards or diagonally */
+                for (int guard = 0; guard < 72; ++guard) {
+                    const bool here = walk && i > 0 && j == jst - x && j > 0;
+                    if (__ballot(here) == 0ull) break;
+                    if (here) {
+                        const int sb = (i - 1) >> 5;
+                        if (sb != s0 && sb != s0 - 1) walk = false;                 /* left the two fetched blocks: refetch */
+                        else {
+                            const int jf = 32 * sb - g.dhi + 1 < 1 ? 1 : 32 * sb - g.dhi + 1;
+                            long long jl = 32ll * (sb + 1) - g.dlo; if (jl > T) jl = T;
+                            if (j < jf || j > jl) { ok = false; walk = false; go = false; }
+                            else {
+                                const uint32_t sel = 0u - (uint32_t)(sb == s0);
+                                const uint32_t vx = (A[x].x & sel) | (Bv[x].x & ~sel), vy = (A[x].y & sel) | (Bv[x].y & ~sel);
+                                const int bit = (i - 1) & 31;
+                                if ((vx >> bit) & 1u) { i -= 1; ncols += 1; }
+                                else if ((vy >> bit) & 1u) { j -= 1; ncols += 1; }
+                                else {
+                                    const int qi_ = i - 1, tj = j - 1;
+                                    const uint32_t qc = ((q_lo[qi_ >> 5][lane] >> (qi_ & 31)) & 1u) | (((q_hi[qi_ >> 5][lane] >> (qi_ & 31)) & 1u) << 1);
+                                    const uint32_t tc = ((t_lo[tj >> 5][lane] >> (tj & 31)) & 1u) | (((t_hi[tj >> 5][lane] >> (tj & 31)) & 1u) << 1);
+                                    nmatch += (uint32_t)(qc == tc);
+                                    i -= 1; j -= 1; ncols += 1;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            go = go && ok && i > 0 && j > 0;
+        }
+        if (valid) {
+            ncols += (uint32_t)(i + j);
+            if (ok && (ncols - nmatch) > (uint32_t)kb) ok = false;
+            msv[r].res_ncols = ok ? ncols : 0u;
+            msv[r].res_nmatch = ok ? nmatch : 0u;
+            if (!ok) msv[r].status = ms.status | BRX_RS_BAND;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+}
+
+#endif /* BRX_MUTATE_H */
