@@ -254,7 +254,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     PPiece *pieces = (PPiece *)A.take((size_t)(tot_pieces + 1) * sizeof(PPiece));
     uint8_t *Fbuf = (uint8_t *)A.take((size_t)f_bytes + 64);
     uint32_t *repl = (uint32_t *)A.take(((size_t)f_bytes + 64) * 4);
-    const uint32_t side_waves = std::min<uint32_t>(n_reads, 256u);                  /* wave-level window aligner / legacy */
+    const uint32_t side_waves = std::min<uint32_t>(n_reads, 4096u);                 /* wave-level window aligner / legacy */
     const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, 512u);      /* lane-level window aligner          */
     uint8_t *win = (uint8_t *)A.take((size_t)side_waves * c->win_bytes);
     MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
@@ -292,19 +292,40 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         const uint32_t *n_in = mctr + 2 * MC_WORDS + MC_OUT;
         const uint32_t *act_in = order;
         uint32_t n_up = n_reads, pass = 0;
+        const uint32_t lane_threshold = 6144;      /* fewer active reads than this: one wave per window (lower latency) */
+        const uint32_t tail_reads = 48;            /* this few reads left: run them to completion on the GPU            */
+        auto read_counts = [&](uint32_t *ctr) -> int {
+            HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            return wait_stream(c, st, "mutate pass");
+        };
         for (; n_up > 0 && pass < (1u << 20); ++pass) {
             uint32_t *ctr = mctr + (pass & 1u) * MC_WORDS;
             uint32_t *act_out = (pass & 1u) ? active_b : active_a;
             HIPCHK(c, hipMemsetAsync(ctr, 0, MC_WORDS * sizeof(uint32_t), st));
-            hipLaunchKernelGGL(k_mutate_seg, dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out, ctr,
-                               req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk);
-            hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64)), dim3(64), 0, st, msv, req_easy,
-                               ctr + MC_EASY, winbuf, lane_tb);
+            if (n_up <= tail_reads) {
+                hipLaunchKernelGGL((k_mutate_seg<true>), dim3(n_up), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out, ctr,
+                                   req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
+                                   win, (uint64_t)c->win_bytes, counters + 1);
+                rc = read_counts(ctr);
+                if (rc) return rc;
+                n_up = h_ctr[MC_OUT];                   /* 0 unless a window overflowed its slot (then: legacy list) */
+                ++pass;
+                break;
+            }
+            hipLaunchKernelGGL((k_mutate_seg<false>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                               ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
+                               win, (uint64_t)c->win_bytes, counters + 1);
+            if (n_up > lane_threshold)
+                hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64)), dim3(64), 0, st, msv, req_easy,
+                                   ctr + MC_EASY, winbuf, lane_tb);
             hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
                                ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1);
-            HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            { int rcw = wait_stream(c, st, "mutate pass"); if (rcw) return rcw; }
-            n_up = h_ctr[MC_OUT];
+            /* the active count only shrinks: look at it every 4th pass while it is large, every pass near the end */
+            if (n_up <= 4 * tail_reads || (pass & 3u) == 3u) {
+                rc = read_counts(ctr);
+                if (rc) return rc;
+                n_up = h_ctr[MC_OUT];
+            }
             n_in = ctr + MC_OUT;
             act_in = act_out;
         }

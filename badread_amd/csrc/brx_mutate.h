@@ -49,10 +49,15 @@ enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WOR
 /* -------------------------------------------------------------------------------------------------
  * k_mutate_seg
  * ----------------------------------------------------------------------------------------------- */
+/* INLINE = false: park at every alignment (bulk passes).  INLINE = true: align in place with the
+ * wave-systolic aligner and run every read to completion (the last few reads of a batch, where a
+ * host round trip per alignment would cost more than the alignment). */
+template <bool INLINE>
 __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
                                                     const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,
                                                     uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
-                                                    const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk) {
+                                                    const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk,
+                                                    uint32_t lane_threshold, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
@@ -79,6 +84,7 @@ __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, co
         uint64_t loops = 0;
         uint32_t change = 0, nalign = 0;
         bool resume = ms.phase == 1u;
+        uint32_t st_extra = ms.status;
         if (resume) {
             errors = ms.errors; loops = ms.round_loops; change = ms.change; nalign = ms.nalign;
             const double id = ms.res_ncols ? (double)ms.res_nmatch / (double)ms.res_ncols : 0.0;     /* misc.py:228-240 */
@@ -168,11 +174,27 @@ __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, co
                             wave_join(em, F, rp, a, b, tbuf, nullptr);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             __builtin_amdgcn_s_waitcnt(0);
+                            if constexpr (INLINE) {
+                                uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)blockIdx.x * scr_bytes);
+                                int ncols = 0, nmatch = 0; bool nospace = false;
+                                const bool ok = brx_wave_align<1>(qb, (int)ql, tbuf, (int)tl, (int)cost, tb, scr_bytes / 8, nullptr,
+                                                                  &ncols, &nmatch, &nospace);
+                                if (!ok && !nospace) st_extra |= BRX_RS_BAND;
+                                if (nospace && lane == 0) atomicOr(&flags[0], 1u);
+                                const double id = ncols ? (double)nmatch / (double)ncols : 0.0;
+                                if (n <= BRX_ALIGN_SIZE) errors = (1.0 - id) * dn;
+                                else {
+                                    const double est_err = (1.0 - id) * dn;
+                                    const double weight = (double)BRX_ALIGN_SIZE / dn;
+                                    errors = est_err * weight + errors * (1.0 - weight);
+                                }
+                                continue;                           /* next position of this k-mer */
+                            }
                             for (uint32_t x = lane; x < tl; x += 64) odd |= tbuf[x] > 3;
                             const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
                             const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
                             const bool easy = __ballot(odd) == 0ull && g.G == 1 && band_blocks <= BRX_LANE_W &&
-                                              tl <= BRX_LANE_TMAX && ql > 0 && tl > 0;
+                                              tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 && n_in > lane_threshold;
                             klass = easy ? MC_EASY : MC_HARD;
                         }
                         if (lane == 0) {
@@ -181,7 +203,7 @@ __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, co
                             o.phase = klass == MC_LEGACY ? 3u : 1u;
                             o.surv_lane = (uint32_t)l; o.j_next = (uint32_t)(j + 1);
                             o.win_a = a; o.win_b = b; o.tl = tl; o.cost = cost; o.res_ncols = 0; o.res_nmatch = 0;
-                            o.passes = ms.passes + 1;
+                            o.passes = ms.passes + 1; o.status = st_extra;
                             msv[r] = o;
                             uint32_t *list = klass == MC_EASY ? req_easy : klass == MC_HARD ? req_hard : req_legacy;
                             list[atomicAdd(klass == MC_LEGACY ? legacy_ctr : &ctr[klass], 1u)] = r;
@@ -216,7 +238,7 @@ __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, co
         st = wave_sum(st); et = wave_sum(et);
         if (lane == 0) {
             RS *o = &rs[r];
-            o->status = s.status | ms.status; o->m = m; o->ub = cost; o->start_trim = st; o->end_trim = et;
+            o->status = s.status | st_extra; o->m = m; o->ub = cost; o->start_trim = st; o->end_trim = et;
             o->loops = (uint32_t)loops; o->changes = change; o->naligns = nalign;
             const BrxGeom g = brx_make_geom((int)m, (int)n, (int)cost);
             uint64_t units = (m == 0) ? 0 : brx_align_units(g);
