@@ -11,7 +11,8 @@ plasmids (200 kb depth=2, 5 kb depth=10), uniform ACGT from numpy default_rng(1)
 qscore models; default adapters, junk/random/chimera 1 %, glitches 10000,25,25), seed 42.
 A "step" is ONE pass of the whole hot path (plan -> fragments -> mutate -> align -> qscores ->
 FASTQ bytes) over one batch of `--reads-per-step` read indices per GPU through the C-ABI
-(brx_simulate_batch); the default 8192 reads x 15 kb is ~45 % of the 50x job per step.  Inputs
+(brx_simulate_batch); the default 16384 reads x 15 kb is ~90 % of the 50x job per step, and up to
+`--streams` steps are in flight at once on separate HIP streams (one context each).  Inputs
 (packed reference, model tables) are resident in HBM before the timed region; the FASTQ bytes stay
 in HBM (the PCIe-inclusive rate is reported separately as `value_incl_d2h`).  Weak scaling: every
 rank processes its own slice [step*N*R + rank*R, +R) of the read-index space, no collective on the
@@ -22,6 +23,8 @@ simulated base) and `cpu_baseline` (the C oracle -- a sing
 the same algorithm -- run on all host cores of this box on a bounded sample of the same workload).
 """
 import argparse
+import os as _os
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')      # one hardware queue per in-flight batch stream (HIP's default of 4 serialises them)
 import json
 import os
 import sys
@@ -117,11 +120,11 @@ def cpu_baseline(wl, first_read, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--reads-per-step', type=int, default=8192, help='read indices per GPU per step')
-    ap.add_argument('--scratch-gb', type=float, default=56.0, help='scratch arena per in-flight batch')
-    ap.add_argument('--streams', type=int, default=3,
+    ap.add_argument('--steps', type=int, default=12)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--reads-per-step', type=int, default=16384, help='read indices per GPU per step')
+    ap.add_argument('--scratch-gb', type=float, default=40.0, help='scratch arena per in-flight batch')
+    ap.add_argument('--streams', type=int, default=6,
                     help='batches in flight per GPU (one context + HIP stream + host thread each): the slowest read '
                          'of one batch overlaps the bulk of the next')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline leg (0 = skip)')
