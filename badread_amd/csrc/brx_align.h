@@ -119,10 +119,6 @@ __device__ __forceinline__ int brx_from_lane_above(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
 }
 
-/* timing experiments only (BRX_VARIANT env, results become invalid): bit0 no traceback stores,
- * bit1 no query loads at band entry, bit2 no target-window refills */
-__device__ int brx_variant = 0;
-
 #define BRX_RING_BYTES 512          /* per-wave LDS window of target bytes (two 256-byte halves) */
 /* One wave per workgroup, so one window per workgroup.  File scope keeps the LDS address space
  * visible to the compiler (ds_read_u8 / ds_write_b32); a generic or volatile pointer to it turns
@@ -144,15 +140,24 @@ __shared__ uint32_t brx_ring32[BRX_RING_BYTES / 4];
  * remaining global loads are the 32 query bytes a lane reads when its superblock enters the band
  * (once per R columns per wave).
  * ------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ int brx_wave_min(int v) {
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) { const int o = __shfl_xor(v, dd, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t brx_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   /* v_bfi_b32 */
+
 template <int G>
 __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                   const BrxGeom g, uint2 *__restrict__ tb, uint32_t *prog = nullptr) {
     const int lane = threadIdx.x & 63;
-    const int variant = __builtin_amdgcn_readfirstlane(brx_variant);
     constexpr int NEVER = 0x7FFFFFFF;
-    /* a lane works on superblock s during time steps [tf, tl] (column j = t - s), then hops to s + 64 */
+    /* A lane works on superblock s during time steps [tf, tl] (column j = t - s), then hops to s + 64.
+     * The band is narrower than 62 superblocks (brx_make_geom), so whenever the lane above was active
+     * in the previous step it held superblock s - 1 and worked on this same column: the carry word
+     * needs no tag.  carry: 0 = lane above idle (top of the band: +1), 1/2/3 = hout -1/0/+1. */
     int s = lane;
-    int tf = NEVER, tl = -1, slot = 0;
+    int tf = NEVER, tl = NEVER, slot = 0;
     if (s < g.NS) { tf = brx_jfirst(g, s) + s; tl = brx_jlast(g, s) + s; slot = s % g.WSp; }
     uint32_t Pv[G], Mv[G];
     uint32_t pe[G][5];
@@ -162,44 +167,57 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
 #pragma unroll
         for (int c = 0; c < 5; ++c) pe[x][c] = 0;
     }
-    int packed = -8;                                 /* (superblock << 3) | active << 2 | (hout + 1) of the previous step */
+    uint32_t carry = 0;
 
-    /* target window: chunk c = target bytes [256c, 256c+256) lives in ring half c & 1 */
+    /* target window: chunk c = target bytes [256c, 256c+256) lives in ring half c & 1; `odd` remembers
+       which halves hold a symbol outside A,C,G,T,N (IUPAC codes: slow equality path) */
     auto fetch_chunk = [&](int c) -> uint32_t {
         const int idx = 256 * c + 4 * lane;
         return (idx + 4 <= g.T + 16) ? *reinterpret_cast<const uint32_t *>(Ts + idx) : 0xFEFEFEFEu;
     };
-    brx_ring32[lane] = fetch_chunk(0);
-    brx_ring32[64 + lane] = fetch_chunk(1);
-    uint32_t pending = 0;
+    auto chunk_odd = [&](int c, uint32_t v) -> uint32_t {
+        const int idx = 256 * c + 4 * lane;
+        bool o = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) o |= idx + b < g.T && ((v >> (8 * b)) & 0xFFu) > 4u;
+        return __ballot(o) != 0ull ? 1u : 0u;
+    };
+    uint32_t pending = fetch_chunk(0);
+    brx_ring32[lane] = pending;
+    uint32_t odd = chunk_odd(0, pending);
+    pending = fetch_chunk(1);
+    brx_ring32[64 + lane] = pending;
+    odd |= chunk_odd(1, pending) << 1;
     int s_top = 0;                                   /* first superblock still inside the band (wave-uniform) */
-    int jl_top = brx_jlast(g, 0);
+    int t_top = brx_jlast(g, 0) + 1;                 /* time step at which s_top leaves the band              */
     uint32_t cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(0 - s) & (BRX_RING_BYTES - 1)];   /* column 1 - s */
+    int next_entry = brx_wave_min(tf);               /* next time step at which some lane's superblock enters */
+    int next_hop = brx_wave_min(tl);                 /* ... or leaves the band                                  */
 
     const size_t step_units = (size_t)g.WSp * (size_t)G;
     uint2 *dst = tb + ((size_t)1 * (size_t)g.WSp + (size_t)slot) * (size_t)G;
     for (int t = 1; t <= g.t_end; ++t, dst += step_units) {
-        BRX_PROG(prog, 4, t);
         /* ---- refill of the target window, keyed on the newest column in use (scalar code) ---- */
-        while (__builtin_expect(s_top < g.NS - 1 && t - s_top > jl_top, 0)) { s_top += 1; jl_top = brx_jlast(g, s_top); }
+        while (__builtin_expect(s_top < g.NS - 1 && t >= t_top, 0)) { s_top += 1; t_top = brx_jlast(g, s_top) + s_top + 1; }
         const int front = t - s_top - 1;             /* 0-based target index of the newest column */
-        if (__builtin_expect((front & 63) != 0 || (variant & 4), 1)) { }
-        else if ((front & 255) == 128) pending = fetch_chunk((front >> 8) + 1);
-        else if ((front & 255) == 192) brx_ring32[(((front >> 8) + 1) & 1) * 64 + lane] = pending;
-
-        const int nb = brx_from_lane_above(packed);
-        const uint32_t c = cnext;
-        const bool active = t >= tf && t <= tl;
+        if (__builtin_expect((front & 63) == 0, 0)) {
+            if ((front & 255) == 128) pending = fetch_chunk((front >> 8) + 1);
+            else if ((front & 255) == 192) {
+                const int c = (front >> 8) + 1;
+                brx_ring32[(c & 1) * 64 + lane] = pending;
+                odd = (odd & ~(1u << (c & 1))) | (chunk_odd(c, pending) << (c & 1));
+            }
+        }
 
         /* ---- a superblock enters the band (one lane every R steps): build its equality masks ---- */
-        if (__builtin_expect(__ballot(t == tf) != 0ull, 0)) {
+        if (__builtin_expect(t == next_entry, 0)) {
             if (t == tf) {
 #pragma unroll
                 for (int x = 0; x < G; ++x) {
                     Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;          /* cells below the band grow by +1 per row */
                     const int w = s * G + x;
                     uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
-                    if (w < g.NW && !(variant & 2)) {
+                    if (w < g.NW) {
                         const uint32_t *q4 = reinterpret_cast<const uint32_t *>(Qs + 32 * w);
 #pragma unroll 1
                         for (int d = 0; d < 8; ++d) {
@@ -220,56 +238,61 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
                     pe[x][0] = m0; pe[x][1] = m1; pe[x][2] = m2; pe[x][3] = m3; pe[x][4] = m4;
                 }
             }
+            next_entry = brx_wave_min(tf > t ? tf : NEVER);
         }
 
-        /* ---- the column update, executed by every lane; lanes outside the band discard the result ---- */
-        const bool fed = s > 0 && (nb >> 3) == s - 1 && (nb & 4);      /* the superblock above handed a carry over */
-        uint32_t hp = fed ? (uint32_t)((nb & 3) == 2) : 1u;
-        uint32_t hm = fed ? (uint32_t)((nb & 3) == 0) : 0u;
-        const uint32_t k0 = 0u - (uint32_t)(c == 0), k1 = 0u - (uint32_t)(c == 1), k2 = 0u - (uint32_t)(c == 2),
-                       k3 = 0u - (uint32_t)(c == 3), k4 = 0u - (uint32_t)(c == 4);
-        const bool rare = __builtin_expect(__ballot(active && c > 4) != 0ull, 0);   /* IUPAC symbol other than N in the target */
+        /* ---- the column update: straight-line VALU code, lanes outside the band discard the result ---- */
+        const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
+        const uint32_t c = cnext;
+        const uint32_t actm = ~(uint32_t)(((t - tf) | (tl - t)) >> 31);        /* all ones iff tf <= t <= tl */
+        uint32_t hp = (0x9u >> nb) & 1u, hm = (0x2u >> nb) & 1u;
+        const uint32_t k0 = 0u - (c & 1u), k1 = 0u - ((c >> 1) & 1u), k4 = 0u - ((c >> 2) & 1u);
+        const bool rare = __builtin_expect(odd != 0u, 0) && __ballot(actm != 0u && c > 4u) != 0ull;
 #pragma unroll
         for (int x = 0; x < G; ++x) {
-            /* select by mask arithmetic, NOT by ?: -- hipcc folds a select chain over the elements of a
-               private array into one dynamically indexed load, which pins the whole array in scratch
-               memory (a vmcnt-ordered load per column) */
-            uint32_t Eq = (pe[x][0] & k0) | (pe[x][1] & k1) | (pe[x][2] & k2) | (pe[x][3] & k3) | (pe[x][4] & k4);
-            if (rare) { if (active && c > 4 && s * G + x < g.NW) Eq = brx_eq_rare(Qs, g.Q, s * G + x, c); }
+            /* symbol select by mask arithmetic (v_bfi), NOT by ?: over the array -- hipcc folds a select
+               chain over the elements of a private array into one dynamically indexed load, which pins
+               the array in scratch memory (a vmcnt-ordered load per column) */
+            uint32_t Eq = brx_bfi(k1, brx_bfi(k0, pe[x][3], pe[x][2]), brx_bfi(k0, pe[x][1], pe[x][0]));
+            Eq = brx_bfi(k4, pe[x][4], Eq);
+            if (rare) { if (actm != 0u && c > 4u && s * G + x < g.NW) Eq = brx_eq_rare(Qs, g.Q, s * G + x, c); }
             uint32_t pv = Pv[x], mv = Mv[x];
             const uint32_t Xv = Eq | mv;
             const uint32_t Eq2 = Eq | hm;
             const uint32_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
             const uint32_t Ph = mv | ~(Xh | pv);
             const uint32_t Mh = pv & Xh;
-            const uint32_t op = Ph >> 31, om = Mh >> 31;
             const uint32_t PhS = (Ph << 1) | hp;
             const uint32_t MhS = (Mh << 1) | hm;
             pv = MhS | ~(Xv | PhS);
             mv = PhS & Xv;
-            const bool live = active && (G == 1 || s * G + x < g.NW);   /* words past the last query row do not exist */
-            if (live) {
-                Pv[x] = pv; Mv[x] = mv;
-                if (!(variant & 1)) dst[x] = make_uint2(pv, Ph);
-                hp = op; hm = om;
-            }
+            uint32_t livem = actm;
+            if (G > 1) livem &= 0u - (uint32_t)(s * G + x < g.NW);            /* words past the last query row do not exist */
+            Pv[x] = brx_bfi(livem, pv, Pv[x]);
+            Mv[x] = brx_bfi(livem, mv, Mv[x]);
+            if (livem) dst[x] = make_uint2(pv, Ph);
+            hp = brx_bfi(livem, Ph >> 31, hp);
+            hm = brx_bfi(livem, Mh >> 31, hm);
         }
-        packed = (s << 3) | (active ? (4 | (int)(hp + 1u - hm)) : 0);
+        carry = (hp + 2u - hm) & actm;
 
         /* ---- a superblock leaves the band: its lane takes superblock s + 64 ---- */
-        if (__builtin_expect(__ballot(t >= tl && tf != NEVER) != 0ull, 0)) {
-            if (t >= tl && tf != NEVER) {
+        if (__builtin_expect(t == next_hop, 0)) {
+            if (t >= tl) {
                 s += 64;
                 if (s < g.NS) {
                     tf = brx_jfirst(g, s) + s; tl = brx_jlast(g, s) + s;
                     const int nslot = s % g.WSp;
                     dst += ((ptrdiff_t)nslot - (ptrdiff_t)slot) * (ptrdiff_t)G;
                     slot = nslot;
-                } else { tf = NEVER; tl = -1; }
+                } else { tf = NEVER; tl = NEVER; }
             }
+            next_hop = brx_wave_min(tl);
+            next_entry = brx_wave_min(tf > t ? tf : NEVER);
         }
         cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(t - s) & (BRX_RING_BYTES - 1)];   /* column t + 1 - s */
     }
+    (void)prog;
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -117,12 +117,6 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
-    {
-        const char *v = getenv("BRX_VARIANT");
-        int variant = v ? atoi(v) : 0;
-        if ((e = hipMemcpyToSymbol(HIP_SYMBOL(brx_variant), &variant, sizeof(int))) != hipSuccess)
-            return create_fail(c, "hipMemcpyToSymbol(brx_variant)", e);
-    }
     c->err[0] = 0;
     *out = c;
     return BRX_OK;
@@ -232,12 +226,12 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     RS *rs = (RS *)A.take((size_t)n_reads * sizeof(RS));
     uint64_t *totals = (uint64_t *)A.take(16 * sizeof(uint64_t));
     uint32_t *order = (uint32_t *)A.take((size_t)n_reads * 4);
-    uint32_t *counters = (uint32_t *)A.take(128 * 4);       /* [0] mutate queue, [1] flags, [2..] final queues (2 per chunk) */
+    uint32_t *counters = (uint32_t *)A.take(256 * 4);       /* [0] unused, [1] flags, [2..] final-stage queues (4 per chunk) */
     uint64_t *units_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *tboff_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *clk = (uint64_t *)A.take((size_t)n_reads * 64);     /* per-read cycle counters, brx_last_read_cycles() */
     if (!A.ok()) return scratch_short(c, A.used + (size_t)n_reads * 200000);
-    HIPCHK(c, hipMemsetAsync(counters, 0, 128 * 4, st));
+    HIPCHK(c, hipMemsetAsync(counters, 0, 256 * 4, st));
     HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, st));
     HIPCHK(c, hipMemsetAsync(clk, 0, (size_t)n_reads * 64, st));
     c->d_clk = clk; c->clk_reads = n_reads;
@@ -398,12 +392,16 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         /* wide reads are few but long: start them first on the side stream, narrow ones fill the rest of the chip */
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        hipLaunchKernelGGL((k_final<16, true>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, c->side,
-                           dev, rs, order, b, e, counters + 2 + 2 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+        hipLaunchKernelGGL((k_fin_align<16, 4, 64>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, c->side,
+                           dev, rs, order, b, e, counters + 2 + 4 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+        hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, c->side,
+                           dev, rs, order, b, e, counters + 3 + 4 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
-        hipLaunchKernelGGL((k_final<2, false>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 3 + 2 * ci,
+        hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 4 + 4 * ci,
                            Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 5 + 4 * ci,
+                           seqbuf, opsbuf, tb_base, clk);
     }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_FINAL], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_EMIT], st));

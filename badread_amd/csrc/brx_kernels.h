@@ -7,7 +7,8 @@
  *   k_build     1 wave  = 1 read   fragment bytes from the 2-bit reference, coalesced
  *   k_mutate    1 wave  = 1 read   64 k-mer proposals per step, survivors applied in lane order,
  *                                  in-loop windowed Myers alignment by the whole wave
- *   k_final     1 wave  = 1 read   join -> banded Myers + traceback -> qscore windows -> quals
+ *   k_fin_align 1 wave  = 1 read   join -> banded Myers + traceback (one instantiation per band class)
+ *   k_fin_qscore 1 wave = 1 read   qscore windows -> quals
  *   k_emit      1 wave  = 1 read   FASTQ bytes
  * Waves of the heavy kernels are persistent and pull reads (longest first) from a device queue.
  */
@@ -720,59 +721,88 @@ __device__ inline int64_t qs_lookup(const brx_qscore_model &qm, uint64_t key) {
     }
 }
 
-/* Two instantiations share every queue range: k_final<2, false> takes the reads whose band fits two
- * words per lane (lean registers, high occupancy), k_final<16, true> the wide ones; each skips the
- * other's reads.  They run concurrently on two streams. */
-template <int MAXG, bool WIDE>
-__global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
-                                               uint32_t *queue, const uint8_t *Fbuf, const uint32_t *repl,
-                                               uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
-    __shared__ uint32_t qhist[256];
+/* The final stage is two kernels so that each gets its own register budget (occupancy is what hides
+ * the latency of the serial column steps):
+ *   k_fin_align<MAXG, GLO, GHI>   join + banded Myers + traceback for the reads whose band geometry has
+ *                                 GLO <= words-per-lane <= GHI; every instantiation walks the same queue
+ *                                 range and skips the other classes' reads, so narrow and wide reads run
+ *                                 side by side on two streams
+ *   k_fin_qscore                  cigar windows -> qscore rows -> quality bytes, per-read statistics     */
+template <int MAXG, int GLO, int GHI>
+__global__ void __launch_bounds__(64) k_fin_align(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
+                                                   uint32_t *queue, const uint8_t *Fbuf, const uint32_t *repl,
+                                                   uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
-    const brx_qscore_model &qm = d.qm;
-    const int k = em.k;
     for (;;) {
         const uint32_t qi = q_begin + wave_pop(queue);
         if (qi >= q_end) break;
         const uint32_t r = order[qi];
-        RS s = rs[r];
+        const RS s = rs[r];
         if (s.n == 0) continue;
         {
-            const int G = s.m ? brx_make_geom((int)s.m, (int)s.n, (int)s.ub).G : 1;
-            if ((G > 2 || G == 0) != WIDE) continue;
+            int G = s.m ? brx_make_geom((int)s.m, (int)s.n, (int)s.ub).G : 1;
+            if (G == 0) G = 64;                                  /* no geometry: the widest class reports the failure */
+            if (G < GLO || G > GHI) continue;
         }
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
         uint64_t aclk[2] = {0, 0};
-        const uint64_t read = d.first_read + r;
         const uint32_t n = s.n, m = s.m;
         const uint8_t *F = Fbuf + s.F_off;
         const uint32_t *rp = repl + s.F_off;
         uint8_t *seq = seqbuf + s.seq_off;
-        uint8_t *qual = seq + (((uint64_t)m + 16 + 15) & ~15ull);
         uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
         uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
-        uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
-        uint32_t *col_of = reinterpret_cast<uint32_t *>(tb + (s.units - col_units));
+        const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
 
         wave_join(em, F, rp, 0, n, seq, nullptr);
         for (uint32_t x = lane; x < 16; x += 64) seq[m + x] = 0xFE;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         int ncols = 0, nmatch = 0; bool nospace = false;
-        bool ok = brx_wave_align<MAXG>(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch, &nospace,
-                                 nullptr, aclk);
-        const uint64_t t_aligned = __builtin_amdgcn_s_memtime();
-        if (!ok) s.status |= BRX_RS_BAND;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
+        const bool ok = brx_wave_align<MAXG>(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch,
+                                             &nospace, nullptr, aclk);
+        if (lane == 0) {
+            RS *o = &rs[r];
+            o->status = s.status | (ok ? 0u : BRX_RS_BAND);
+            o->n_cols = (uint32_t)ncols; o->n_match = (uint32_t)nmatch;
+            uint64_t *ck = clk + (uint64_t)r * 8;
+            ck[3] = __builtin_amdgcn_s_memtime() - t_begin; ck[4] = aclk[0]; ck[5] = aclk[1];
+            ck[7] = (uint64_t)brx_make_geom((int)m, (int)n, (int)s.ub).G;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
+                                                    uint32_t *queue, uint8_t *seqbuf, const uint8_t *opsbuf, uint8_t *tb_base,
+                                                    uint64_t *clk) {
+    __shared__ uint32_t qhist[256];
+    const int lane = lane_id();
+    const brx_qscore_model &qm = d.qm;
+    for (;;) {
+        const uint32_t qi = q_begin + wave_pop(queue);
+        if (qi >= q_end) break;
+        const uint32_t r = order[qi];
+        RS s = rs[r];
+        if (s.n == 0) continue;
+        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        const uint64_t read = d.first_read + r;
+        const uint32_t n = s.n, m = s.m;
+        uint8_t *seq = seqbuf + s.seq_off;
+        uint8_t *qual = seq + (((uint64_t)m + 16 + 15) & ~15ull);
+        const uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
+        uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
+        const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
+        uint32_t *col_of = reinterpret_cast<uint32_t *>(tb + (s.units - col_units));
+        const bool ok = !(s.status & BRX_RS_BAND);
+        const uint32_t ncols = s.n_cols;
         const uint8_t *ops = ops_end - ncols;
 
         /* column of every read base (qscore_model.py:46-52) */
         uint32_t run = 0;
-        for (uint32_t base = 0; base < (uint32_t)ncols; base += 64) {
+        for (uint32_t base = 0; base < ncols; base += 64) {
             uint32_t c = base + lane;
-            uint32_t nd = (c < (uint32_t)ncols && ops[c] != BRX_OP_D) ? 1u : 0u;
+            uint32_t nd = (c < ncols && ops[c] != BRX_OP_D) ? 1u : 0u;
             uint32_t inc = wave_incl_scan(nd);
             if (nd) col_of[run + inc - 1] = c;
             run += wave_bcast_u32(inc, 63);
@@ -845,12 +875,9 @@ __global__ void __launch_bounds__(64) k_final(BrxDev d, RS *rs, const uint32_t *
             if (hi < lo) hi = lo;
             RS *o = &rs[r];
             o->status = s.status | ((hi - lo) == 0 ? BRX_RS_EMPTY : 0u);
-            o->n_cols = (uint32_t)ncols; o->n_match = (uint32_t)nmatch; o->qerr = qerr;
+            o->qerr = qerr;
             o->seq_len = hi - lo;
-            uint64_t *ck = clk + (uint64_t)r * 8;
-            const uint64_t t_end = __builtin_amdgcn_s_memtime();
-            ck[3] = t_end - t_begin; ck[4] = aclk[0]; ck[5] = aclk[1]; ck[6] = t_end - t_aligned;
-            ck[7] = (uint64_t)brx_make_geom((int)m, (int)n, (int)s.ub).G;
+            clk[(uint64_t)r * 8 + 6] = __builtin_amdgcn_s_memtime() - t_begin;
         }
         __syncthreads();
     }
