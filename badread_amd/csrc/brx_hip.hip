@@ -21,6 +21,8 @@
 
 #include "brx_kernels.h"
 
+#define BRX_MAX_CHUNKS 60
+
 struct brx_ctx {
     int device;
     int n_cu;
@@ -36,7 +38,9 @@ struct brx_ctx {
     hipEvent_t ev_b[BRX_STAGE_COUNT], ev_e[BRX_STAGE_COUNT];   /* begin / end of each stage on the launch stream */
     float stage_ms[BRX_STAGE_COUNT];
     uint32_t final_launches, mutate_passes;
-    hipStream_t side;            /* second stream: the wide-band k_final runs beside the narrow one */
+    hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one */
+    hipEvent_t ev_a1b[BRX_MAX_CHUNKS], ev_a1e[BRX_MAX_CHUNKS];   /* k_fin_align<1,1,1> of every scratch chunk */
+    hipEvent_t ev_qsb[BRX_MAX_CHUNKS], ev_qse[BRX_MAX_CHUNKS];   /* k_fin_qscore of every scratch chunk      */
     hipEvent_t ev_fork, ev_join;
     uint64_t *d_clk; uint32_t clk_reads;
     char err[512];
@@ -115,6 +119,11 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         if ((e = hipEventCreate(&c->ev_e[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     }
     if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
+    for (int i = 0; i < BRX_MAX_CHUNKS; ++i) {
+        if ((e = hipEventCreate(&c->ev_a1b[i])) != hipSuccess || (e = hipEventCreate(&c->ev_a1e[i])) != hipSuccess ||
+            (e = hipEventCreate(&c->ev_qsb[i])) != hipSuccess || (e = hipEventCreate(&c->ev_qse[i])) != hipSuccess)
+            return create_fail(c, "hipEventCreate", e);
+    }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     c->err[0] = 0;
@@ -193,6 +202,7 @@ extern "C" int brx_last_read_cycles(brx_ctx *c, uint64_t *h_out, uint32_t n_read
     return BRX_OK;
 }
 
+extern "C" uint32_t brx_last_mutate_passes(const brx_ctx *c) { return c ? c->mutate_passes : 0; }
 extern "C" uint32_t brx_last_final_launches(const brx_ctx *c) { return c ? c->final_launches : 0; }
 
 static int read_totals(brx_ctx *c, hipStream_t st, const uint64_t *d_totals, int n) {
@@ -397,11 +407,15 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, c->side,
                            dev, rs, order, b, e, counters + 3 + 4 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+        HIPCHK(c, hipEventRecord(c->ev_a1b[ci], st));
         hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 4 + 4 * ci,
                            Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+        HIPCHK(c, hipEventRecord(c->ev_a1e[ci], st));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        HIPCHK(c, hipEventRecord(c->ev_qsb[ci], st));
         hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 5 + 4 * ci,
                            seqbuf, opsbuf, tb_base, clk);
+        HIPCHK(c, hipEventRecord(c->ev_qse[ci], st));
     }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_FINAL], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_EMIT], st));
@@ -423,8 +437,16 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     HIPCHK(c, hipGetLastError());
     for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
         float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, c->ev_b[i], c->ev_e[i]);
+        if (i != BRX_STAGE_ALIGN1 && i != BRX_STAGE_QSCORE) (void)hipEventElapsedTime(&ms, c->ev_b[i], c->ev_e[i]);
         c->stage_ms[i] = ms;
+    }
+    /* per-launch AVERAGE over the scratch chunks, which is what a kernel trace reports */
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+        float a = 0.f, q = 0.f;
+        (void)hipEventElapsedTime(&a, c->ev_a1b[ci], c->ev_a1e[ci]);
+        (void)hipEventElapsedTime(&q, c->ev_qsb[ci], c->ev_qse[ci]);
+        c->stage_ms[BRX_STAGE_ALIGN1] += a / (float)chunks.size();
+        c->stage_ms[BRX_STAGE_QSCORE] += q / (float)chunks.size();
     }
     c->final_launches = (uint32_t)chunks.size();
     if (out_bytes) *out_bytes = (size_t)rec_bytes;

@@ -78,7 +78,7 @@ assert READ_STATS_DTYPE.itemsize == 64
 
 RS_NOFRAG, RS_TOO_MANY_SEGS, RS_BAND, RS_QMISS, RS_EMPTY = 1, 2, 4, 8, 16
 E_SCRATCH, E_OUTPUT, E_NOFRAG = -3, -4, -5
-STAGE_NAMES = ('plan', 'build', 'mutate', 'scan', 'final', 'emit')
+STAGE_NAMES = ('plan', 'build', 'mutate', 'scan', 'final', 'emit', 'align1', 'qscore')
 
 
 class SimParams(object):
@@ -233,9 +233,11 @@ def load_library():
     lib.brx_align_batch.restype = ctypes.c_int
     lib.brx_align_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 11
     lib.brx_last_stage_ms.restype = ctypes.c_int
-    lib.brx_last_stage_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float * 6)]
+    lib.brx_last_stage_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float * 8)]
     lib.brx_last_read_cycles.restype = ctypes.c_int
     lib.brx_last_read_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    lib.brx_last_mutate_passes.restype = ctypes.c_uint32
+    lib.brx_last_mutate_passes.argtypes = [ctypes.c_void_p]
     lib.brx_last_final_launches.restype = ctypes.c_uint32
     lib.brx_last_final_launches.argtypes = [ctypes.c_void_p]
     _lib = lib
@@ -430,7 +432,7 @@ class HipEngine(EngineBase):
         return ops_list, dist, ncols, nmatch
 
     def stage_ms(self):
-        arr = (ctypes.c_float * 6)()
+        arr = (ctypes.c_float * 8)()
         self._check(self.lib.brx_last_stage_ms(self.ctx, ctypes.byref(arr)))
         return dict(zip(STAGE_NAMES, [float(x) for x in arr]))
 
@@ -439,6 +441,9 @@ class HipEngine(EngineBase):
         out = np.zeros((n_reads, 8), dtype=np.uint64)
         self._check(self.lib.brx_last_read_cycles(self.ctx, out.ctypes.data, n_reads))
         return out
+
+    def mutate_passes(self):
+        return int(self.lib.brx_last_mutate_passes(self.ctx))
 
     def final_launches(self):
         return int(self.lib.brx_last_final_launches(self.ctx))

@@ -84,40 +84,55 @@ def configure(engine, wl):
     return engine
 
 
-def cpu_baseline(wl, first_read, budget_s):
-    """The oracle (oracle/brx_oracle.c, a scalar C port of the same path) on every host core: threads pull
-    16-read chunks of the same read-index stream until `budget_s` seconds have passed."""
+def cpu_worker(first_read, budget_s, out_path):
+    """One process = one core: the oracle over 16-read chunks of the same read-index stream for `budget_s` seconds."""
+    import io
     sys.path.insert(0, os.path.join(REPO, 'oracle'))
     import pyoracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    chunk = 16
-    lock = threading.Lock()
-    state = {'next': 0, 'bases': 0, 'reads': 0}
+    eng = configure(pyoracle.OracleEngine(), build_workload(io.StringIO()))
+    eng.simulate_batch(SEED, first_read, 2)                      # page everything in before the clock starts
+    bases = reads = 0
     t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        _, st = eng.simulate_batch(SEED, first_read + reads, 16)
+        bases += int(st['seq_len'].sum())
+        reads += 16
+    with open(out_path, 'w') as f:
+        json.dump({'bases': bases, 'reads': reads, 'seconds': time.perf_counter() - t0}, f)
 
-    def worker():
-        eng = configure(pyoracle.OracleEngine(), wl)
-        while time.perf_counter() - t0 < budget_s:
-            with lock:
-                idx = state['next']
-                state['next'] += 1
-            _, st = eng.simulate_batch(SEED, first_read + idx * chunk, chunk)     # ctypes releases the GIL
-            with lock:
-                state['bases'] += int(st['seq_len'].sum())
-                state['reads'] += chunk
 
-    threads = [threading.Thread(target=worker) for _ in range(cores)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    dt = time.perf_counter() - t0
-    return {'value': state['bases'] / dt, 'unit': 'bases/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{state["reads"]} reads / {state["bases"]} bases of the same workload and seed in {dt:.1f} s, '
-                      f'oracle/brx_oracle.c (gcc -O2), one thread per host core'}
+def cpu_baseline(first_read, budget_s):
+    """The oracle (oracle/brx_oracle.c, a scalar C port of the same path: gamma/beta draws, fragment build, mutate
+    loop with block-Myers window alignments, final alignment + traceback, qscore lookup, FASTQ record) on EVERY host
+    core: one single-threaded process per core, disjoint slices of the same read-index stream, own clock each."""
+    import subprocess
+    import tempfile
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    tmp = tempfile.mkdtemp(prefix='brx_cpu_')
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='')
+    procs = []
+    for i in range(cores):
+        out = os.path.join(tmp, f'{i}.json')
+        procs.append((out, subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(first_read + i * 100000),
+                                             str(budget_s), out], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    bases = reads = 0
+    rate = 0.0
+    done = 0
+    for out, pr in procs:
+        pr.wait()
+        if os.path.isfile(out):
+            rec = json.load(open(out))
+            bases += rec['bases']; reads += rec['reads']; rate += rec['bases'] / rec['seconds']; done += 1
+    return {'value': rate, 'unit': 'bases/s', 'cores': done, 'kind': 'port',
+            'sample': f'{reads} reads / {bases} bases of the same workload and seed, {budget_s:.0f} s of CPU time per core, '
+                      f'oracle/brx_oracle.c (gcc -O2) as one single-threaded process per host core; value = sum of the '
+                      f'per-process rates'}
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == '--cpu-worker':
+        cpu_worker(int(sys.argv[2]), float(sys.argv[3]), sys.argv[4])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=12)
@@ -127,7 +142,7 @@ def main():
     ap.add_argument('--streams', type=int, default=6,
                     help='batches in flight per GPU (one context + HIP stream + host thread each): the slowest read '
                          'of one batch overlaps the bulk of the next')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline leg (0 = skip)')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='seconds each host core runs the cpu_baseline leg (0 = skip)')
     ap.add_argument('--d2h', action='store_true', help='also time steps that copy the FASTQ bytes to pinned host memory')
     args = ap.parse_args()
 
@@ -170,7 +185,7 @@ def main():
 
     def run_steps(indices):
         """Steps `indices`, C at a time: worker i owns context i / stream i and takes every C-th step."""
-        acc = [{'bases': 0, 'stages': {}, 'final_launches': 0, 'error': None} for _ in range(C)]
+        acc = [{'bases': 0, 'g1_bases': 0, 'passes': 0, 'stages': {}, 'final_launches': 0, 'error': None} for _ in range(C)]
 
         def worker(i):
             try:
@@ -179,6 +194,9 @@ def main():
                     for idx in indices[i::C]:
                         _, stats = step(idx, engines[i])
                         acc[i]['bases'] += int(stats['seq_len'].sum())
+                        g_words = engines[i].read_cycles(R)[:, 7]
+                        acc[i]['g1_bases'] += int(stats['seq_len'][g_words == 1].sum())
+                        acc[i]['passes'] += engines[i].mutate_passes()
                         for name, ms in engines[i].stage_ms().items():
                             acc[i]['stages'][name] = acc[i]['stages'].get(name, 0.0) + ms
                         acc[i]['final_launches'] += engines[i].final_launches()
@@ -235,12 +253,15 @@ def main():
             dist.destroy_process_group()
         return
     stages = {k: v / args.steps for k, v in stage_sum.items()}
-    dominant = max(('mutate', 'final'), key=lambda k: stages.get(k, 0.0))
-    kernel = {'mutate': 'k_mutate', 'final': 'k_final'}[dominant]
-    launches = 1.0 if dominant == 'mutate' else final_launches / args.steps
+    # dominant single kernel: k_fin_align<1,1,1> (final banded Myers alignment + traceback of the reads whose band
+    # fits one 32-bit word per lane); stage 'align1' is the HIP-event duration of ONE launch, averaged over launches
+    kernel = 'k_fin_align<1,1,1>'
+    launches = final_launches / args.steps
+    g1_bases_per_step = sum(a['g1_bases'] for a in acc) / args.steps
+    launch_ms = stages['align1']
+    algo_bytes = ALGO_BYTES_PER_BASE * g1_bases_per_step / launches
+    achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
     bases_per_step_rank0 = bases / (args.steps * world)
-    launch_ms = stages[dominant] / launches
-    achieved = ALGO_BYTES_PER_BASE * (bases_per_step_rank0 / launches) / (launch_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
     if os.path.isfile(tfile):
@@ -261,16 +282,16 @@ def main():
                    'parallelism': f'reads sharded by index over {world} GPU(s), reference replicated, no collectives'},
         'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'algorithmic_bytes_per_launch': ALGO_BYTES_PER_BASE * bases_per_step_rank0 / launches,
+                     'algorithmic_bytes_per_launch': algo_bytes, 'bases_per_launch': g1_bases_per_step / launches,
                      'launch_ms': launch_ms, 'launches_per_step': launches,
                      'note': 'integer-ALU / latency bound path: see DESIGN.md section 5; launch_ms is the HIP-event '
                              'duration of one launch while other batches share the GPU'},
-        'stage_ms_per_step': stages,
+        'stage_ms_per_step': stages, 'mutate_passes_per_step': sum(a['passes'] for a in acc) / args.steps,
     }
     if d2h is not None:
         result['value_incl_d2h'] = d2h
     if world == 1 and args.cpu_seconds > 0:
-        result['cpu_baseline'] = cpu_baseline(wl, 10_000_000, args.cpu_seconds)
+        result['cpu_baseline'] = cpu_baseline(10_000_000, args.cpu_seconds)
         result['gpu_over_cpu'] = value / result['cpu_baseline']['value']
     else:
         result['cpu_baseline'] = None
