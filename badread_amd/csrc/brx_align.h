@@ -433,10 +433,10 @@ __device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32
  * Register use grows with it (7 VGPRs per word), so kernels that only ever meet narrow bands are
  * instantiated with a small MAXG and run at a higher occupancy; geometries above MAXG take the
  * slow memory-resident path below (correct, rare). */
-template <int MAXG>
+template <int MAXG, int MING = 1>
 __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *Ts, const BrxGeom &g, uint2 *tb,
                                              uint32_t *prog = nullptr) {
-    if (g.G > MAXG) {
+    if (g.G > MAXG || g.G < MING) {
         uint32_t *peq = reinterpret_cast<uint32_t *>(tb + brx_tb_units(g));
         uint2 *st = tb + brx_tb_units(g) + ((uint64_t)5 * (uint64_t)g.NW * 4 + 7) / 8;
         brx_build_peq(Qs, g, peq);
@@ -445,16 +445,16 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
         brx_align_forward_wide(Qs, Ts, g, tb, peq, st);
         return;
     }
-    if (g.G == 1) { brx_align_forward<1>(Qs, Ts, g, tb, prog); return; }
-    if constexpr (MAXG >= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 16) { if (g.G == 16) { brx_align_forward<16>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward<1>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 16 && MING <= 16) { if (g.G == 16) { brx_align_forward<16>(Qs, Ts, g, tb, prog); return; } }
 }
 
 /* Full alignment with a given band bound k.  Returns false if the band was too narrow.
  * Handles empty inputs.  All lanes of the wave must call; results are wave-uniform. */
-template <int MAXG = 16>
+template <int MAXG = 16, int MING = 1>
 __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *Ts, int T, int k,
                                       uint2 *tb, uint64_t tb_cap_units, uint8_t *ops_end,
                                       int *n_cols, int *n_match, bool *no_space, uint32_t *prog = nullptr,
@@ -474,7 +474,7 @@ __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *T
     BRX_PROG(prog, 3, 1);
     BRX_PROG(prog, 6, (uint32_t)g.t_end);
     const uint64_t c0 = __builtin_amdgcn_s_memtime();
-    brx_align_forward_any<MAXG>(Qs, Ts, g, tb, prog);
+    brx_align_forward_any<MAXG, MING>(Qs, Ts, g, tb, prog);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);      /* stores of this wave visible to its own later loads */
     BRX_PROG(prog, 3, 2);

@@ -38,6 +38,8 @@ struct brx_ctx {
     hipEvent_t ev_b[BRX_STAGE_COUNT], ev_e[BRX_STAGE_COUNT];   /* begin / end of each stage on the launch stream */
     float stage_ms[BRX_STAGE_COUNT];
     uint32_t final_launches, mutate_passes;
+    int mutate_inline;
+    uint32_t lane_threshold;
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one */
     hipEvent_t ev_a1b[BRX_MAX_CHUNKS], ev_a1e[BRX_MAX_CHUNKS];   /* k_fin_align<1,1,1> of every scratch chunk */
     hipEvent_t ev_qsb[BRX_MAX_CHUNKS], ev_qse[BRX_MAX_CHUNKS];   /* k_fin_qscore of every scratch chunk      */
@@ -126,6 +128,8 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
+    { const char *lt = getenv("BRX_LANE_THRESHOLD"); c->lane_threshold = lt ? (uint32_t)atoi(lt) : 3000u; }
     c->err[0] = 0;
     *out = c;
     return BRX_OK;
@@ -236,12 +240,12 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     RS *rs = (RS *)A.take((size_t)n_reads * sizeof(RS));
     uint64_t *totals = (uint64_t *)A.take(16 * sizeof(uint64_t));
     uint32_t *order = (uint32_t *)A.take((size_t)n_reads * 4);
-    uint32_t *counters = (uint32_t *)A.take(256 * 4);       /* [0] unused, [1] flags, [2..] final-stage queues (4 per chunk) */
+    uint32_t *counters = (uint32_t *)A.take(512 * 4);       /* [0] unused, [1] flags, [2..] final-stage queues (6 per chunk) */
     uint64_t *units_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *tboff_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *clk = (uint64_t *)A.take((size_t)n_reads * 64);     /* per-read cycle counters, brx_last_read_cycles() */
     if (!A.ok()) return scratch_short(c, A.used + (size_t)n_reads * 200000);
-    HIPCHK(c, hipMemsetAsync(counters, 0, 256 * 4, st));
+    HIPCHK(c, hipMemsetAsync(counters, 0, 512 * 4, st));
     HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, st));
     HIPCHK(c, hipMemsetAsync(clk, 0, (size_t)n_reads * 64, st));
     c->d_clk = clk; c->clk_reads = n_reads;
@@ -296,8 +300,10 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         const uint32_t *n_in = mctr + 2 * MC_WORDS + MC_OUT;
         const uint32_t *act_in = order;
         uint32_t n_up = n_reads, pass = 0;
-        const uint32_t lane_threshold = 6144;      /* fewer active reads than this: one wave per window (lower latency) */
-        const uint32_t tail_reads = 48;            /* this few reads left: run them to completion on the GPU            */
+        const uint32_t lane_threshold = c->lane_threshold;   /* fewer active reads than this: one wave per window (lower latency) */
+        /* this few reads left: run them to completion on the GPU, aligning in place (no host round trips).
+           BRX_MUTATE_INLINE=1 does that for the whole batch: one launch, no passes. */
+        const uint32_t tail_reads = c->mutate_inline ? 0xFFFFFFFFu : 48u;
         auto read_counts = [&](uint32_t *ctr) -> int {
             HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             return wait_stream(c, st, "mutate pass");
@@ -307,7 +313,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             uint32_t *act_out = (pass & 1u) ? active_b : active_a;
             HIPCHK(c, hipMemsetAsync(ctr, 0, MC_WORDS * sizeof(uint32_t), st));
             if (n_up <= tail_reads) {
-                hipLaunchKernelGGL((k_mutate_seg<true>), dim3(n_up), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out, ctr,
+                hipLaunchKernelGGL((k_mutate_seg<true>), dim3(std::min(n_up, side_waves)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out, ctr,
                                    req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                    win, (uint64_t)c->win_bytes, counters + 1);
                 rc = read_counts(ctr);
@@ -402,18 +408,20 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         /* wide reads are few but long: start them first on the side stream, narrow ones fill the rest of the chip */
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        hipLaunchKernelGGL((k_fin_align<16, 4, 64>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, c->side,
-                           dev, rs, order, b, e, counters + 2 + 4 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+        hipLaunchKernelGGL((k_fin_align<16, 8, 64>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, c->side,
+                           dev, rs, order, b, e, counters + 2 + 6 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+        hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, c->side,
+                           dev, rs, order, b, e, counters + 6 + 6 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, c->side,
-                           dev, rs, order, b, e, counters + 3 + 4 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+                           dev, rs, order, b, e, counters + 3 + 6 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
         HIPCHK(c, hipEventRecord(c->ev_a1b[ci], st));
-        hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 4 + 4 * ci,
+        hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 4 + 6 * ci,
                            Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         HIPCHK(c, hipEventRecord(c->ev_a1e[ci], st));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
         HIPCHK(c, hipEventRecord(c->ev_qsb[ci], st));
-        hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 5 + 4 * ci,
+        hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 5 + 6 * ci,
                            seqbuf, opsbuf, tb_base, clk);
         HIPCHK(c, hipEventRecord(c->ev_qse[ci], st));
     }

@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(64) k_fin_align(BrxDev d, RS *rs, const uint32
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         int ncols = 0, nmatch = 0; bool nospace = false;
-        const bool ok = brx_wave_align<MAXG>(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch,
+        const bool ok = brx_wave_align<MAXG, (GLO < MAXG ? GLO : MAXG)>(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch,
                                              &nospace, nullptr, aclk);
         if (lane == 0) {
             RS *o = &rs[r];

@@ -53,7 +53,7 @@ enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WOR
  * wave-systolic aligner and run every read to completion (the last few reads of a batch, where a
  * host round trip per alignment would cost more than the alignment). */
 template <bool INLINE>
-__global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
+__global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
                                                     const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,
                                                     uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
                                                     const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk,
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, co
         const RS s = rs[r];
         if (s.n == 0) continue;
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
-        const MS ms = msv[r];
+        MS ms = msv[r];
         const uint64_t read = d.first_read + r;
         const uint32_t n = s.n;
         const uint8_t *F = Fbuf + s.F_off;
@@ -83,8 +83,13 @@ __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, co
         double errors = 0.0;
         uint64_t loops = 0;
         uint32_t change = 0, nalign = 0;
-        bool resume = ms.phase == 1u;
         uint32_t st_extra = ms.status;
+        bool parked = false;
+      for (;;) {                                   /* INLINE: one trip per alignment of this read */
+        errors = 0.0; loops = 0; change = 0; nalign = 0;
+        bool resume = ms.phase == 1u;
+        st_extra = ms.status;
+        parked = false;
         if (resume) {
             errors = ms.errors; loops = ms.round_loops; change = ms.change; nalign = ms.nalign;
             const double id = ms.res_ncols ? (double)ms.res_nmatch / (double)ms.res_ncols : 0.0;     /* misc.py:228-240 */
@@ -96,7 +101,6 @@ __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, co
             }
         }
         bool done = !resume && need < 0.5;
-        bool parked = false;
         while (!done) {
             double est;
             if (resume) est = ms.est;
@@ -174,40 +178,28 @@ __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, co
                             wave_join(em, F, rp, a, b, tbuf, nullptr);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             __builtin_amdgcn_s_waitcnt(0);
-                            if constexpr (INLINE) {
-                                uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)blockIdx.x * scr_bytes);
-                                int ncols = 0, nmatch = 0; bool nospace = false;
-                                const bool ok = brx_wave_align<1>(qb, (int)ql, tbuf, (int)tl, (int)cost, tb, scr_bytes / 8, nullptr,
-                                                                  &ncols, &nmatch, &nospace);
-                                if (!ok && !nospace) st_extra |= BRX_RS_BAND;
-                                if (nospace && lane == 0) atomicOr(&flags[0], 1u);
-                                const double id = ncols ? (double)nmatch / (double)ncols : 0.0;
-                                if (n <= BRX_ALIGN_SIZE) errors = (1.0 - id) * dn;
-                                else {
-                                    const double est_err = (1.0 - id) * dn;
-                                    const double weight = (double)BRX_ALIGN_SIZE / dn;
-                                    errors = est_err * weight + errors * (1.0 - weight);
-                                }
-                                continue;                           /* next position of this k-mer */
-                            }
                             for (uint32_t x = lane; x < tl; x += 64) odd |= tbuf[x] > 3;
                             const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
                             const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
-                            const bool easy = __ballot(odd) == 0ull && g.G == 1 && band_blocks <= BRX_LANE_W &&
+                            const bool easy = !INLINE && __ballot(odd) == 0ull && g.G == 1 && band_blocks <= BRX_LANE_W &&
                                               tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 && n_in > lane_threshold;
                             klass = easy ? MC_EASY : MC_HARD;
                         }
-                        if (lane == 0) {
+                        {
                             MS o = ms;
                             o.errors = errors; o.est = est; o.round_loops = loops; o.change = change; o.nalign = nalign;
                             o.phase = klass == MC_LEGACY ? 3u : 1u;
                             o.surv_lane = (uint32_t)l; o.j_next = (uint32_t)(j + 1);
                             o.win_a = a; o.win_b = b; o.tl = tl; o.cost = cost; o.res_ncols = 0; o.res_nmatch = 0;
                             o.passes = ms.passes + 1; o.status = st_extra;
-                            msv[r] = o;
-                            uint32_t *list = klass == MC_EASY ? req_easy : klass == MC_HARD ? req_hard : req_legacy;
-                            list[atomicAdd(klass == MC_LEGACY ? legacy_ctr : &ctr[klass], 1u)] = r;
-                            if (klass != MC_LEGACY) active_out[atomicAdd(&ctr[MC_OUT], 1u)] = r;
+                            if (INLINE && klass != MC_LEGACY) ms = o;          /* stays in registers: aligned below */
+                            else if (lane == 0) {
+                                msv[r] = o;
+                                uint32_t *list = klass == MC_EASY ? req_easy : klass == MC_HARD ? req_hard : req_legacy;
+                                list[atomicAdd(klass == MC_LEGACY ? legacy_ctr : &ctr[klass], 1u)] = r;
+                                if (klass != MC_LEGACY) active_out[atomicAdd(&ctr[MC_OUT], 1u)] = r;
+                            }
+                            if (klass == MC_LEGACY) ms.phase = 3u;
                         }
                         parked = true;
                         break;
@@ -224,6 +216,20 @@ __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, co
             loops += B;
             if (B < 64) { loops += 1; break; }
         }
+        if (INLINE && parked && ms.phase == 1u) {
+            /* align the parked window here, at the top level where only MS is live, and resume the same read */
+            const uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+            uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)blockIdx.x * scr_bytes);
+            int ncols = 0, nmatch = 0; bool nospace = false;
+            const bool ok = brx_wave_align<1>(qb, (int)(ms.win_b - ms.win_a), tbuf, (int)ms.tl, (int)ms.cost, tb, scr_bytes / 8, nullptr,
+                                              &ncols, &nmatch, &nospace);
+            ms.res_ncols = (uint32_t)ncols; ms.res_nmatch = (uint32_t)nmatch;
+            if (!ok && !nospace) ms.status |= BRX_RS_BAND;
+            if (nospace && lane == 0) atomicOr(&flags[0], 1u);
+            continue;
+        }
+        break;
+      }
         uint64_t *ck = clk + (uint64_t)r * 8;
         if (parked) {
             if (lane == 0) ck[0] += __builtin_amdgcn_s_memtime() - t_begin;
@@ -245,7 +251,7 @@ __global__ void __launch_bounds__(64) k_mutate_seg(BrxDev d, RS *rs, MS *msv, co
             if (m && g.G == 0) { o->status |= BRX_RS_BAND; units = 0; }
             o->units = units + ((uint64_t)m * 4 + 7) / 8 + 2;     /* + col_of[] for the qscore stage */
             msv[r].phase = 2u;
-            ck[0] += __builtin_amdgcn_s_memtime() - t_begin; ck[1] = ms.passes;
+            ck[0] += __builtin_amdgcn_s_memtime() - t_begin; ck[1] = INLINE ? nalign : ms.passes;
         }
     }
 }

@@ -1,0 +1,68 @@
+"""
+GPU end-to-end: the `badread simulate` command line (python -m badread_amd simulate ...) on the HIP path
+against the same driver run on the CPU oracle engine: stdout bytes identical, banner on stderr, and the
+documented behaviours of the reference CLI (FASTQ only on stdout, seed determinism, test/test_simulate2.py:160-177).
+"""
+import io
+import os
+import subprocess
+import sys
+
+import pytest
+
+import helpers as H
+from badread_amd import simulate as S
+from test_host_simulate import Args, parse_fastq
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+SMALL_REF = os.path.join(HERE, 'golden', 'small_ref.fasta')
+
+
+def run_cli(*extra):
+    cmd = [sys.executable, '-m', 'badread_amd', 'simulate', '--reference', SMALL_REF, '--quantity', '15x',
+           '--length', '400,300', '--seed', '11'] + list(extra)
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r.stdout, r.stderr.decode()
+
+
+def test_cli_matches_the_oracle_driver_and_is_deterministic():
+    out, err = run_cli()
+    recs = parse_fastq(out)
+    assert sum(len(r[1]) for r in recs) >= 15 * 3621
+    assert 'Badread v' in err and 'Target read set size: 54,315 bp' in err and b'Badread' not in out
+    out2, _ = run_cli()
+    assert out == out2
+    args = Args(quantity='15x', mean_frag_length=400.0, frag_length_stdev=300.0, mean_identity=95.0, max_identity=99.0,
+                identity_stdev=2.5, error_model='nanopore2023', qscore_model='nanopore2023', seed=11,
+                junk_reads=1, random_reads=1, chimeras=1)
+    sink = io.BytesIO()
+    S.simulate(args, output=io.StringIO(), engine=H.oracle_engine(), stdout=sink, shard=S.Shard())
+    assert sink.getvalue() == out
+
+
+def test_cli_models_and_identity_modes():
+    out, _ = run_cli('--error_model', 'random', '--qscore_model', 'ideal', '--identity', '20,3', '--glitches', '0,0,0',
+                     '--start_adapter_seq', '', '--end_adapter_seq', '')
+    assert len(parse_fastq(out)) > 10
+    out, _ = run_cli('--error_model', 'pacbio2021', '--qscore_model', 'pacbio2021', '--identity', '30,3')
+    assert len(parse_fastq(out)) > 10
+
+
+def test_sequence_fragment_drop_in():
+    import random
+    from badread_amd.error_model import ErrorModel
+    from badread_amd.qscore_model import QScoreModel
+    em, qm = ErrorModel('nanopore2023', io.StringIO()), QScoreModel('nanopore2023', io.StringIO())
+    random.seed(5)
+    frag = ''.join(random.choice('ACGT') for _ in range(3000))
+    seq, quals, identity, by_q = S.sequence_fragment(frag, 1.0, em, qm)
+    assert seq == frag and len(quals) == len(seq) and identity == 1.0          # test/test_simulate.py:45-51
+    random.seed(6)
+    a = S.sequence_fragment(frag, 0.9, em, qm)
+    random.seed(6)
+    b = S.sequence_fragment(frag, 0.9, em, qm)
+    assert a == b and a[0] != frag and abs(a[2] - 0.9) < 0.05 and 0.0 < a[3] < 1.0
+    assert S.sequence_fragment('', 0.9, em, qm) == ('', '', 0.0, 0.0)
