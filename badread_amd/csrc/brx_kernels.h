@@ -472,8 +472,10 @@ __device__ inline bool dev_choose_alt(const brx_error_model &em, const uint8_t *
     if (w2 < st) return false;                                   /* the common case: unchanged */
     uint32_t a0 = em.d_row_off[row], a1 = em.d_row_off[row + 1];
     if (a0 == a1) { dev_random_change(kmer, k, w3, rep); return true; }
-    uint32_t a = a0;
-    while (a < a1 && !(w2 < em.d_thr[a])) ++a;
+    /* first alternative whose cumulative threshold exceeds the draw (thresholds are non-decreasing):
+       binary search -- the linear walk of up to 26 dependent loads dominated the proposal rounds */
+    uint32_t a = a0, hi_ = a1;
+    while (a < hi_) { const uint32_t mid = (a + hi_) >> 1; if (w2 < em.d_thr[mid]) hi_ = mid; else a = mid + 1; }
     if (a == a1) {
         if (em.d_thr[a1 - 1] == 0xFFFFFFFFu) a = a1 - 1;
         else { dev_random_change(kmer, k, w3, rep); return true; }
@@ -850,8 +852,10 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
                     uint32_t w4[4];
                     brx_draw4(d.seed, read, BRX_ST_QS, (uint64_t)(sp >> 2), w4);
                     uint32_t u = w4[sp & 3];
-                    uint32_t e = e0;
-                    while (e < e1 - 1 && !(u < qm.d_thr[e])) ++e;
+                    /* first entry whose cumulative threshold exceeds the draw, else the last one: binary
+                       search over the row (rows hold up to ~90 scores; thresholds are non-decreasing) */
+                    uint32_t e = e0, hi_ = e1 - 1;
+                    while (e < hi_) { const uint32_t mid = (e + hi_) >> 1; if (u < qm.d_thr[mid]) hi_ = mid; else e = mid + 1; }
                     score = qm.d_score[e]; found = true;
                     break;
                 }

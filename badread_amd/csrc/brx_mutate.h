@@ -137,16 +137,22 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
                 surv &= surv - 1;
                 const uint64_t i0 = wave_bcast_u64(ipos, l);
                 const double scale = est * brx_sqrt(est);
-                for (int j = first ? j0 : 0; j < k; ++j) {
-                    uint32_t mine = 0;
+                /* lane j < k takes position j of the k-mer: its replacement word from the proposing lane and
+                   the current state of that position with ONE load for all positions, then the untouched,
+                   changed positions (simulate.py:309) are applied in order */
+                uint32_t wj = 0;
 #pragma unroll
-                    for (int jj = 0; jj < 16; ++jj) mine = (jj == j) ? rep[jj] : mine;
-                    const uint32_t w = wave_bcast_u32(mine, l);
-                    if (!w) continue;
-                    const uint64_t pos = i0 + (uint64_t)j;
-                    const uint32_t cur = rp[pos];
-                    if (cur) continue;
-                    if (lane == 0) rp[pos] = w;
+                for (int jj = 0; jj < 16; ++jj) {
+                    if (jj < k) { const uint32_t v = wave_bcast_u32(rep[jj], l); wj = (lane == jj) ? v : wj; }
+                }
+                const uint32_t curj = lane < k ? rp[i0 + (uint64_t)lane] : 1u;
+                unsigned long long todo = __ballot(lane < k && wj != 0u && curj == 0u);
+                if (first) todo &= ~((1ull << j0) - 1ull);
+                while (todo) {
+                    const int j = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const uint32_t w = wave_bcast_u32(wj, j);
+                    if (lane == j) rp[i0 + (uint64_t)j] = w;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     change += 1;
                     const uint32_t len = (w >> 24) & 0x7Fu;
