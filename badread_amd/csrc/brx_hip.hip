@@ -240,12 +240,12 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     RS *rs = (RS *)A.take((size_t)n_reads * sizeof(RS));
     uint64_t *totals = (uint64_t *)A.take(16 * sizeof(uint64_t));
     uint32_t *order = (uint32_t *)A.take((size_t)n_reads * 4);
-    uint32_t *counters = (uint32_t *)A.take(512 * 4);       /* [0] unused, [1] flags, [2..] final-stage queues (6 per chunk) */
+    uint32_t *counters = (uint32_t *)A.take(1024 * 4);      /* [0] join queue, [1] flags, [2..] final-stage queues and list sizes (8 per chunk, from word 2 and 8) */
     uint64_t *units_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *tboff_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *clk = (uint64_t *)A.take((size_t)n_reads * 64);     /* per-read cycle counters, brx_last_read_cycles() */
     if (!A.ok()) return scratch_short(c, A.used + (size_t)n_reads * 200000);
-    HIPCHK(c, hipMemsetAsync(counters, 0, 512 * 4, st));
+    HIPCHK(c, hipMemsetAsync(counters, 0, 1024 * 4, st));
     HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, st));
     HIPCHK(c, hipMemsetAsync(clk, 0, (size_t)n_reads * 64, st));
     c->d_clk = clk; c->clk_reads = n_reads;
@@ -366,9 +366,15 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     const uint64_t seq_bytes = c->h_totals[3], ops_bytes = c->h_totals[4];
     uint8_t *seqbuf = (uint8_t *)A.take((size_t)seq_bytes + 64);
     uint8_t *opsbuf = (uint8_t *)A.take((size_t)ops_bytes + 64);
+    uint2 *qplanes = (uint2 *)A.take(((size_t)(seq_bytes >> 4) + 64) * sizeof(uint2));     /* query bit planes, k_fin_join */
+    uint32_t *lane_list32 = (uint32_t *)A.take((size_t)n_reads * 4);
+    uint32_t *lane_list64 = (uint32_t *)A.take((size_t)n_reads * 4);
     if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
 
     /* ---- stage: final alignment + qscores, in chunks that fit the remaining arena ---- */
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_FINAL], st));
+    hipLaunchKernelGGL(k_fin_join, dim3(std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 16u)), dim3(64), 0, st, dev, rs, counters + 0,
+                       Fbuf, repl, seqbuf, qplanes);
     std::vector<uint32_t> h_order(n_reads);
     std::vector<RS> h_rs(n_reads);
     HIPCHK(c, hipMemcpyAsync(h_order.data(), order, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
@@ -399,29 +405,36 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     HIPCHK(c, hipMemcpyAsync(tboff_sorted, h_tboff.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, st));
     (void)units_sorted;
     hipLaunchKernelGGL(k_set_tboff, dim3(nb64), dim3(64), 0, st, n_reads, rs, order, tboff_sorted);
-    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_FINAL], st));
     if (chunks.size() > 60) return scratch_short(c, tb_at + (size_t)std::min<uint64_t>((sum_units + 64ull * n_reads) * 8 / 8 + 1, (uint64_t)64 << 30));
     for (size_t ci = 0; ci < chunks.size(); ++ci) {
         uint32_t b = chunks[ci].first, e = chunks[ci].second;
         if (e == b) continue;
         uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
+        uint32_t *cq = counters + 16 + 16 * ci;               /* this chunk's queue heads and list sizes */
         /* wide reads are few but long: start them first on the side stream, narrow ones fill the rest of the chip */
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
         hipLaunchKernelGGL((k_fin_align<16, 8, 64>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, c->side,
-                           dev, rs, order, b, e, counters + 2 + 6 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+                           dev, rs, order, b, e, cq + 0, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, c->side,
-                           dev, rs, order, b, e, counters + 6 + 6 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+                           dev, rs, order, b, e, cq + 4, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, c->side,
-                           dev, rs, order, b, e, counters + 3 + 6 * ci, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+                           dev, rs, order, b, e, cq + 1, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+        /* lane-per-read classes: lists of this chunk, then 64 reads per wave */
+        hipLaunchKernelGGL(k_class_list, dim3(1), dim3(64), 0, st, rs, order, b, e, BRX_KL_LANE32, lane_list32, cq + 5);
+        hipLaunchKernelGGL(k_class_list, dim3(1), dim3(64), 0, st, rs, order, b, e, BRX_KL_LANE64, lane_list64, cq + 6);
         HIPCHK(c, hipEventRecord(c->ev_a1b[ci], st));
-        hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 4 + 6 * ci,
-                           Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+        hipLaunchKernelGGL((k_fin_lane<32>), dim3(std::min<uint32_t>((e - b + 63) / 64, (uint32_t)c->n_cu * 4u)), dim3(64), 0, st,
+                           rs, lane_list32, cq + 5, cq + 7, Fbuf, seqbuf, qplanes, opsbuf, tb_base, clk);
         HIPCHK(c, hipEventRecord(c->ev_a1e[ci], st));
+        hipLaunchKernelGGL((k_fin_lane<64>), dim3(std::min<uint32_t>((e - b + 63) / 64, (uint32_t)c->n_cu * 2u)), dim3(64), 0, st,
+                           rs, lane_list64, cq + 6, cq + 8, Fbuf, seqbuf, qplanes, opsbuf, tb_base, clk);
+        hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, cq + 2,
+                           Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
         HIPCHK(c, hipEventRecord(c->ev_qsb[ci], st));
-        hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, counters + 5 + 6 * ci,
+        hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, cq + 3,
                            seqbuf, opsbuf, tb_base, clk);
         HIPCHK(c, hipEventRecord(c->ev_qse[ci], st));
     }

@@ -38,7 +38,7 @@ struct RS {
     uint32_t n, m, ub, start_trim;
     uint32_t end_trim, seg_off, piece_off, n_cols;
     uint32_t n_match, loops, changes, naligns;
-    uint32_t seq_len, rec_len, hdr_len, pad_;
+    uint32_t seq_len, rec_len, hdr_len, klass;     /* klass: final-alignment class, set by k_fin_join (brx_finlane.h) */
     uint64_t F_off, seq_off, ops_off, units, tb_off, rec_off;
     double target, qerr;
 };
@@ -681,6 +681,7 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
 }
 
 #include "brx_mutate.h"
+#include "brx_finlane.h"
 
 /* offsets for the final stage.  totals: [3]=seq bytes [4]=ops bytes */
 __global__ void __launch_bounds__(64) k_scan_mut(uint32_t n_reads, RS *rs, uint64_t *totals) {
@@ -742,25 +743,15 @@ __global__ void __launch_bounds__(64) k_fin_align(BrxDev d, RS *rs, const uint32
         const uint32_t r = order[qi];
         const RS s = rs[r];
         if (s.n == 0) continue;
-        {
-            int G = s.m ? brx_make_geom((int)s.m, (int)s.n, (int)s.ub).G : 1;
-            if (G == 0) G = 64;                                  /* no geometry: the widest class reports the failure */
-            if (G < GLO || G > GHI) continue;
-        }
+        if ((int)s.klass < GLO || (int)s.klass > GHI) continue;           /* other band class, or a lane-aligned read */
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
         uint64_t aclk[2] = {0, 0};
         const uint32_t n = s.n, m = s.m;
         const uint8_t *F = Fbuf + s.F_off;
-        const uint32_t *rp = repl + s.F_off;
-        uint8_t *seq = seqbuf + s.seq_off;
+        uint8_t *seq = seqbuf + s.seq_off;                                 /* joined and padded by k_fin_join */
         uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
         uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
         const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
-
-        wave_join(em, F, rp, 0, n, seq, nullptr);
-        for (uint32_t x = lane; x < 16; x += 64) seq[m + x] = 0xFE;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
         int ncols = 0, nmatch = 0; bool nospace = false;
         const bool ok = brx_wave_align<MAXG, (GLO < MAXG ? GLO : MAXG)>(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch,
                                              &nospace, nullptr, aclk);
