@@ -16,6 +16,11 @@
  *
  * Classes (RS.klass, set by k_fin_join): BRX_KL_LANE32 / BRX_KL_LANE64 = pure ACGT pairs whose band spans
  * at most 30 / 62 blocks; everything else keeps the wave-systolic kernels (klass = words per lane).
+ *
+ * Measured (profiles/README.md, r01c): 8x fewer wave-cycles per read than the wave-systolic kernel, but
+ * 36 KB of LDS per wave admit only 4 waves per CU against 20 for k_fin_align<1,1,1>, and a batch of 16 k
+ * reads is only 256 such waves -- the launch becomes a handful of very long waves.  It is therefore OFF by
+ * default (BRX_FIN_LANE=1 enables it); it pays once >= ~100 k reads are in flight per GPU.
  */
 #ifndef BRX_FINLANE_H
 #define BRX_FINLANE_H
@@ -31,7 +36,7 @@ __host__ __device__ inline uint64_t brx_lane_units(int T, int band_blocks) { ret
  * k_fin_join: one wave per read.  join(new_fragment_bases) -> seq (+ pad), class of the read, planes.
  * ----------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, uint32_t *queue, const uint8_t *Fbuf, const uint32_t *repl,
-                                                  uint8_t *seqbuf, uint2 *qplanes) {
+                                                  uint8_t *seqbuf, uint2 *qplanes, int lane_classes) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     for (;;) {
@@ -52,7 +57,7 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, uint32_t *que
         for (uint32_t x = lane; x < m; x += 64) odd |= seq[x] > 3;
         const BrxGeom g = brx_make_geom((int)m, (int)n, (int)s.ub);
         uint32_t klass = g.G ? (uint32_t)g.G : 64u;
-        if (__ballot(odd) == 0ull && g.G != 0 && m > 0 && n > 0) {
+        if (lane_classes && __ballot(odd) == 0ull && g.G != 0 && m > 0 && n > 0) {
             const int bb = brx_band_blocks(g);
             if (bb <= 30) klass = BRX_KL_LANE32;
             else if (bb <= 62) klass = BRX_KL_LANE64;

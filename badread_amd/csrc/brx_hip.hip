@@ -38,7 +38,7 @@ struct brx_ctx {
     hipEvent_t ev_b[BRX_STAGE_COUNT], ev_e[BRX_STAGE_COUNT];   /* begin / end of each stage on the launch stream */
     float stage_ms[BRX_STAGE_COUNT];
     uint32_t final_launches, mutate_passes;
-    int mutate_inline;
+    int mutate_inline, fin_lane;
     uint32_t lane_threshold;
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one */
     hipEvent_t ev_a1b[BRX_MAX_CHUNKS], ev_a1e[BRX_MAX_CHUNKS];   /* k_fin_align<1,1,1> of every scratch chunk */
@@ -129,6 +129,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
+    { const char *fl = getenv("BRX_FIN_LANE"); c->fin_lane = (fl && atoi(fl)) ? 1 : 0; }
     { const char *lt = getenv("BRX_LANE_THRESHOLD"); c->lane_threshold = lt ? (uint32_t)atoi(lt) : 3000u; }
     c->err[0] = 0;
     *out = c;
@@ -374,7 +375,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     /* ---- stage: final alignment + qscores, in chunks that fit the remaining arena ---- */
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_FINAL], st));
     hipLaunchKernelGGL(k_fin_join, dim3(std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 16u)), dim3(64), 0, st, dev, rs, counters + 0,
-                       Fbuf, repl, seqbuf, qplanes);
+                       Fbuf, repl, seqbuf, qplanes, c->fin_lane);
     std::vector<uint32_t> h_order(n_reads);
     std::vector<RS> h_rs(n_reads);
     HIPCHK(c, hipMemcpyAsync(h_order.data(), order, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
@@ -422,6 +423,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
                            dev, rs, order, b, e, cq + 1, Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side));
         /* lane-per-read classes: lists of this chunk, then 64 reads per wave */
+        if (c->fin_lane) {
         hipLaunchKernelGGL(k_class_list, dim3(1), dim3(64), 0, st, rs, order, b, e, BRX_KL_LANE32, lane_list32, cq + 5);
         hipLaunchKernelGGL(k_class_list, dim3(1), dim3(64), 0, st, rs, order, b, e, BRX_KL_LANE64, lane_list64, cq + 6);
         HIPCHK(c, hipEventRecord(c->ev_a1b[ci], st));
@@ -430,8 +432,11 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         HIPCHK(c, hipEventRecord(c->ev_a1e[ci], st));
         hipLaunchKernelGGL((k_fin_lane<64>), dim3(std::min<uint32_t>((e - b + 63) / 64, (uint32_t)c->n_cu * 2u)), dim3(64), 0, st,
                            rs, lane_list64, cq + 6, cq + 8, Fbuf, seqbuf, qplanes, opsbuf, tb_base, clk);
+        }
+        if (!c->fin_lane) HIPCHK(c, hipEventRecord(c->ev_a1b[ci], st));
         hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, cq + 2,
                            Fbuf, repl, seqbuf, opsbuf, tb_base, clk);
+        if (!c->fin_lane) HIPCHK(c, hipEventRecord(c->ev_a1e[ci], st));
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
         HIPCHK(c, hipEventRecord(c->ev_qsb[ci], st));
         hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, cq + 3,

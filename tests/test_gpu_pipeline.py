@@ -83,3 +83,23 @@ def test_sequence_fragments_matches_oracle():
         assert (st_h[f] == st_o[f]).all(), f
     # identity 1.0 returns the fragment untouched (test_simulate.py:45-51)
     assert H.first_diff(res_h[0][0], frags[0]) < 0
+
+
+@pytest.mark.parametrize('env', [{'BRX_FIN_LANE': '1'}, {'BRX_MUTATE_INLINE': '1'}, {'BRX_LANE_THRESHOLD': '0'},
+                                 {'BRX_LANE_THRESHOLD': '1000000'}])
+def test_alternative_kernel_routes_give_the_same_bytes(env, monkeypatch):
+    """The optional routes (lane-per-read final aligner, in-place mutate alignments, lane- or wave-per-window for
+    every pass) are read from the environment when a context is created; all must reproduce the oracle."""
+    from badread_amd.engine import HipEngine
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pref, _ = H.small_reference()
+    p = SimParams(frag_mean=5000, frag_stdev=4500)
+    eng = H.configure(HipEngine(0, scratch_bytes=2 << 30), pref, 'nanopore2023', 'nanopore2023', p)
+    orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
+    out_h, st_h = eng.simulate_batch(21, 0, 300)
+    out_o, st_o = orc.simulate_batch(21, 0, 300)
+    for f in STAT_FIELDS:
+        assert (st_h[f] == st_o[f]).all(), f
+    assert H.first_diff(out_h, out_o) < 0
+    eng.close()
