@@ -32,6 +32,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #define BRX_OP_EQ 0
 #define BRX_OP_X 1
@@ -50,7 +51,9 @@ struct BrxGeom {
     int G, R;          /* words per lane, rows per superblock (32*G)              */
     int NS, NW;        /* superblocks, 32-row words                               */
     int WSp;           /* band slots per time step in the traceback store         */
-    int t_end;         /* last time step = T + NS - 1                             */
+    int K;             /* time skew between neighbouring superblocks: superblock s handles column j at
+                          time j + K*s.  K = 4 for G = 1 (four columns per loop trip), else 1            */
+    int t_end;         /* last traceback row = T + K*(NS - 1)                      */
 };
 
 /* k must be >= |Q-T|.  Returns G = 0 if the band is wider than 64 lanes x 32 words can hold. */
@@ -66,14 +69,15 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k) {
     int bw = g.dhi - g.dlo + 1;
     int G = 1;
     while (G <= 32 && bw > 56 * 32 * G) G *= 2;
-    if (G > 32) { g.G = 0; g.R = 0; g.NS = 0; g.NW = 0; g.WSp = 0; g.t_end = 0; return g; }
+    if (G > 32) { g.G = 0; g.R = 0; g.NS = 0; g.NW = 0; g.WSp = 0; g.K = 1; g.t_end = 0; return g; }
     g.G = G; g.R = 32 * G;
     g.NW = (Q + 31) / 32;
     g.NS = (Q + g.R - 1) / g.R;
     g.WSp = (bw + g.R - 2) / (g.R + 1) + 2;
     if (g.WSp > g.NS) g.WSp = g.NS;
     if (g.WSp < 1) g.WSp = 1;
-    g.t_end = T + g.NS - 1;
+    g.K = G == 1 ? 4 : 1;
+    g.t_end = T + g.K * (g.NS - 1);
     return g;
 }
 
@@ -119,7 +123,7 @@ __device__ __forceinline__ int brx_from_lane_above(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
 }
 
-#define BRX_RING_BYTES 512          /* per-wave LDS window of target bytes (two 256-byte halves) */
+#define BRX_RING_BYTES 1024         /* per-wave LDS window of target bytes (four 256-byte chunks)  */
 /* One wave per workgroup, so one window per workgroup.  File scope keeps the LDS address space
  * visible to the compiler (ds_read_u8 / ds_write_b32); a generic or volatile pointer to it turns
  * every access into a flat load that waits on vmcnt -- exactly what the window is there to avoid. */
@@ -169,7 +173,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
     }
     uint32_t carry = 0;
 
-    /* target window: chunk c = target bytes [256c, 256c+256) lives in ring half c & 1; `odd` remembers
+    /* target window: chunk c = target bytes [256c, 256c+256) lives in half c & 1 of the first 512 ring bytes; `odd` remembers
        which halves hold a symbol outside A,C,G,T,N (IUPAC codes: slow equality path) */
     auto fetch_chunk = [&](int c) -> uint32_t {
         const int idx = 256 * c + 4 * lane;
@@ -190,7 +194,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
     odd |= chunk_odd(1, pending) << 1;
     int s_top = 0;                                   /* first superblock still inside the band (wave-uniform) */
     int t_top = brx_jlast(g, 0) + 1;                 /* time step at which s_top leaves the band              */
-    uint32_t cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(0 - s) & (BRX_RING_BYTES - 1)];   /* column 1 - s */
+    uint32_t cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(0 - s) & 511u];   /* column 1 - s */
     int next_entry = brx_wave_min(tf);               /* next time step at which some lane's superblock enters */
     int next_hop = brx_wave_min(tl);                 /* ... or leaves the band                                  */
 
@@ -290,7 +294,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
             next_hop = brx_wave_min(tl);
             next_entry = brx_wave_min(tf > t ? tf : NEVER);
         }
-        cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(t - s) & (BRX_RING_BYTES - 1)];   /* column t + 1 - s */
+        cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(t - s) & 511u];   /* column t + 1 - s */
     }
     (void)prog;
 }
@@ -320,7 +324,7 @@ __device__ inline bool brx_align_traceback(const uint8_t *__restrict__ Qs, const
             if (inband) {
                 int x = ((ci - 1) & (g.R - 1)) >> 5;
                 int bit = (ci - 1) & 31;
-                uint2 v = tb[((size_t)(cj + s) * (size_t)g.WSp + (size_t)(s % g.WSp)) * (size_t)g.G + (size_t)x];
+                uint2 v = tb[((size_t)(cj + g.K * s) * (size_t)g.WSp + (size_t)(s % g.WSp)) * (size_t)g.G + (size_t)x];
                 up = (v.x >> bit) & 1u;
                 left = (v.y >> bit) & 1u;
             }
@@ -429,6 +433,172 @@ __device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32
     }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * forward pass for G = 1, FOUR columns per loop trip (g.K = 4): superblock s handles columns
+ * 4(tau - s) + 1 .. 4(tau - s) + 4 in trip tau, so the lane above has finished exactly these four
+ * columns one trip earlier and hands its four carries over in one DPP word.  The loop bookkeeping
+ * (time tests, ring refill, lane hops, pointer arithmetic: ~40 of the ~85 instructions of a
+ * one-column trip) is paid once per four columns.  Traceback row of column j of superblock s is
+ * j + 4s = 4 tau + c + 1: the same for every lane of a trip, so the stores stay slot-contiguous.
+ * ------------------------------------------------------------------------------------------- */
+__device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
+                                            const BrxGeom g, uint2 *__restrict__ tb) {
+    const int lane = threadIdx.x & 63;
+    constexpr int NEVER = 0x7FFFFFFF;
+    constexpr int JNEVER = 0x3FFFFFFF;              /* `j - jf` must not overflow for the (negative) j of an idle lane */
+    constexpr int K = 4;
+    int s = lane;
+    int jf = JNEVER, jl = -1, slot = 0;              /* column window of the lane's current superblock */
+    int tf = NEVER, tl = NEVER;                     /* first / last loop trip of that window          */
+    if (s < g.NS) {
+        jf = brx_jfirst(g, s); jl = brx_jlast(g, s); slot = s % g.WSp;
+        tf = s + (jf - 1) / K; tl = s + (jl - 1) / K;
+        if (jl < jf) { tf = NEVER; }                /* empty window: never active, but it still hops at tl */
+    }
+    uint32_t Pv = 0xFFFFFFFFu, Mv = 0;
+    uint32_t pe0 = 0, pe1 = 0, pe2 = 0, pe3 = 0, pe4 = 0;
+    uint32_t carry = 0;                             /* 4 x 2 bits: 0 idle, 1/2/3 = hout -1/0/+1       */
+
+    auto fetch_chunk = [&](int c) -> uint32_t {
+        const int idx = 256 * c + 4 * lane;
+        return (idx + 4 <= g.T + 16) ? *reinterpret_cast<const uint32_t *>(Ts + idx) : 0xFEFEFEFEu;
+    };
+    auto chunk_odd = [&](int c, uint32_t v) -> uint32_t {
+        const int idx = 256 * c + 4 * lane;
+        bool o = false;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) o |= idx + b < g.T && ((v >> (8 * b)) & 0xFFu) > 4u;
+        return __ballot(o) != 0ull ? 1u : 0u;
+    };
+    uint32_t odd = 0, pending = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                   /* chunks 0..2; chunk c lives in ring quarter c & 3 */
+        pending = fetch_chunk(c);
+        brx_ring32[(c & 3) * 64 + lane] = pending;
+        odd |= chunk_odd(c, pending) << c;
+    }
+    int s_top = 0;                                  /* first superblock still inside the band (uniform) */
+    int tl_top = (brx_jlast(g, 0) - 1) / K;         /* its last trip                                     */
+    int next_entry = brx_wave_min(tf), next_hop = brx_wave_min(tl);
+    const int tau_end = (g.NS - 1) + (g.T - 1) / K;
+    const size_t trip_units = (size_t)K * (size_t)g.WSp;
+    uint2 *dst = tb + (size_t)1 * (size_t)g.WSp + (size_t)slot;          /* row 4 tau + 1, this lane's slot */
+    uint32_t wnext = brx_ring32[((uint32_t)(K * (0 - s)) >> 2) & (BRX_RING_BYTES / 4 - 1)];
+    for (int tau = 0; tau <= tau_end; ++tau, dst += trip_units) {
+        /* ---- refill of the target window, keyed on the newest byte in use (scalar code) ---- */
+        while (__builtin_expect(s_top < g.NS - 1 && tau > tl_top, 0)) { s_top += 1; tl_top = s_top + (brx_jlast(g, s_top) - 1) / K; }
+        const int fq = (tau - s_top);               /* newest column group in use: bytes 4 fq .. 4 fq + 3 */
+        if (__builtin_expect((fq & 15) == 0 && fq > 0, 0)) {
+            /* The band spans fewer than 62 superblocks, so the oldest byte still read is 4 (fq - 61):
+               when the front enters chunk m (fq = 64 m) chunk m - 2 is dead and chunk m + 2 takes its
+               quarter of the ring; its load was issued a quarter chunk earlier. */
+            const int ph = (fq >> 4) & 3;
+            if (ph == 3) pending = fetch_chunk((fq >> 6) + 3);
+            else if (ph == 0) {
+                const int c = (fq >> 6) + 2;
+                brx_ring32[(c & 3) * 64 + lane] = pending;
+                odd = (odd & ~(1u << (c & 3))) | (chunk_odd(c, pending) << (c & 3));
+            }
+        }
+
+        /* ---- a superblock enters the band: build its equality masks ---- */
+        if (__builtin_expect(tau == next_entry, 0)) {
+            if (tau == tf) {
+                Pv = 0xFFFFFFFFu; Mv = 0;                         /* cells below the band grow by +1 per row */
+                uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+                const uint32_t *q4 = reinterpret_cast<const uint32_t *>(Qs + 32 * s);
+#pragma unroll 1
+                for (int d = 0; d < 8; ++d) {
+                    const uint32_t v = q4[d];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t code = (v >> (8 * b)) & 0xFFu;
+                        const int r = 4 * d + b;
+                        const bool ok = (32 * s + r) < g.Q;
+                        m0 |= (uint32_t)(ok && code == 0) << r;
+                        m1 |= (uint32_t)(ok && code == 1) << r;
+                        m2 |= (uint32_t)(ok && code == 2) << r;
+                        m3 |= (uint32_t)(ok && code == 3) << r;
+                        m4 |= (uint32_t)(ok && code == 4) << r;
+                    }
+                }
+                pe0 = m0; pe1 = m1; pe2 = m2; pe3 = m3; pe4 = m4;
+            }
+            next_entry = brx_wave_min(tf > tau ? tf : NEVER);
+        }
+
+        /* ---- four column updates, straight-line ---- */
+        const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
+        const uint32_t w = wnext;
+        const int jb = K * (tau - s);                              /* columns jb + 1 .. jb + 4 */
+        uint32_t out = 0;
+        bool rare = false;
+        if (__builtin_expect(odd != 0u, 0)) {
+            bool lr = false;
+#pragma unroll
+            for (int c = 0; c < K; ++c) lr |= (jb + 1 + c >= jf) && (jb + 1 + c <= jl) && ((w >> (8 * c)) & 0xFFu) > 4u;
+            rare = __ballot(lr) != 0ull;
+        }
+        /* one column; RARE = the trip contains an IUPAC symbol other than N (out-of-line equality mask) */
+        auto column = [&](const int c, auto rare_tag) {
+            const int j = jb + 1 + c;
+            const uint32_t actm = ~(uint32_t)(((j - jf) | (jl - j)) >> 31);     /* all ones iff jf <= j <= jl */
+            const uint32_t ch = (w >> (8 * c)) & 0xFFu;
+            const uint32_t hin = (nb >> (2 * c)) & 3u;
+            const uint32_t hp = (0x9u >> hin) & 1u, hm = (0x2u >> hin) & 1u;
+            const uint32_t k0 = 0u - (ch & 1u), k1 = 0u - ((ch >> 1) & 1u), k4 = 0u - ((ch >> 2) & 1u);
+            uint32_t Eq = brx_bfi(k1, brx_bfi(k0, pe3, pe2), brx_bfi(k0, pe1, pe0));
+            Eq = brx_bfi(k4, pe4, Eq);
+            if constexpr (decltype(rare_tag)::value) {
+                if (actm != 0u && ch > 4u) {                   /* inline, rolled: a call would impose the callee's registers */
+                    uint32_t mq = 0;
+#pragma unroll 1
+                    for (int rr = 0; rr < 32; ++rr) { const int qi = 32 * s + rr; if (qi < g.Q && Qs[qi] == ch) mq |= 1u << rr; }
+                    Eq = mq;
+                }
+            }
+            const uint32_t Xv = Eq | Mv;
+            const uint32_t Eq2 = Eq | hm;
+            const uint32_t Xh = (((Eq2 & Pv) + Pv) ^ Pv) | Eq2;
+            const uint32_t Ph = Mv | ~(Xh | Pv);
+            const uint32_t Mh = Pv & Xh;
+            const uint32_t PhS = (Ph << 1) | hp;
+            const uint32_t MhS = (Mh << 1) | hm;
+            const uint32_t pv = MhS | ~(Xv | PhS);
+            const uint32_t mv = PhS & Xv;
+            if (actm) dst[(size_t)c * (size_t)g.WSp] = make_uint2(pv, Ph);
+            Pv = brx_bfi(actm, pv, Pv);
+            Mv = brx_bfi(actm, mv, Mv);
+            out |= (((Ph >> 31) + 2u - (Mh >> 31)) & actm) << (2 * c);
+        };
+        if (__builtin_expect(rare, 0)) {
+#pragma unroll 1
+            for (int c = 0; c < K; ++c) column(c, std::true_type{});
+        } else {
+            column(0, std::false_type{}); column(1, std::false_type{}); column(2, std::false_type{}); column(3, std::false_type{});
+        }
+        carry = out;
+
+        /* ---- a superblock leaves the band: its lane takes superblock s + 64 ---- */
+        if (__builtin_expect(tau == next_hop, 0)) {
+            if (tau >= tl) {
+                s += 64;
+                if (s < g.NS) {
+                    jf = brx_jfirst(g, s); jl = brx_jlast(g, s);
+                    tf = s + (jf - 1) / K; tl = s + (jl - 1) / K;
+                    if (jl < jf) tf = NEVER;
+                    const int nslot = s % g.WSp;
+                    dst += (ptrdiff_t)nslot - (ptrdiff_t)slot;
+                    slot = nslot;
+                } else { jf = JNEVER; jl = -1; tf = NEVER; tl = NEVER; }
+            }
+            next_hop = brx_wave_min(tl);
+            next_entry = brx_wave_min(tf > tau ? tf : NEVER);
+        }
+        wnext = brx_ring32[((uint32_t)(K * (tau + 1 - s)) >> 2) & (BRX_RING_BYTES / 4 - 1)];   /* bytes of the next trip */
+    }
+}
+
 /* MAXG: the widest band geometry (32-bit words per lane) compiled with register-resident state.
  * Register use grows with it (7 VGPRs per word), so kernels that only ever meet narrow bands are
  * instantiated with a small MAXG and run at a higher occupancy; geometries above MAXG take the
@@ -445,7 +615,7 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
         brx_align_forward_wide(Qs, Ts, g, tb, peq, st);
         return;
     }
-    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward<1>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_k4(Qs, Ts, g, tb); return; } }
     if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, prog); return; } }
     if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, prog); return; } }
     if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, prog); return; } }

@@ -732,7 +732,7 @@ __device__ inline int64_t qs_lookup(const brx_qscore_model &qm, uint64_t key) {
  *                                 side by side on two streams
  *   k_fin_qscore                  cigar windows -> qscore rows -> quality bytes, per-read statistics     */
 template <int MAXG, int GLO, int GHI>
-__global__ void __launch_bounds__(64) k_fin_align(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
+__global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                    uint32_t *queue, const uint8_t *Fbuf, const uint32_t *repl,
                                                    uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
     const int lane = lane_id();

@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
 /* -------------------------------------------------------------------------------------------------
  * k_win_wave: one parked window per wave (the windows k_win_lane does not take)
  * ----------------------------------------------------------------------------------------------- */
-__global__ void __launch_bounds__(64) k_win_wave(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr, uint32_t *queue,
+__global__ void __launch_bounds__(64, 5) k_win_wave(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr, uint32_t *queue,
                                                   const uint8_t *winbuf, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags) {
     const int lane = lane_id();
     const uint32_t n_req = uni(*n_req_ptr);
