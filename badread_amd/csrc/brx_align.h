@@ -54,10 +54,28 @@ struct BrxGeom {
     int K;             /* time skew between neighbouring superblocks: superblock s handles column j at
                           time j + K*s.  K = 4 for G = 1 (four columns per loop trip), else 1            */
     int t_end;         /* last traceback row = T + K*(NS - 1)                      */
+    int H;             /* windowed traceback store: only superblocks within H rows of the straight line
+                          row = column * Q / T are written (BRX_H_ALL: every superblock of the band)    */
+    uint32_t slope;    /* Q / T with 20 fractional bits (0 when the store is not windowed)               */
 };
+#define BRX_H_ALL (1 << 29)
 
-/* k must be >= |Q-T|.  Returns G = 0 if the band is wider than 64 lanes x 32 words can hold. */
-__host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k) {
+__host__ __device__ inline uint32_t brx_isqrt(uint32_t v) {
+    uint32_t r = 0;
+    for (uint32_t bit = 1u << 15; bit; bit >>= 1) { const uint32_t c = r | bit; if ((uint64_t)c * c <= v) r = c; }
+    return r;
+}
+
+/* k must be >= |Q-T|.  Returns G = 0 if the band is wider than 64 lanes x 32 words can hold.
+ *
+ * hmul != 0 (windowed store): the forward pass still computes the whole Ukkonen band (the cell values, and therefore every
+ * Pv/Ph bit, are unchanged), but only the superblocks that intersect rows [c(j) - H, c(j) + H] of column j,
+ * c(j) = j*Q/T, are written to the traceback store.  The canonical path of an alignment with k edits strays
+ * from that straight line like a random walk of ~k steps (measured: at most 1.5 sqrt(distance) rows on
+ * nanopore2023 reads of 2-60 kb), so with H = hmul sqrt(k) + 24, hmul = 4, the traceback practically never asks
+ * for a cell that was not stored (hmul < 0: H = 8, a test setting that makes most reads miss); when it does, the alignment reports failure and the caller repeats it with the full
+ * store.  A traceback that succeeds read exactly the bits the full store would have held: same result. */
+__host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul = 0) {
     BrxGeom g;
     g.Q = Q; g.T = T;
     int dend = Q - T;
@@ -78,8 +96,25 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k) {
     if (g.WSp < 1) g.WSp = 1;
     g.K = G == 1 ? 4 : 1;
     g.t_end = T + g.K * (g.NS - 1);
+    g.H = BRX_H_ALL; g.slope = 0;
+    if (hmul != 0 && G <= 16 && T > 0 && (uint64_t)Q < ((uint64_t)T << 11)) {
+        const int H = hmul > 0 ? hmul * (int)brx_isqrt((uint32_t)k) + 24 : 8;
+        const int slots = (2 * H + g.R - 1) / g.R + 2;      /* superblocks that can meet the window in one store row */
+        if (slots < g.WSp) { g.WSp = slots; g.H = H; g.slope = (uint32_t)(((uint64_t)Q << 20) / (uint64_t)T); }
+    }
     return g;
 }
+
+/* Is superblock s written for the column group represented by column jrep?  (jrep = the column itself when
+ * K = 1; the third column of the four-column trip when K = 4: brx_jrep.)  For a fixed store row the rows
+ * R*s - c(jrep) grow by at least R per superblock, so at most (2H + R - 1)/R + 1 consecutive superblocks
+ * pass -- they land in distinct slots s % WSp. */
+__host__ __device__ __forceinline__ bool brx_stored(const BrxGeom &g, int s, int jrep) {
+    const int c = (int)(((uint64_t)(uint32_t)jrep * (uint64_t)g.slope) >> 20);
+    const int a = g.R * s + g.H + g.R - 1 - c;
+    return (uint32_t)a <= (uint32_t)(2 * g.H + g.R - 1);
+}
+__host__ __device__ __forceinline__ int brx_jrep(const BrxGeom &g, int j) { return g.K == 4 ? (((j - 1) & ~3) + 2) : j; }
 
 /* 8-byte units of traceback storage an alignment needs */
 __host__ __device__ inline uint64_t brx_tb_units(const BrxGeom &g) {
@@ -92,6 +127,19 @@ __host__ __device__ inline uint64_t brx_peq_units(const BrxGeom &g) {
     return g.G > BRX_REGPEQ_MAXG ? ((uint64_t)5 * (uint64_t)g.NW * 4 + 7) / 8 + (uint64_t)64 * (uint64_t)g.G : 0;
 }
 __host__ __device__ inline uint64_t brx_align_units(const BrxGeom &g) { return brx_tb_units(g) + brx_peq_units(g); }
+
+/* scratch units of a read's final alignment (query = mutated read, m bytes; target = fragment, n bytes; ub = the
+ * proven bound on their distance): traceback store + the col_of[] array of the qscore stage.  *too_wide: the band
+ * does not fit the aligner at all (BRX_RS_BAND). */
+__host__ __device__ inline uint64_t brx_final_units(uint32_t m, uint32_t n, uint32_t ub, int hmul, bool *too_wide) {
+    uint64_t units = 0;
+    *too_wide = false;
+    if (m) {
+        const BrxGeom g = brx_make_geom((int)m, (int)n, (int)ub, hmul);
+        if (g.G == 0) *too_wide = true; else units = brx_align_units(g);
+    }
+    return units + ((uint64_t)m * 4 + 7) / 8 + 2;
+}
 
 __device__ inline int brx_jfirst(const BrxGeom &g, int s) {
     int j = g.R * s - g.dhi + 1;
@@ -252,6 +300,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
         uint32_t hp = (0x9u >> nb) & 1u, hm = (0x2u >> nb) & 1u;
         const uint32_t k0 = 0u - (c & 1u), k1 = 0u - ((c >> 1) & 1u), k4 = 0u - ((c >> 2) & 1u);
         const bool rare = __builtin_expect(odd != 0u, 0) && __ballot(actm != 0u && c > 4u) != 0ull;
+        const bool keep = brx_stored(g, s, t - s);                             /* windowed traceback store */
 #pragma unroll
         for (int x = 0; x < G; ++x) {
             /* symbol select by mask arithmetic (v_bfi), NOT by ?: over the array -- hipcc folds a select
@@ -274,7 +323,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
             if (G > 1) livem &= 0u - (uint32_t)(s * G + x < g.NW);            /* words past the last query row do not exist */
             Pv[x] = brx_bfi(livem, pv, Pv[x]);
             Mv[x] = brx_bfi(livem, mv, Mv[x]);
-            if (livem) dst[x] = make_uint2(pv, Ph);
+            if (livem && keep) dst[x] = make_uint2(pv, Ph);
             hp = brx_bfi(livem, Ph >> 31, hp);
             hm = brx_bfi(livem, Mh >> 31, hm);
         }
@@ -320,7 +369,9 @@ __device__ inline bool brx_align_traceback(const uint8_t *__restrict__ Qs, const
         bool inband = false, up = false, left = false, eq = false;
         if (valid) {
             int s = (ci - 1) >> shiftR;
-            inband = cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s);
+            /* a cell the windowed store did not keep counts as outside the band: the run stops there and
+               the alignment fails if the path really needs it */
+            inband = cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s) && brx_stored(g, s, brx_jrep(g, cj));
             if (inband) {
                 int x = ((ci - 1) & (g.R - 1)) >> 5;
                 int bit = (ci - 1) & 31;
@@ -531,6 +582,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
         const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
         const uint32_t w = wnext;
         const int jb = K * (tau - s);                              /* columns jb + 1 .. jb + 4 */
+        const uint32_t keepm = brx_stored(g, s, jb + 2) ? ~0u : 0u;   /* windowed traceback store: one test per trip */
         uint32_t out = 0;
         bool rare = false;
         if (__builtin_expect(odd != 0u, 0)) {
@@ -566,7 +618,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
             const uint32_t MhS = (Mh << 1) | hm;
             const uint32_t pv = MhS | ~(Xv | PhS);
             const uint32_t mv = PhS & Xv;
-            if (actm) dst[(size_t)c * (size_t)g.WSp] = make_uint2(pv, Ph);
+            if (actm & keepm) dst[(size_t)c * (size_t)g.WSp] = make_uint2(pv, Ph);
             Pv = brx_bfi(actm, pv, Pv);
             Mv = brx_bfi(actm, mv, Mv);
             out |= (((Ph >> 31) + 2u - (Mh >> 31)) & actm) << (2 * c);
@@ -628,7 +680,7 @@ template <int MAXG = 16, int MING = 1>
 __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *Ts, int T, int k,
                                       uint2 *tb, uint64_t tb_cap_units, uint8_t *ops_end,
                                       int *n_cols, int *n_match, bool *no_space, uint32_t *prog = nullptr,
-                                      uint64_t *clk = nullptr) {
+                                      uint64_t *clk = nullptr, int hmul = 0) {
     const int lane = threadIdx.x & 63;
     *no_space = false;
     if (Q == 0 || T == 0) {
@@ -639,7 +691,7 @@ __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *T
         *n_cols = Q + T; *n_match = 0;
         return true;
     }
-    BrxGeom g = brx_make_geom(Q, T, k);
+    BrxGeom g = brx_make_geom(Q, T, k, hmul);
     if (g.G == 0 || brx_align_units(g) > tb_cap_units) { *no_space = true; *n_cols = 0; *n_match = 0; return false; }
     BRX_PROG(prog, 3, 1);
     BRX_PROG(prog, 6, (uint32_t)g.t_end);

@@ -38,7 +38,7 @@ struct RS {
     uint32_t n, m, ub, start_trim;
     uint32_t end_trim, seg_off, piece_off, n_cols;
     uint32_t n_match, loops, changes, naligns;
-    uint32_t seq_len, rec_len, hdr_len, klass;     /* klass: final-alignment class, set by k_fin_join (brx_finlane.h) */
+    uint32_t seq_len, rec_len, hdr_len, klass;     /* klass: band class of the final alignment (words per lane) | BRX_KL_RETRY, set by k_fin_join */
     uint64_t F_off, seq_off, ops_off, units, tb_off, rec_off;
     double target, qerr;
 };
@@ -50,6 +50,7 @@ struct BrxDev {
     brx_sim_params p;
     uint64_t seed, first_read;
     uint32_t n_reads, raw_mode;      /* raw_mode: sequence_fragments (no plan, raw output) */
+    int tb_hmul;                     /* window of the final traceback store: H = tb_hmul sqrt(ub) + 24 rows (brx_make_geom); 0 = full */
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -670,10 +671,7 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
             RS *o = &rs[r];
             o->status = s.status; o->m = m; o->ub = cost; o->start_trim = st; o->end_trim = et;
             o->loops = (uint32_t)loops; o->changes = change; o->naligns = nalign;
-            BrxGeom g = brx_make_geom((int)m, (int)n, (int)cost);
-            uint64_t units = (m == 0) ? 0 : brx_align_units(g);
-            if (m && g.G == 0) { o->status |= BRX_RS_BAND; units = 0; }
-            o->units = units + ((uint64_t)m * 4 + 7) / 8 + 2;     /* + col_of[] for the qscore stage */
+            o->units = 0;                                          /* sized by k_fin_join */
             uint64_t *ck = clk + (uint64_t)r * 8;
             ck[0] = __builtin_amdgcn_s_memtime() - t_begin; ck[1] = aclk[0]; ck[2] = aclk[1];
         }
@@ -681,7 +679,6 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
 }
 
 #include "brx_mutate.h"
-#include "brx_finlane.h"
 
 /* offsets for the final stage.  totals: [3]=seq bytes [4]=ops bytes */
 __global__ void __launch_bounds__(64) k_scan_mut(uint32_t n_reads, RS *rs, uint64_t *totals) {
@@ -701,10 +698,11 @@ __global__ void __launch_bounds__(64) k_scan_mut(uint32_t n_reads, RS *rs, uint6
     if (lane == 0) { totals[3] = seq_run << 4; totals[4] = ops_run << 4; }
 }
 
-/* rs[order[i]].tb_off = off[i]: the host lays traceback stores out in processing order */
-__global__ void __launch_bounds__(64) k_set_tboff(uint32_t n, RS *rs, const uint32_t *order, const uint64_t *off) {
+/* rs[order[i]].tb_off = off[i] (and .units = units[i] when given): the host lays traceback stores out in
+   processing order; the retry phase also replaces the windowed sizes by full-band sizes */
+__global__ void __launch_bounds__(64) k_set_tboff(uint32_t n, RS *rs, const uint32_t *order, const uint64_t *off, const uint64_t *units) {
     uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i < n) rs[order[i]].tb_off = off[i];
+    if (i < n) { rs[order[i]].tb_off = off[i]; if (units) rs[order[i]].units = units[i]; }
 }
 
 /* =============================================================================================
@@ -724,26 +722,61 @@ __device__ inline int64_t qs_lookup(const brx_qscore_model &qm, uint64_t key) {
     }
 }
 
-/* The final stage is two kernels so that each gets its own register budget (occupancy is what hides
+/* The final stage is three kernels so that each gets its own register budget (occupancy is what hides
  * the latency of the serial column steps):
- *   k_fin_align<MAXG, GLO, GHI>   join + banded Myers + traceback for the reads whose band geometry has
+ *   k_fin_join                    join(new_fragment_bases) (simulate.py:351) + pad; band class of the read
+ *   k_fin_align<MAXG, GLO, GHI>   banded Myers + traceback for the reads whose band geometry has
  *                                 GLO <= words-per-lane <= GHI; every instantiation walks the same queue
  *                                 range and skips the other classes' reads, so narrow and wide reads run
  *                                 side by side on two streams
- *   k_fin_qscore                  cigar windows -> qscore rows -> quality bytes, per-read statistics     */
-template <int MAXG, int GLO, int GHI>
-__global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
-                                                   uint32_t *queue, const uint8_t *Fbuf, const uint32_t *repl,
-                                                   uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
+ *   k_fin_qscore                  cigar windows -> qscore rows -> quality bytes, per-read statistics
+ * Two phases.  Phase 0 aligns every read with the WINDOWED traceback store (brx_make_geom): the forward pass
+ * computes the whole band but writes only the superblocks near the straight line from corner to corner, which
+ * is where the path lives -- a third to an eighth of the bytes.  A read whose traceback asks for a cell that
+ * was not written gets BRX_KL_RETRY and is aligned again in phase 1 with the full store (the host sizes that
+ * pass).  Results never depend on which phase produced them. */
+#define BRX_KL_RETRY 0x10000u     /* phase 0 missed: repeat in phase 1                                   */
+#define BRX_KL_FULL 0x20000u      /* never windowed: the read holds a junk piece (low-complexity repeats, where
+                                     the canonical traceback collects every indel at one end of the repeat) */
+
+__global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, uint32_t *queue, const uint8_t *Fbuf, const uint32_t *repl,
+                                                  const PPiece *pieces, uint8_t *seqbuf) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
+    for (;;) {
+        const uint32_t r = wave_pop(queue);
+        if (r >= d.n_reads) break;
+        const RS s = rs[r];
+        if (s.n == 0) continue;
+        uint8_t *seq = seqbuf + s.seq_off;
+        wave_join(em, Fbuf + s.F_off, repl + s.F_off, 0, s.n, seq, nullptr);
+        for (uint32_t x = lane; x < 16; x += 64) seq[s.m + x] = 0xFE;        /* the aligner reads up to 16 bytes past the end */
+        if (lane == 0) {
+            const BrxGeom g = brx_make_geom((int)s.m, (int)s.n, (int)s.ub);
+            bool junk = false, too_wide;
+            if (!d.raw_mode) for (uint32_t i = 0; i < s.n_pieces; ++i) junk |= (pieces[s.piece_off + i].w0 & 3u) == PC_JUNK;
+            RS *o = &rs[r];
+            o->klass = (g.G ? (uint32_t)g.G : 64u) | (junk ? BRX_KL_FULL : 0u);
+            o->units = brx_final_units(s.m, s.n, s.ub, junk ? 0 : d.tb_hmul, &too_wide);     /* traceback store + col_of[] */
+            if (too_wide) o->status = s.status | BRX_RS_BAND;
+        }
+    }
+}
+
+template <int MAXG, int GLO, int GHI>
+__global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
+                                                   uint32_t *queue, uint32_t *retries, int phase, const uint8_t *Fbuf,
+                                                   uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
+    const int lane = lane_id();
     for (;;) {
         const uint32_t qi = q_begin + wave_pop(queue);
         if (qi >= q_end) break;
         const uint32_t r = order[qi];
         const RS s = rs[r];
         if (s.n == 0) continue;
-        if ((int)s.klass < GLO || (int)s.klass > GHI) continue;           /* other band class, or a lane-aligned read */
+        const int klass = (int)(s.klass & 0xFFFFu);
+        if (klass < GLO || klass > GHI) continue;                          /* another band class */
+        if (((s.klass & BRX_KL_RETRY) != 0u) != (phase != 0)) continue;     /* phase 1 repeats the window misses only */
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
         uint64_t aclk[2] = {0, 0};
         const uint32_t n = s.n, m = s.m;
@@ -754,20 +787,26 @@ __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d,
         const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
         int ncols = 0, nmatch = 0; bool nospace = false;
         const bool ok = brx_wave_align<MAXG, (GLO < MAXG ? GLO : MAXG)>(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch,
-                                             &nospace, nullptr, aclk);
+                                             &nospace, nullptr, aclk, (phase == 0 && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0);
         if (lane == 0) {
             RS *o = &rs[r];
-            o->status = s.status | (ok ? 0u : BRX_RS_BAND);
-            o->n_cols = (uint32_t)ncols; o->n_match = (uint32_t)nmatch;
+            if (!ok && phase == 0) {
+                o->klass = s.klass | BRX_KL_RETRY;
+                atomicAdd(retries, 1u);
+                clk[(uint64_t)r * 8 + 2] = 1;                               /* brx_last_read_cycles: window miss */
+            } else {
+                o->status = s.status | (ok ? 0u : BRX_RS_BAND);
+                o->n_cols = (uint32_t)ncols; o->n_match = (uint32_t)nmatch;
+            }
             uint64_t *ck = clk + (uint64_t)r * 8;
             ck[3] = __builtin_amdgcn_s_memtime() - t_begin; ck[4] = aclk[0]; ck[5] = aclk[1];
-            ck[7] = (uint64_t)brx_make_geom((int)m, (int)n, (int)s.ub).G;
+            ck[7] = (uint64_t)klass;
         }
     }
 }
 
 __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
-                                                    uint32_t *queue, uint8_t *seqbuf, const uint8_t *opsbuf, uint8_t *tb_base,
+                                                    uint32_t *queue, int phase, uint8_t *seqbuf, const uint8_t *opsbuf, uint8_t *tb_base,
                                                     uint64_t *clk) {
     __shared__ uint32_t qhist[256];
     const int lane = lane_id();
@@ -778,6 +817,7 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
         const uint32_t r = order[qi];
         RS s = rs[r];
         if (s.n == 0) continue;
+        if (((s.klass & BRX_KL_RETRY) != 0u) != (phase != 0)) continue;     /* window misses are scored in phase 1 */
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
         const uint64_t read = d.first_read + r;
         const uint32_t n = s.n, m = s.m;

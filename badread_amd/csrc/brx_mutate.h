@@ -252,14 +252,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
             RS *o = &rs[r];
             o->status = s.status | st_extra; o->m = m; o->ub = cost; o->start_trim = st; o->end_trim = et;
             o->loops = (uint32_t)loops; o->changes = change; o->naligns = nalign;
-            const BrxGeom g = brx_make_geom((int)m, (int)n, (int)cost);
-            uint64_t units = (m == 0) ? 0 : brx_align_units(g);
-            if (m && g.G == 0) { o->status |= BRX_RS_BAND; units = 0; }
-            if (m && g.G) {          /* the lane-per-read aligner stores (columns + 2) rows of band-blocks words */
-                const uint64_t lu = (uint64_t)(n + 2) * (uint64_t)((g.dhi - g.dlo) / 32 + 2);
-                if (lu > units) units = lu;
-            }
-            o->units = units + ((uint64_t)m * 4 + 7) / 8 + 2;     /* + col_of[] for the qscore stage */
+            o->units = 0;                                          /* sized by k_fin_join */
             msv[r].phase = 2u;
             ck[0] += __builtin_amdgcn_s_memtime() - t_begin; ck[1] = INLINE ? nalign : ms.passes;
         }

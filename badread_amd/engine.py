@@ -240,6 +240,8 @@ def load_library():
     lib.brx_last_mutate_passes.argtypes = [ctypes.c_void_p]
     lib.brx_last_final_launches.restype = ctypes.c_uint32
     lib.brx_last_final_launches.argtypes = [ctypes.c_void_p]
+    lib.brx_last_window_misses.restype = ctypes.c_uint32
+    lib.brx_last_window_misses.argtypes = [ctypes.c_void_p]
     _lib = lib
     return lib
 
@@ -447,6 +449,10 @@ class HipEngine(EngineBase):
 
     def final_launches(self):
         return int(self.lib.brx_last_final_launches(self.ctx))
+
+    def window_misses(self):
+        """Reads of the last batch that needed the full traceback store (second pass of the final stage)."""
+        return int(self.lib.brx_last_window_misses(self.ctx))
 
 
 _default_engine = None

@@ -101,13 +101,26 @@ def cpu_worker(first_read, budget_s, out_path):
         json.dump({'bases': bases, 'reads': reads, 'seconds': time.perf_counter() - t0}, f)
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes
+    expose 256 hardware threads but limit the container to 16 CPUs' worth of time: /sys/fs/cgroup/cpu.max)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(first_read, budget_s):
     """The oracle (oracle/brx_oracle.c, a scalar C port of the same path: gamma/beta draws, fragment build, mutate
     loop with block-Myers window alignments, final alignment + traceback, qscore lookup, FASTQ record) on EVERY host
-    core: one single-threaded process per core, disjoint slices of the same read-index stream, own clock each."""
+    usable core (usable_cores()): one single-threaded process per core, disjoint slices of the same read-index stream, own clock each."""
     import subprocess
     import tempfile
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = usable_cores()
     tmp = tempfile.mkdtemp(prefix='brx_cpu_')
     env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='')
     procs = []
@@ -185,7 +198,7 @@ def main():
 
     def run_steps(indices):
         """Steps `indices`, C at a time: worker i owns context i / stream i and takes every C-th step."""
-        acc = [{'bases': 0, 'g1_bases': 0, 'passes': 0, 'stages': {}, 'final_launches': 0, 'error': None} for _ in range(C)]
+        acc = [{'bases': 0, 'g1_bases': 0, 'passes': 0, 'stages': {}, 'final_launches': 0, 'misses': 0, 'error': None} for _ in range(C)]
 
         def worker(i):
             try:
@@ -200,6 +213,7 @@ def main():
                         for name, ms in engines[i].stage_ms().items():
                             acc[i]['stages'][name] = acc[i]['stages'].get(name, 0.0) + ms
                         acc[i]['final_launches'] += engines[i].final_launches()
+                        acc[i]['misses'] += engines[i].window_misses()
                     streams[i].synchronize()
             except BaseException as ex:          # surfaced on the main thread
                 acc[i]['error'] = ex
@@ -287,6 +301,7 @@ def main():
                      'note': 'integer-ALU / latency bound path: see DESIGN.md section 5; launch_ms is the HIP-event '
                              'duration of one launch while other batches share the GPU'},
         'stage_ms_per_step': stages, 'mutate_passes_per_step': sum(a['passes'] for a in acc) / args.steps,
+        'traceback_window_misses_per_step': sum(a['misses'] for a in acc) / args.steps,
     }
     if d2h is not None:
         result['value_incl_d2h'] = d2h

@@ -228,8 +228,8 @@ int brx_align_batch(brx_ctx *ctx, uint32_t n_pairs,
  *   MUTATE  all passes of {k_mutate_seg, k_win_lane, k_win_wave} (+ k_mutate for overflow reads),
  *           including the host round trips between passes; brx_last_mutate_passes() gives the count
  *   SCAN    k_scan_mut
- *   FINAL   the whole final stage: k_fin_align<...> for every band class (two streams) + k_fin_qscore,
- *           one set of launches per scratch chunk
+ *   FINAL   the whole final stage: k_fin_join, then k_fin_align<...> for every band class (two streams) +
+ *           k_fin_qscore, one set of launches per scratch chunk (and per phase: brx_last_window_misses)
  *   EMIT    k_recsize, k_scan_rec, k_emit, k_stats (includes one small size read-back)
  *   ALIGN1  average duration of ONE launch of k_fin_align<1,1,1> (the largest single kernel) over the chunks
  *   QSCORE  average duration of ONE launch of k_fin_qscore over the chunks                              */
@@ -238,13 +238,17 @@ enum { BRX_STAGE_PLAN = 0, BRX_STAGE_BUILD = 1, BRX_STAGE_MUTATE = 2, BRX_STAGE_
 int brx_last_stage_ms(const brx_ctx *ctx, float ms[BRX_STAGE_COUNT]);
 /* Shader-clock cycles (s_memtime) each read of the last pipeline call spent in the two heavy
  * kernels, 8 x u64 per read, copied to HOST memory h_out (valid until the next call on ctx):
- *   [0] k_mutate_seg total over all passes  [1] passes (alignments) of the read  [2] unused
+ *   [0] k_mutate_seg total over all passes  [1] passes (alignments) of the read  [2] 1 if the final traceback left the stored window
  *   [3] k_fin_align total   [4] final alignment forward    [5] final traceback   [6] k_fin_qscore
  *   [7] words per lane (G) of the final alignment's band geometry                                */
 int brx_last_read_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
 /* number of scratch chunks (sets of final-stage launches) and of mutate passes of the last call */
 uint32_t brx_last_mutate_passes(const brx_ctx *ctx);
 uint32_t brx_last_final_launches(const brx_ctx *ctx);
+/* Reads of the last call whose final traceback asked for a cell outside the windowed traceback store and were
+ * aligned a second time with the full store (environment BRX_TB_WINDOW: window height in
+ * sqrt(edit bound) units, default 4, 0 = always the full store).  Results do not depend on it. */
+uint32_t brx_last_window_misses(const brx_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -85,11 +85,12 @@ def test_sequence_fragments_matches_oracle():
     assert H.first_diff(res_h[0][0], frags[0]) < 0
 
 
-@pytest.mark.parametrize('env', [{'BRX_FIN_LANE': '1'}, {'BRX_MUTATE_INLINE': '1'}, {'BRX_LANE_THRESHOLD': '0'},
-                                 {'BRX_LANE_THRESHOLD': '1000000'}])
+@pytest.mark.parametrize('env', [{'BRX_TB_WINDOW': '0'}, {'BRX_TB_WINDOW': '-1'}, {'BRX_TB_WINDOW': '1'}, {'BRX_MUTATE_INLINE': '1'},
+                                 {'BRX_LANE_THRESHOLD': '0'}, {'BRX_LANE_THRESHOLD': '1000000'}])
 def test_alternative_kernel_routes_give_the_same_bytes(env, monkeypatch):
-    """The optional routes (lane-per-read final aligner, in-place mutate alignments, lane- or wave-per-window for
-    every pass) are read from the environment when a context is created; all must reproduce the oracle."""
+    """The optional routes (full / 8-row / narrow traceback window of the final alignment -- the 8-row window
+    makes most reads miss and repeat with the full store --, in-place mutate alignments, lane- or wave-per-window
+    for every pass) are read from the environment when a context is created; all must reproduce the oracle."""
     from badread_amd.engine import HipEngine
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -102,4 +103,9 @@ def test_alternative_kernel_routes_give_the_same_bytes(env, monkeypatch):
     for f in STAT_FIELDS:
         assert (st_h[f] == st_o[f]).all(), f
     assert H.first_diff(out_h, out_o) < 0
+    misses = eng.window_misses()
+    if env.get('BRX_TB_WINDOW') == '0':
+        assert misses == 0
+    if env.get('BRX_TB_WINDOW') == '-1':
+        assert misses > 50, misses                     # the retry pass really ran
     eng.close()
