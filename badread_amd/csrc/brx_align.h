@@ -99,7 +99,7 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul =
     g.H = BRX_H_ALL; g.slope = 0;
     if (hmul != 0 && G <= 16 && T > 0 && (uint64_t)Q < ((uint64_t)T << 11)) {
         const int H = hmul > 0 ? hmul * (int)brx_isqrt((uint32_t)k) + 24 : 8;
-        const int slots = (2 * H + g.R - 1) / g.R + 2;      /* superblocks that can meet the window in one store row */
+        const int slots = (2 * H + g.R - 1) / g.R + 1;      /* superblocks that can meet the window in one store row */
         if (slots < g.WSp) { g.WSp = slots; g.H = H; g.slope = (uint32_t)(((uint64_t)Q << 20) / (uint64_t)T); }
     }
     return g;

@@ -39,7 +39,9 @@ struct brx_ctx {
     float stage_ms[BRX_STAGE_COUNT];
     uint32_t final_launches, mutate_passes;
     int mutate_inline;
-    int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (4; 0 = full store; -1 = 8 rows, test) */
+    uint32_t seg_waves_per_cu;   /* BRX_SEG_WAVES_PER_CU: persistent waves of k_mutate_seg per CU */
+    uint32_t tail_reads;         /* BRX_TAIL_READS: this few reads left in the mutate stage -> one in-place launch */
+    int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one */
@@ -131,7 +133,9 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
-    { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 4; }
+    { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
+    { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 2048u; }
+    { const char *sw = getenv("BRX_SEG_WAVES_PER_CU"); c->seg_waves_per_cu = sw && atoi(sw) > 0 ? (uint32_t)atoi(sw) : 8u; }
     { const char *lt = getenv("BRX_LANE_THRESHOLD"); c->lane_threshold = lt ? (uint32_t)atoi(lt) : 3000u; }
     c->err[0] = 0;
     *out = c;
@@ -293,7 +297,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
 
     /* ---- stage: mutate (multi-pass: segments of the loop, parked window alignments; brx_mutate.h) ---- */
     {
-        const uint32_t seg_waves = std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 8u);
+        const uint32_t seg_waves = std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * (uint64_t)c->seg_waves_per_cu);
         HIPCHK(c, hipMemsetAsync(msv, 0, (size_t)n_reads * sizeof(MS), st));
         HIPCHK(c, hipMemsetAsync(mctr, 0, 4 * MC_WORDS * sizeof(uint32_t), st));
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
@@ -308,7 +312,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         const uint32_t lane_threshold = c->lane_threshold;   /* fewer active reads than this: one wave per window (lower latency) */
         /* this few reads left: run them to completion on the GPU, aligning in place (no host round trips).
            BRX_MUTATE_INLINE=1 does that for the whole batch: one launch, no passes. */
-        const uint32_t tail_reads = c->mutate_inline ? 0xFFFFFFFFu : 48u;
+        const uint32_t tail_reads = c->mutate_inline ? 0xFFFFFFFFu : c->tail_reads;
         auto read_counts = [&](uint32_t *ctr) -> int {
             HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             return wait_stream(c, st, "mutate pass");
@@ -336,7 +340,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
                                ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1);
             /* the active count only shrinks: look at it every 4th pass while it is large, every pass near the end */
-            if (n_up <= 4 * tail_reads || (pass & 3u) == 3u) {
+            if (n_up <= 4 * std::min<uint32_t>(tail_reads, 48u) || n_up <= tail_reads + 64 || (pass & 3u) == 3u) {
                 rc = read_counts(ctr);
                 if (rc) return rc;
                 n_up = h_ctr[MC_OUT];

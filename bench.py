@@ -151,8 +151,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--reads-per-step', type=int, default=16384, help='read indices per GPU per step')
-    ap.add_argument('--scratch-gb', type=float, default=24.0, help='scratch arena per in-flight batch')
-    ap.add_argument('--streams', type=int, default=10,
+    ap.add_argument('--scratch-gb', type=float, default=30.0, help='scratch arena per in-flight batch')
+    ap.add_argument('--streams', type=int, default=8,
                     help='batches in flight per GPU (one context + HIP stream + host thread each): the slowest read '
                          'of one batch overlaps the bulk of the next')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='seconds each host core runs the cpu_baseline leg (0 = skip)')

@@ -247,7 +247,7 @@ uint32_t brx_last_mutate_passes(const brx_ctx *ctx);
 uint32_t brx_last_final_launches(const brx_ctx *ctx);
 /* Reads of the last call whose final traceback asked for a cell outside the windowed traceback store and were
  * aligned a second time with the full store (environment BRX_TB_WINDOW: window height in
- * sqrt(edit bound) units, default 4, 0 = always the full store).  Results do not depend on it. */
+ * sqrt(edit bound) units, default 2, 0 = always the full store).  Results do not depend on it. */
 uint32_t brx_last_window_misses(const brx_ctx *ctx);
 
 #ifdef __cplusplus
