@@ -44,7 +44,8 @@ struct brx_ctx {
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
-    hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one */
+    hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
+                                    three wide classes: a stream per class measured 30 % slower, r01d) */
     hipEvent_t ev_a1b[BRX_MAX_CHUNKS], ev_a1e[BRX_MAX_CHUNKS];   /* k_fin_align<1,1,1> of every scratch chunk */
     hipEvent_t ev_qsb[BRX_MAX_CHUNKS], ev_qse[BRX_MAX_CHUNKS];   /* k_fin_qscore of every scratch chunk      */
     hipEvent_t ev_fork, ev_join;
@@ -83,16 +84,29 @@ extern "C" const char *brx_version(void) { return "brx-hip 0.1 (gfx950)"; }
 
 static char g_create_err[512] = "";
 
+/* every stream, event and pinned buffer the context owns (the context is calloc'ed: unset handles are null) */
+static void release(brx_ctx *c) {
+    if (!c) return;
+    for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
+        if (c->ev_b[i]) (void)hipEventDestroy(c->ev_b[i]);
+        if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]);
+    }
+    for (int i = 0; i < BRX_MAX_CHUNKS; ++i) {
+        if (c->ev_a1b[i]) (void)hipEventDestroy(c->ev_a1b[i]);
+        if (c->ev_a1e[i]) (void)hipEventDestroy(c->ev_a1e[i]);
+        if (c->ev_qsb[i]) (void)hipEventDestroy(c->ev_qsb[i]);
+        if (c->ev_qse[i]) (void)hipEventDestroy(c->ev_qse[i]);
+    }
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->h_totals) (void)hipHostFree(c->h_totals);
+    free(c);
+}
+
 static int create_fail(brx_ctx *c, const char *what, hipError_t e) {
     snprintf(g_create_err, sizeof(g_create_err), "brx_create: %s failed: %s (%d)", what, hipGetErrorString(e), (int)e);
-    if (c) {
-        for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
-            if (c->ev_b[i]) (void)hipEventDestroy(c->ev_b[i]);
-            if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]);
-        }
-        if (c->h_totals) (void)hipHostFree(c->h_totals);
-        free(c);
-    }
+    release(c);
     return BRX_E_HIP;
 }
 
@@ -142,15 +156,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     return BRX_OK;
 }
 
-extern "C" void brx_destroy(brx_ctx *c) {
-    if (!c) return;
-    for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
-        if (c->ev_b[i]) (void)hipEventDestroy(c->ev_b[i]);
-        if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]);
-    }
-    if (c->h_totals) (void)hipHostFree(c->h_totals);
-    free(c);
-}
+extern "C" void brx_destroy(brx_ctx *c) { release(c); }
 
 extern "C" const char *brx_last_error(const brx_ctx *c) { return c ? c->err : g_create_err; }
 

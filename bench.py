@@ -24,7 +24,7 @@ the same algorithm -- run on all host cores of this box on a bounded sample of t
 """
 import argparse
 import os as _os
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')      # one hardware queue per in-flight batch stream (HIP's default of 4 serialises them)
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '40')      # a hardware queue per stream of every in-flight batch: main + side stream each (HIP's default of 4 serialises them)
 import json
 import os
 import sys

@@ -102,3 +102,33 @@ def mutate_seq(rng, s, rate):
         if r < rate:
             out.append('ACGT'[rng.integers(0, 4)])
     return ''.join(out)
+
+
+def identity_tolerance_check(engine, models=('random', 'nanopore2018', 'nanopore2020', 'nanopore2023', 'pacbio2016', 'pacbio2021'),
+                             identities=(1.0, 0.9, 0.8), lengths=(3000, 1000), trials=20, seed=1234):
+    """The reference's own acceptance test of sequence_fragment (test/test_simulate.py:57-163) against `engine`:
+    for every error model (qscore model 'random'), target identity and read length, `trials` random fragments;
+    each read's identity (fragment aligned against the read, misc.identity_from_edlib_cigar) within 0.5 x the target
+    error of the target, and their mean within 0.05 x.  Returns the number of reads checked."""
+    import statistics
+    rng = np.random.default_rng(seed)
+    engine.set_qscore_model(qscore_tables('random'))
+    checked = 0
+    first = 0
+    for model in models:
+        engine.set_error_model(error_tables(model))
+        for target in identities:
+            for length in lengths:
+                frags = [rng.integers(0, 4, length).astype(np.uint8) for _ in range(trials)]
+                res, _ = engine.sequence_fragments(seed, first, frags, [target] * trials)
+                first += trials
+                seqs = [r[0] for r in res]
+                # test_simulate.py:85 aligns the fragment (query) against the read (target)
+                _, _, ncols, nmatch = engine.align_batch([bytes(f) for f in frags], [bytes(s) for s in seqs], want_ops=False)
+                ids = [nm / nc if nc else 0.0 for nm, nc in zip(nmatch.tolist(), ncols.tolist())]
+                err = 1.0 - target
+                for i, ident in enumerate(ids):
+                    assert abs(ident - target) <= 0.5 * err + 1e-12, (model, target, length, i, ident)
+                assert abs(statistics.mean(ids) - target) <= 0.05 * err + 1e-12, (model, target, length, statistics.mean(ids))
+                checked += trials
+    return checked

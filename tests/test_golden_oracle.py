@@ -211,3 +211,20 @@ def test_aligner_band_hint_does_not_change_the_path():
         d2, o2 = pyoracle.align(q.encode(), t.encode(), k=k)
         assert d2 == d and H.first_diff(ops, o2) < 0
     assert pyoracle.align(q.encode(), t.encode(), k=d - 1)[0] < 0       # too narrow a band is reported, not guessed
+
+
+def test_reference_identity_tolerances_on_the_oracle():
+    """test/test_simulate.py:57-163 (every packaged error model x identities 1.0/0.9/0.8 x lengths 3000/1000 x 20
+    trials) with the oracle as the engine: the restated mutate loop lands where the reference's test requires."""
+    eng = H.oracle_engine()
+    pref, _ = H.small_reference()
+    H.configure(eng, pref)
+    assert H.identity_tolerance_check(eng) == 6 * 3 * 2 * 20
+
+
+def test_distributions_match_the_running_reference(tmp_path):
+    """SURVEY.md 8d gate 3: >= 10 000 reads from our driver (oracle engine) against >= 10 000 reads of the
+    unmodified reference CLI (tests/golden/ks_reference.npz): KS at alpha = 0.01 on four per-read statistics."""
+    import stat_parity
+    report, crit, tv = stat_parity.check(H.oracle_engine(), tmp_path)
+    print(report, crit, tv)

@@ -66,3 +66,19 @@ def test_sequence_fragment_drop_in():
     b = S.sequence_fragment(frag, 0.9, em, qm)
     assert a == b and a[0] != frag and abs(a[2] - 0.9) < 0.05 and 0.0 < a[3] < 1.0
     assert S.sequence_fragment('', 0.9, em, qm) == ('', '', 0.0, 0.0)
+
+
+def test_reference_identity_tolerances():
+    """The reference's acceptance test of sequence_fragment (test/test_simulate.py:57-163) pointed at the HIP path:
+    six error models x three target identities x two lengths x 20 trials, per-read and mean tolerances as written
+    there; both the reads and the checking alignments go through the C-ABI."""
+    eng = H.hip_engine()
+    pref, _ = H.small_reference()
+    H.configure(eng, pref)
+    assert H.identity_tolerance_check(eng) == 6 * 3 * 2 * 20
+
+
+def test_distributions_match_the_running_reference(tmp_path):
+    """SURVEY.md 8d gate 3 on the HIP path: same check as tests/test_golden_oracle.py, engine = libbrx_hip.so."""
+    import stat_parity
+    stat_parity.check(H.hip_engine(), tmp_path)
