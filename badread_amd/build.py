@@ -1,5 +1,5 @@
 """
-Build libbrx_hip.so in-tree with hipcc for gfx950 (`python -m badread_amd.build`).
+Build libbrx_hip.so (hipcc, gfx950) and libbrx_host.so (g++, zlib) in-tree (`python -m badread_amd.build`).
 
 Flags that matter:
   --offload-arch=gfx950   the only target (CDNA4 / MI355X); no other architectures, no fallbacks
@@ -33,6 +33,7 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    build_host(force)
     if not force and not needs_build():
         return OUT
     cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
@@ -44,5 +45,21 @@ def build(force=False, verbose=False):
     return OUT
 
 
+HOST_OUT = os.path.join(CSRC, 'libbrx_host.so')
+HOST_DEPS = ['brx_fasta.cpp', os.path.join('..', '..', 'include', 'brx_host.h'), os.path.join('..', '..', 'include', 'brx.h')]
+
+
+def build_host(force=False):
+    """libbrx_host.so: the CPU-side helpers (FASTA packer); g++ + zlib, no HIP."""
+    if not force and os.path.exists(HOST_OUT) and \
+            all(os.path.getmtime(os.path.join(CSRC, d)) <= os.path.getmtime(HOST_OUT) for d in HOST_DEPS):
+        return HOST_OUT
+    cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wextra',
+           os.path.join(CSRC, 'brx_fasta.cpp'), '-o', HOST_OUT, '-lz']
+    subprocess.check_call(cmd, cwd=CSRC)
+    return HOST_OUT
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose='-v' in sys.argv))
+    print(HOST_OUT)

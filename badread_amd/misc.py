@@ -76,7 +76,9 @@ def load_fasta(filename):
                 chunks.append(line)
                 continue
             flush()
-            header, chunks = line[1:], []
+            if header:                    # lines before the first header stay in the list: they start the first contig
+                chunks = []
+            header = line[1:]
             short = header.split()[0]
             lowered = header.lower()
             depth = 1.0

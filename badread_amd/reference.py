@@ -24,6 +24,45 @@ EXCEPTION_DTYPE = np.dtype([('start', '<u8'), ('end', '<u8'), ('code', '<u4'), (
 FLAG_CIRCULAR, FLAG_HAIRPIN_LEFT, FLAG_HAIRPIN_RIGHT = 1, 2, 4
 _CHUNK = 1 << 24
 
+import ctypes as _ct  # noqa: E402
+
+
+class FastaView(_ct.Structure):
+    """brx_fasta_view of include/brx_host.h"""
+    _fields_ = [('n_bases', _ct.c_uint64), ('n_words', _ct.c_uint64), ('n_contigs', _ct.c_uint32),
+                ('n_exceptions', _ct.c_uint32), ('names_len', _ct.c_uint32), ('n_symbols', _ct.c_uint32),
+                ('packed', _ct.POINTER(_ct.c_uint32)), ('contigs', _ct.c_void_p), ('exceptions', _ct.c_void_p),
+                ('names', _ct.c_void_p), ('depths', _ct.POINTER(_ct.c_double)),
+                ('sym', _ct.c_uint8 * 16), ('comp', _ct.c_uint8 * 16)]
+
+
+_host_lib = None
+
+
+def host_library():
+    """libbrx_host.so (built by `python -m badread_amd.build`); raises if it is missing -- there is no silent
+    fall-back to the Python packer on the product path."""
+    global _host_lib
+    if _host_lib is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.realpath(__file__)), 'csrc', 'libbrx_host.so')
+        if not os.path.isfile(path):
+            raise RuntimeError(f'{path} is missing: run `python -m badread_amd.build`')
+        lib = _ct.CDLL(path)
+        P = _ct.c_void_p
+        lib.brx_fasta_pack.restype = _ct.c_int
+        lib.brx_fasta_pack.argtypes = [_ct.c_char_p, _ct.POINTER(P), _ct.c_char_p, _ct.c_size_t]
+        lib.brx_fasta_load.restype = _ct.c_int
+        lib.brx_fasta_load.argtypes = [_ct.c_char_p, _ct.c_char_p, _ct.POINTER(P), _ct.c_char_p, _ct.c_size_t]
+        lib.brx_fasta_save.restype = _ct.c_int
+        lib.brx_fasta_save.argtypes = [P, _ct.c_char_p, _ct.c_char_p, _ct.c_char_p, _ct.c_size_t]
+        lib.brx_fasta_view_of.restype = _ct.c_int
+        lib.brx_fasta_view_of.argtypes = [P, _ct.POINTER(FastaView)]
+        lib.brx_fasta_free.restype = None
+        lib.brx_fasta_free.argtypes = [P]
+        _host_lib = lib
+    return _host_lib
+
 
 class PackedReference(object):
     """Packed genome + per-contig metadata.  Build with from_fasta() or from_seqs()."""
@@ -45,8 +84,66 @@ class PackedReference(object):
         self.code_of = {}
 
     @classmethod
-    def from_fasta(cls, filename):
+    def from_fasta(cls, filename, cache=None):
+        """FASTA or FASTA.gz -> packed reference through libbrx_host.so (csrc/brx_fasta.cpp: one streaming C++ pass
+        instead of Python strings + numpy).  cache=True (or BRX_REFERENCE_CACHE=1) keeps the packed form in
+        `<filename>.brx2bit` and reuses it while the FASTA's size and mtime are unchanged."""
+        import os
+        if cache is None:
+            cache = os.environ.get('BRX_REFERENCE_CACHE', '') not in ('', '0')
+        return cls._from_native(filename, cache)
+
+    @classmethod
+    def from_fasta_python(cls, filename):
+        """The same result by the pure Python/numpy route (misc.load_fasta + from_seqs); kept as the cross-check
+        of the native packer in the tests."""
         return cls.from_seqs(*load_fasta(filename))
+
+    @classmethod
+    def _from_native(cls, filename, cache):
+        import ctypes
+        lib = host_library()
+        err = ctypes.create_string_buffer(512)
+        handle = ctypes.c_void_p()
+        name = str(filename).encode()
+        sidecar = name + b'.brx2bit'
+        rc = -1
+        if cache:
+            rc = lib.brx_fasta_load(name, sidecar, ctypes.byref(handle), err, len(err))
+        if rc != 0:
+            rc = lib.brx_fasta_pack(name, ctypes.byref(handle), err, len(err))
+            if rc != 0:
+                raise ValueError(err.value.decode('latin-1') or f'could not read {filename}')
+            if cache:
+                lib.brx_fasta_save(handle, name, sidecar, err, len(err))      # best effort: a read-only directory is fine
+        try:
+            v = FastaView()
+            lib.brx_fasta_view_of(handle, ctypes.byref(v))
+            self = cls()
+            nc = int(v.n_contigs)
+            self.n_bases = int(v.n_bases)
+            self.packed = np.ctypeslib.as_array(v.packed, shape=(int(v.n_words),)).copy()
+            self.contigs = np.frombuffer(ctypes.string_at(v.contigs, nc * CONTIG_DTYPE.itemsize), dtype=CONTIG_DTYPE).copy()
+            ne = int(v.n_exceptions)
+            self.exceptions = (np.frombuffer(ctypes.string_at(v.exceptions, ne * EXCEPTION_DTYPE.itemsize), dtype=EXCEPTION_DTYPE).copy()
+                               if ne else np.zeros(0, dtype=EXCEPTION_DTYPE))
+            self.names_pool = ctypes.string_at(v.names, int(v.names_len)) if v.names_len else b''
+            depths = np.ctypeslib.as_array(v.depths, shape=(nc,)).copy()
+            self.sym = np.frombuffer(bytes(v.sym), dtype=np.uint8).copy()
+            self.comp = np.frombuffer(bytes(v.comp), dtype=np.uint8).copy()
+        finally:
+            lib.brx_fasta_free(handle)
+        for i in range(nc):
+            ct = self.contigs[i]
+            n = self.names_pool[int(ct['name_off']):int(ct['name_off']) + int(ct['name_len'])].decode('latin-1')
+            self.names.append(n)
+            self.lengths.append(int(ct['length']))
+            self.depths[n] = float(depths[i])
+            self.circular[n] = bool(ct['flags'] & FLAG_CIRCULAR)
+            self.hairpin_left[n] = bool(ct['flags'] & FLAG_HAIRPIN_LEFT)
+            self.hairpin_right[n] = bool(ct['flags'] & FLAG_HAIRPIN_RIGHT)
+        self.code_of = {chr(self.sym[c]): c for c in range(int(v.n_symbols))}
+        return self
 
     @classmethod
     def from_seqs(cls, seqs, depths=None, circular=None, hairpin_left=None, hairpin_right=None):

@@ -30,7 +30,7 @@ from .engine import RS_NOFRAG, SimParams
 from .error_model import ErrorModel
 from .fragment_lengths import FragmentLengths
 from .identities import Identities
-from .misc import float_to_str, get_random_sequence, load_fasta, str_is_int
+from .misc import float_to_str, get_random_sequence, str_is_int
 from .qscore_model import QScoreModel
 from .reference import PackedReference
 from .version import __version__
@@ -49,16 +49,17 @@ def print_intro(output):
 
 
 def load_reference(reference, output):
-    """FASTA -> PackedReference, with the reference's summary lines (simulate.py:494-507)."""
+    """FASTA(.gz) -> PackedReference through the native packer (libbrx_host.so, csrc/brx_fasta.cpp), with the
+    reference's summary lines (simulate.py:494-507)."""
     print(f'\nLoading reference from {reference}', file=output)
-    seqs, depths, circular, hp_left, hp_right = load_fasta(reference)
-    print(f'  {len(seqs):,} contig{"" if len(seqs) == 1 else "s"}:', file=output)
-    for name, seq in seqs.items():
-        shape = 'circular' if circular[name] else 'linear'
-        print(f'    {name}: {len(seq):,} bp, {shape}, {depths[name]:.2f}x depth', file=output)
-    if len(seqs) > 1:
-        print(f'  total size: {sum(len(s) for s in seqs.values()):,} bp', file=output)
-    return PackedReference.from_seqs(seqs, depths, circular, hp_left, hp_right)
+    pref = PackedReference.from_fasta(reference)
+    print(f'  {len(pref.names):,} contig{"" if len(pref.names) == 1 else "s"}:', file=output)
+    for name, length in zip(pref.names, pref.lengths):
+        shape = 'circular' if pref.circular[name] else 'linear'
+        print(f'    {name}: {length:,} bp, {shape}, {pref.depths[name]:.2f}x depth', file=output)
+    if len(pref.names) > 1:
+        print(f'  total size: {sum(pref.lengths):,} bp', file=output)
+    return pref
 
 
 def adjust_depths(pref, frag_lengths, small_plasmid_bias, rng):
