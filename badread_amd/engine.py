@@ -272,6 +272,7 @@ class HipEngine(EngineBase):
         self._scratch = None
         self._out = None
         self._stats = None
+        self._structs = {}              # last descriptor given to each brx_set_*: what clone() hands to a new context
         self._ensure_scratch(scratch_bytes)
 
     def close(self):
@@ -320,18 +321,36 @@ class HipEngine(EngineBase):
     def set_reference(self, pref, cum_weight=None):
         s = self._fill_reference(pref, cum_weight)
         self._check(self.lib.brx_set_reference(self.ctx, ctypes.byref(s)))
+        self._structs['ref'] = s
 
     def set_error_model(self, tables):
         s = self._fill_error_model(tables)
         self._check(self.lib.brx_set_error_model(self.ctx, ctypes.byref(s)))
+        self._structs['em'] = s
 
     def set_qscore_model(self, tables):
         s = self._fill_qscore_model(tables)
         self._check(self.lib.brx_set_qscore_model(self.ctx, ctypes.byref(s)))
+        self._structs['qm'] = s
+
+    def clone(self, scratch_bytes=None):
+        """Another context on the same device that SHARES this engine's device tables (reference, models,
+        parameters: read-only in every kernel) and owns its scratch, output and stream.  The driver keeps several
+        batches in flight with one clone per batch (badread_amd.simulate.run_batches)."""
+        other = HipEngine(self.device.index or 0, scratch_bytes or (self._scratch.numel() if self._scratch is not None else 1 << 30))
+        other._keep = dict(self._keep)
+        other.sym = self.sym
+        setters = {'ref': self.lib.brx_set_reference, 'em': self.lib.brx_set_error_model,
+                   'qm': self.lib.brx_set_qscore_model, 'params': self.lib.brx_set_params}
+        for key, s in self._structs.items():
+            other._check(setters[key](other.ctx, ctypes.byref(s)))
+            other._structs[key] = s
+        return other
 
     def set_params(self, params):
         s = self._fill_params(params)
         self._check(self.lib.brx_set_params(self.ctx, ctypes.byref(s)))
+        self._structs['params'] = s
 
     # ------------------------------------------------------------------ calls
     def _retry(self, call, n_reads, out_guess, allow_nofrag=False):

@@ -39,6 +39,7 @@ NOFRAG_MESSAGE = ('Error: failed to generate any sequence fragments - are your r
                   'incompatible with your reference contig lengths?')
 ADJUST_SAMPLES = 100000
 DEFAULT_MAX_BATCH = 16384
+DEFAULT_IN_FLIGHT = 4          # super-batches in flight per GPU (--gpu-streams)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -250,51 +251,128 @@ def plan_batch(remaining_bases, mean_length, world, max_batch):
     return per_rank * world
 
 
-def run_batches(engine, seed, target_size, mean_length, write, output, shard=None, max_batch=DEFAULT_MAX_BATCH):
+class _BatchPool(object):
+    """`in_flight` engines (the given one + clones sharing its device tables), each driven by its own host thread on
+    its own HIP stream, so that several batches overlap on the GPU: a batch is a chain of short dependent kernels
+    (hundreds of mutate passes, the long reads' alignments) that cannot fill 256 CUs alone."""
+
+    def __init__(self, engine, in_flight):
+        import concurrent.futures
+        self.engines = [engine]
+        self.streams = [None]
+        if in_flight > 1 and hasattr(engine, 'clone'):
+            torch = getattr(engine, 'torch', None)           # absent on the tests' CPU checker engine
+            self.streams = [torch.cuda.Stream(device=engine.device) if torch else None for _ in range(in_flight)]
+            self.engines += [engine.clone() for _ in range(in_flight - 1)]
+        self.free = list(range(len(self.engines)))
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=len(self.engines)) if len(self.engines) > 1 else None
+
+    def __len__(self):
+        return len(self.engines)
+
+    def submit(self, seed, first, n_mine):
+        i = self.free.pop()
+        eng, stream = self.engines[i], self.streams[i]
+
+        def job():
+            if n_mine == 0:
+                return np.zeros(0, np.uint8), np.zeros(0, dtype=eng.stats_dtype)
+            if stream is None:
+                return eng.simulate_batch(seed, first, n_mine, allow_nofrag=True)
+            torch = eng.torch
+            torch.cuda.set_device(eng.device)
+            with torch.cuda.stream(stream):
+                out, stats = eng.simulate_batch(seed, first, n_mine, allow_nofrag=True)
+                return out.copy(), stats.copy()          # the engine's buffers are reused by its next batch
+        if self.pool is None:
+            class _Done(object):
+                def __init__(self, v): self.v = v
+                def result(self): return self.v
+            return i, _Done(job())
+        return i, self.pool.submit(job)
+
+    def release(self, i):
+        self.free.append(i)
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)
+        for eng in self.engines[1:]:
+            eng.close()
+
+
+def run_batches(engine, seed, target_size, mean_length, write, output, shard=None, max_batch=None, in_flight=1):
     """
-    The `while total_size < target_size` loop over super-batches.  `write(bytes_like)` receives the
-    FASTQ bytes in read order on rank 0 only.  Returns (read count, total bases).
+    The `while total_size < target_size` loop (simulate.py:63-86) over super-batches of read indices.
+    `write(bytes_like)` receives the FASTQ bytes in read order on rank 0 only.  Returns (read count, total bases).
+
+    Up to `in_flight` super-batches run at once (one engine clone, stream and host thread each).  They cover
+    consecutive index ranges and are CONSUMED in index order, where the stop rule is applied, so the output does
+    not depend on `in_flight` or on the batch sizes; batches issued beyond the stopping read are discarded.  The
+    issue schedule depends only on consumed totals, so every rank of a multi-GPU run plans the same batches.
     """
+    import collections
     shard = shard or Shard()
+    max_batch = max_batch or DEFAULT_MAX_BATCH
     count = total = 0
     next_read = 0
     expected_mean = float(mean_length)
     if shard.rank == 0:
         print_progress(count, total, target_size, output)
-    while total < target_size:
-        n_super = plan_batch(target_size - total, expected_mean, shard.world, max_batch)
-        first, n_mine = shard.slice_of(next_read, n_super)
-        if n_mine:
-            out, stats = engine.simulate_batch(seed, first, n_mine, allow_nofrag=True)
-        else:
-            out, stats = np.zeros(0, np.uint8), np.zeros(0, dtype=engine.stats_dtype)
-        lens = np.concatenate(shard.gather_arrays(stats['seq_len'].astype(np.uint32) * (stats['rec_len'] > 0)))
-        failed = np.concatenate(shard.gather_arrays((stats['status'] & RS_NOFRAG).astype(np.uint8)))
-        cut = cut_point(lens, total, target_size)
-        bad = np.flatnonzero(failed)
-        fatal = len(bad) and (cut is None or bad[0] < cut)
-        last = int(bad[0]) - 1 if fatal else (cut if cut is not None else n_super - 1)
-        # bytes of my reads with global batch position <= last
-        my_lo = first - next_read
-        keep = int(np.clip(last - my_lo + 1, 0, n_mine))
-        my_bytes = out[:int(stats['rec_off'][keep - 1] + stats['rec_len'][keep - 1])] if keep else out[:0]
-        parts = shard.gather_arrays(np.ascontiguousarray(my_bytes))
-        if shard.rank == 0:
-            for part in parts:
-                if len(part):
-                    write(part)
-        used = lens[:last + 1]
-        count += int((used > 0).sum())
-        total += int(used.sum())
-        if shard.rank == 0:
-            print_progress(count, total, target_size, output)
-        if fatal:
+    pool = _BatchPool(engine, max(1, int(in_flight)))
+    pending = collections.deque()          # (slot, future, first_of_super_batch, n_super, first, n_mine)
+    fatal = False
+    try:
+        while total < target_size:
+            # keep the pipeline full: what is outstanding is assumed to deliver its expected number of bases
+            while len(pending) < len(pool):
+                outstanding = sum(p[3] for p in pending) * expected_mean
+                remaining = target_size - total - outstanding
+                if remaining <= 0 and pending:
+                    break
+                n_super = plan_batch(max(remaining, 1), expected_mean, shard.world, max_batch)
+                first, n_mine = shard.slice_of(next_read, n_super)
+                slot, fut = pool.submit(seed, first, n_mine)
+                pending.append((slot, fut, next_read, n_super, first, n_mine))
+                next_read += n_super
+            slot, fut, base, n_super, first, n_mine = pending.popleft()
+            out, stats = fut.result()
+            pool.release(slot)
+            lens = np.concatenate(shard.gather_arrays(stats['seq_len'].astype(np.uint32) * (stats['rec_len'] > 0)))
+            failed = np.concatenate(shard.gather_arrays((stats['status'] & RS_NOFRAG).astype(np.uint8)))
+            cut = cut_point(lens, total, target_size)
+            bad = np.flatnonzero(failed)
+            fatal = bool(len(bad) and (cut is None or bad[0] < cut))
+            last = int(bad[0]) - 1 if fatal else (cut if cut is not None else n_super - 1)
+            # bytes of my reads with global batch position <= last
+            my_lo = first - base
+            keep = int(np.clip(last - my_lo + 1, 0, n_mine))
+            my_bytes = out[:int(stats['rec_off'][keep - 1] + stats['rec_len'][keep - 1])] if keep else out[:0]
+            parts = shard.gather_arrays(np.ascontiguousarray(my_bytes))
             if shard.rank == 0:
-                print('\n', file=output)
-            sys.exit(NOFRAG_MESSAGE)
-        if count:
-            expected_mean = max(total / count, 1.0)
-        next_read += n_super
+                for part in parts:
+                    if len(part):
+                        write(part)
+            used = lens[:last + 1]
+            count += int((used > 0).sum())
+            total += int(used.sum())
+            if shard.rank == 0:
+                print_progress(count, total, target_size, output)
+            if fatal:
+                break
+            if count:
+                expected_mean = max(total / count, 1.0)
+    finally:
+        for slot, fut, *_ in pending:       # speculative batches past the stopping read
+            try:
+                fut.result()
+            except Exception:
+                pass
+        pool.close()
+    if fatal:
+        if shard.rank == 0:
+            print('\n', file=output)
+        sys.exit(NOFRAG_MESSAGE)
     if shard.rank == 0:
         print('\n', file=output)
     return count, total
@@ -345,7 +423,8 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
     else:                                   # a text-only stdout (e.g. captured in tests)
         def write(part):
             sys.stdout.write(bytes(part).decode('latin-1'))
-    result = run_batches(engine, seed, target_size, float(args.mean_frag_length), write, quiet, shard)
+    result = run_batches(engine, seed, target_size, float(args.mean_frag_length), write, quiet, shard,
+                         in_flight=getattr(args, 'gpu_streams', None) or DEFAULT_IN_FLIGHT)
     if sink is not None and hasattr(sink, 'flush'):
         sink.flush()
     return result

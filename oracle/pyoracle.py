@@ -127,6 +127,7 @@ class OracleEngine(EngineBase):
         super().__init__()
         self.L = lib()
         self.ctx = ctypes.c_void_p(self.L.orc_create())
+        self._structs = {}
 
     def __del__(self):
         try:
@@ -143,18 +144,37 @@ class OracleEngine(EngineBase):
     def set_reference(self, pref, cum_weight=None):
         s = self._fill_reference(pref, cum_weight)
         self.L.orc_set_reference(self.ctx, ctypes.byref(s))
+        self._structs['ref'] = s
 
     def set_error_model(self, tables):
         s = self._fill_error_model(tables)
         self.L.orc_set_error_model(self.ctx, ctypes.byref(s))
+        self._structs['em'] = s
 
     def set_qscore_model(self, tables):
         s = self._fill_qscore_model(tables)
         self.L.orc_set_qscore_model(self.ctx, ctypes.byref(s))
+        self._structs['qm'] = s
 
     def set_params(self, params):
         s = self._fill_params(params)
         self.L.orc_set_params(self.ctx, ctypes.byref(s))
+        self._structs['params'] = s
+
+    def clone(self):
+        """A second checker context over the same host tables (mirrors HipEngine.clone for the driver tests)."""
+        other = OracleEngine()
+        other._keep = dict(self._keep)
+        other.sym = self.sym
+        setters = {'ref': self.L.orc_set_reference, 'em': self.L.orc_set_error_model,
+                   'qm': self.L.orc_set_qscore_model, 'params': self.L.orc_set_params}
+        for key, s in self._structs.items():
+            setters[key](other.ctx, ctypes.byref(s))
+            other._structs[key] = s
+        return other
+
+    def close(self):
+        pass
 
     def simulate_batch(self, seed, first_read, n_reads, allow_nofrag=False):
         stats = np.zeros(n_reads, dtype=READ_STATS_DTYPE)

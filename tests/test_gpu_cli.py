@@ -82,3 +82,11 @@ def test_distributions_match_the_running_reference(tmp_path):
     """SURVEY.md 8d gate 3 on the HIP path: same check as tests/test_golden_oracle.py, engine = libbrx_hip.so."""
     import stat_parity
     stat_parity.check(H.hip_engine(), tmp_path)
+
+
+def test_gpu_streams_and_batch_size_do_not_change_the_output():
+    """Device batches in flight (engine clones on their own HIP streams) and the batch size are scheduling only."""
+    base, _ = run_cli('--gpu-streams', '1')
+    for extra in (('--gpu-streams', '3', '--gpu-batch', '16'), ('--gpu-streams', '5', '--gpu-batch', '64')):
+        out, _ = run_cli(*extra)
+        assert out == base, extra

@@ -159,3 +159,13 @@ def test_two_ranks_over_gloo_give_the_single_process_bytes(tmp_path, monkeypatch
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert open(outfile, 'rb').read() == single
+
+
+def test_batches_in_flight_do_not_change_the_output(monkeypatch):
+    """--gpu-streams: several super-batches run at once on engine clones and are consumed in index order; the bytes,
+    the read count and the stop point are those of the one-batch-at-a-time run, also when speculative batches
+    overshoot the target."""
+    base, _, count, total = run(Args(quantity='40x'), max_batch=16, monkeypatch=monkeypatch)
+    for streams, mb in ((3, 16), (4, 5), (2, 4096)):
+        got, _, c2, t2 = run(Args(quantity='40x', gpu_streams=streams), max_batch=mb, monkeypatch=monkeypatch)
+        assert got == base and (c2, t2) == (count, total), (streams, mb)
