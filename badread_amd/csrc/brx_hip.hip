@@ -39,6 +39,7 @@ struct brx_ctx {
     float stage_ms[BRX_STAGE_COUNT];
     uint32_t final_launches, mutate_passes;
     int mutate_inline;
+    int fin_balance;             /* BRX_FIN_BALANCE: 1 = the two-word band class runs on the main stream behind the one-word class */
     uint32_t seg_waves_per_cu;   /* BRX_SEG_WAVES_PER_CU: persistent waves of k_mutate_seg per CU */
     uint32_t tail_reads;         /* BRX_TAIL_READS: this few reads left in the mutate stage -> one in-place launch */
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
@@ -147,6 +148,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
+    { const char *fb = getenv("BRX_FIN_BALANCE"); c->fin_balance = fb ? atoi(fb) : 1; }
     { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
     { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 2048u; }
     { const char *sw = getenv("BRX_SEG_WAVES_PER_CU"); c->seg_waves_per_cu = sw && atoi(sw) > 0 ? (uint32_t)atoi(sw) : 8u; }
@@ -446,26 +448,35 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             if (e == b) continue;
             uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
             uint32_t *cq = counters + 16 + 16 * ((size_t)phase * BRX_MAX_CHUNKS + ci);     /* this chunk's queue heads */
-            /* wide reads are few but long: start them first on the side stream, narrow ones fill the rest of the chip */
+            /* The widest bands (8+ words per lane: a few dozen reads, but each a chain of ~100 k column steps of
+               ~2 us) and the 4-word class start first, on the side stream; the main stream aligns the one- and
+               two-word classes (most of the reads) beside them and scores those reads without waiting; the wide
+               reads are scored after the join. */
             HIPCHK(c, hipEventRecord(c->ev_fork, st));
             HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
             hipLaunchKernelGGL((k_fin_align<16, 8, 64>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, c->side,
                                dev, rs, order, b, e, cq + 0, counters + 2, phase, Fbuf, seqbuf, opsbuf, tb_base, clk);
             hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, c->side,
                                dev, rs, order, b, e, cq + 4, counters + 2, phase, Fbuf, seqbuf, opsbuf, tb_base, clk);
-            hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, c->side,
-                               dev, rs, order, b, e, cq + 1, counters + 2, phase, Fbuf, seqbuf, opsbuf, tb_base, clk);
+            if (!c->fin_balance)
+                hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, c->side,
+                                   dev, rs, order, b, e, cq + 1, counters + 2, phase, Fbuf, seqbuf, opsbuf, tb_base, clk);
             HIPCHK(c, hipEventRecord(c->ev_join, c->side));
             const bool timed = phase == 0;
             if (timed) HIPCHK(c, hipEventRecord(c->ev_a1b[ci], st));
             hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, cq + 2, counters + 2, phase,
                                Fbuf, seqbuf, opsbuf, tb_base, clk);
             if (timed) HIPCHK(c, hipEventRecord(c->ev_a1e[ci], st));
-            HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+            if (c->fin_balance)
+                hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, st,
+                                   dev, rs, order, b, e, cq + 1, counters + 2, phase, Fbuf, seqbuf, opsbuf, tb_base, clk);
             if (timed) HIPCHK(c, hipEventRecord(c->ev_qsb[ci], st));
-            hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, cq + 3, phase,
+            hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, cq + 3, phase, 1, c->fin_balance ? 2 : 1,
                                seqbuf, opsbuf, tb_base, clk);
             if (timed) HIPCHK(c, hipEventRecord(c->ev_qse[ci], st));
+            HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+            hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, st, dev, rs, order, b, e,
+                               cq + 5, phase, c->fin_balance ? 3 : 2, 0xFFFF, seqbuf, opsbuf, tb_base, clk);
         }
         if (phase == 0) { timed_chunks = chunks.size(); c->final_launches = (uint32_t)chunks.size(); }
     }

@@ -806,8 +806,8 @@ __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d,
 }
 
 __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
-                                                    uint32_t *queue, int phase, uint8_t *seqbuf, const uint8_t *opsbuf, uint8_t *tb_base,
-                                                    uint64_t *clk) {
+                                                    uint32_t *queue, int phase, int klo, int khi, uint8_t *seqbuf, const uint8_t *opsbuf,
+                                                    uint8_t *tb_base, uint64_t *clk) {
     __shared__ uint32_t qhist[256];
     const int lane = lane_id();
     const brx_qscore_model &qm = d.qm;
@@ -818,6 +818,7 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
         RS s = rs[r];
         if (s.n == 0) continue;
         if (((s.klass & BRX_KL_RETRY) != 0u) != (phase != 0)) continue;     /* window misses are scored in phase 1 */
+        if ((int)(s.klass & 0xFFFFu) < klo || (int)(s.klass & 0xFFFFu) > khi) continue;   /* band classes of this launch */
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
         const uint64_t read = d.first_read + r;
         const uint32_t n = s.n, m = s.m;

@@ -232,7 +232,7 @@ int brx_align_batch(brx_ctx *ctx, uint32_t n_pairs,
  *           k_fin_qscore, one set of launches per scratch chunk (and per phase: brx_last_window_misses)
  *   EMIT    k_recsize, k_scan_rec, k_emit, k_stats (includes one small size read-back)
  *   ALIGN1  average duration of ONE launch of k_fin_align<1,1,1> (the largest single kernel) over the chunks
- *   QSCORE  average duration of ONE launch of k_fin_qscore over the chunks                              */
+ *   QSCORE  average duration of ONE launch of k_fin_qscore for the one- and two-word band classes over the chunks */
 enum { BRX_STAGE_PLAN = 0, BRX_STAGE_BUILD = 1, BRX_STAGE_MUTATE = 2, BRX_STAGE_SCAN = 3,
        BRX_STAGE_FINAL = 4, BRX_STAGE_EMIT = 5, BRX_STAGE_ALIGN1 = 6, BRX_STAGE_QSCORE = 7, BRX_STAGE_COUNT = 8 };
 int brx_last_stage_ms(const brx_ctx *ctx, float ms[BRX_STAGE_COUNT]);

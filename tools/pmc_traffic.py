@@ -1,0 +1,34 @@
+"""profiles/pmc_traffic.json (what bench.py reports as roofline.traffic) from a per-kernel PMC summary:
+
+    python tools/pmc_traffic.py <pmc_per_kernel.csv> <reads_per_step> [kernel] > profiles/pmc_traffic.json
+
+FETCH_SIZE and WRITE_SIZE (KB) come from separate rocprofv3 passes (tools/profile_round.sh).  Per
+MI355X_MICROARCH.md (HBM section) gfx950's FETCH_SIZE tallies 128-byte requests as 64 bytes, so it is doubled;
+WRITE_SIZE is taken as reported.  The correction was calibrated there on wide streaming reads; this kernel's reads
+are narrow (target bytes, traceback words), so the read half is an upper estimate."""
+import csv
+import json
+import sys
+
+
+def main():
+    path, reads = sys.argv[1], int(sys.argv[2])
+    kernel = sys.argv[3] if len(sys.argv) > 3 else 'k_fin_align<1, 1, 1>'
+    vals = {}
+    for row in csv.DictReader(open(path)):
+        if row['kernel'].replace(' ', '') == kernel.replace(' ', '') and row['counter'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            vals[row['counter']] = (float(row.get('mean') or row.get('mean_value_KB')), int(row['dispatches']))
+    fetch, nf = vals['FETCH_SIZE']
+    write, nw = vals['WRITE_SIZE']
+    json.dump({'kernel': kernel.replace(' ', ''), 'reads_per_step': reads,
+               'FETCH_SIZE_KB_per_launch': fetch, 'WRITE_SIZE_KB_per_launch': write,
+               'hbm_bytes_per_launch': (2.0 * fetch + write) * 1024.0,
+               'note': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 2 --warmup 1 '
+                       f'--streams 1), mean over {nf} / {nw} dispatches; FETCH_SIZE doubled per MI355X_MICROARCH.md '
+                       f'(gfx950 counts 128-B requests as 64 B; calibrated for wide streaming reads only: upper estimate '
+                       f'here); WRITE_SIZE as reported (KB)'}, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == '__main__':
+    main()

@@ -18,5 +18,6 @@ for ctrs in "${@:2}"; do
       python "$root/bench.py" --steps 2 --warmup 1 --streams 1 --cpu-seconds 0 > "$out/${tag}_pmc$i.json" 2> "$out/${tag}_pmc$i.err"
 done
 python "$root/tools/pmc_summary.py" "$out/${tag}"_pmc*/*counter_collection.csv > "$out/${tag}_pmc_per_kernel.csv" 2>> "$out/${tag}_trace.err"
+python "$root/tools/pmc_traffic.py" "$out/${tag}_pmc_per_kernel.csv" 16384 > "$out/${tag}_pmc_traffic.json" 2>> "$out/${tag}_trace.err"
 rm -rf "$out/${tag}"_pmc*/ "$out/${tag}_trace"
 tail -c 600 "$out/${tag}_bench_profiled.json"; head -12 "$out/${tag}_bench_kernel_stats.csv"
