@@ -201,6 +201,7 @@ def load_library():
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m badread_amd.build` '
                            '(hipcc, --offload-arch=gfx950).  There is no CPU fallback.')
+    import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime torch ships, not a second copy
     lib = ctypes.CDLL(LIB_PATH)
     lib.brx_create.restype = ctypes.c_int
     lib.brx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]

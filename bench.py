@@ -10,13 +10,14 @@ plasmids (200 kb depth=2, 5 kb depth=10), uniform ACGT from numpy default_rng(1)
 `badread simulate` parameters (length 15000,13000; identity 95,99,2.5; nanopore2023 error and
 qscore models; default adapters, junk/random/chimera 1 %, glitches 10000,25,25), seed 42.
 A "step" is ONE pass of the whole hot path (plan -> fragments -> mutate -> align -> qscores ->
-FASTQ bytes) over one batch of `--reads-per-step` read indices per GPU through the C-ABI
-(brx_simulate_batch); the default 16384 reads x 15 kb is ~90 % of the 50x job per step, and up to
-`--streams` steps are in flight at once on separate HIP streams (one context each).  Inputs
-(packed reference, model tables) are resident in HBM before the timed region; the FASTQ bytes stay
-in HBM (the PCIe-inclusive rate is reported separately as `value_incl_d2h`).  Weak scaling: every
-rank processes its own slice [step*N*R + rank*R, +R) of the read-index space, no collective on the
-data path.
+FASTQ bytes) over one batch of `--reads-per-step` read indices per GPU (default 131072 reads x 15 kb
+~ 2 Gbases, seven times the 50x job).  The batch goes through the C-ABI as `--streams` device
+batches (brx_simulate_batch, 16384 reads each by default) that are in flight together, one context
++ HIP stream + host thread each; device batches of consecutive steps follow each other without a
+barrier, exactly as the CLI driver runs them (badread_amd.simulate.run_batches).  Inputs (packed
+reference, model tables) are resident in HBM before the timed region; the FASTQ bytes stay in HBM
+(the PCIe-inclusive rate is reported separately as `value_incl_d2h`).  Weak scaling: every rank
+processes its own slices of the read-index space, no collective on the data path.
 
 The JSON line carries `roofline` (dominant kernel, HBM bound, algorithmic bytes = 2.26 B per
 simulated base) and `cpu_baseline` (the C oracle -- a single-threaded port of
@@ -148,13 +149,14 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--reads-per-step', type=int, default=16384, help='read indices per GPU per step')
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--reads-per-step', type=int, default=131072,
+                    help='read indices per GPU per step; split into --streams device batches')
     ap.add_argument('--scratch-gb', type=float, default=30.0, help='scratch arena per in-flight batch')
     ap.add_argument('--streams', type=int, default=8,
-                    help='batches in flight per GPU (one context + HIP stream + host thread each): the slowest read '
-                         'of one batch overlaps the bulk of the next')
+                    help='device batches in flight per GPU (one context + HIP stream + host thread each): the slowest '
+                         'read of one device batch overlaps the bulk of the others')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='seconds each host core runs the cpu_baseline leg (0 = skip)')
     ap.add_argument('--d2h', action='store_true', help='also time steps that copy the FASTQ bytes to pinned host memory')
     args = ap.parse_args()
@@ -175,8 +177,8 @@ def main():
 
     from badread_amd.engine import HipEngine
     wl = build_workload(io.StringIO())
-    R = args.reads_per_step
-    C = max(1, min(args.streams, args.steps))
+    C = max(1, args.streams)
+    R = max(64, args.reads_per_step // C)              # reads per device batch (one brx_simulate_batch call)
     engines = [configure(HipEngine(local, scratch_bytes=int(args.scratch_gb * (1 << 30))), wl) for _ in range(C)]
     streams = [torch.cuda.Stream(device=local) for _ in range(C)]
     eng = engines[0]
@@ -196,8 +198,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_steps(indices):
-        """Steps `indices`, C at a time: worker i owns context i / stream i and takes every C-th step."""
+    def run_steps(step_indices):
+        """The device batches of steps `step_indices`, C in flight: worker i owns context i / stream i and takes
+        every C-th device batch; batch b of step k covers read indices ((k*C + b)*world + rank)*R ..."""
+        indices = [k * C + b for k in step_indices for b in range(C)]
         acc = [{'bases': 0, 'g1_bases': 0, 'passes': 0, 'stages': {}, 'final_launches': 0, 'misses': 0, 'error': None} for _ in range(C)]
 
         def worker(i):
@@ -266,7 +270,7 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    stages = {k: v / args.steps for k, v in stage_sum.items()}
+    stages = {k: v / (args.steps * C) for k, v in stage_sum.items()}          # per device batch
     # dominant single kernel: k_fin_align<1,1,1> (final banded Myers alignment + traceback of the reads whose band
     # fits one 32-bit word per lane); stage 'align1' is the HIP-event duration of ONE launch, averaged over launches
     kernel = 'k_fin_align<1,1,1>'
@@ -291,16 +295,16 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u64', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: 5.5 Mb K. pneumoniae-like synthetic reference (3 circular contigs), '
                                'nanopore2023 error+qscore models, default badread simulate parameters, seed 42',
-                   'reads_per_step_per_gpu': R, 'bases_per_step_per_gpu': bases_per_step_rank0,
-                   'batches_in_flight_per_gpu': C,
+                   'reads_per_step_per_gpu': R * C, 'bases_per_step_per_gpu': bases_per_step_rank0,
+                   'device_batches_per_step': C, 'reads_per_device_batch': R,
                    'parallelism': f'reads sharded by index over {world} GPU(s), reference replicated, no collectives'},
         'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                      'algorithmic_bytes_per_launch': algo_bytes, 'bases_per_launch': g1_bases_per_step / launches,
                      'launch_ms': launch_ms, 'launches_per_step': launches,
-                     'note': 'integer-ALU / latency bound path: see DESIGN.md section 5; launch_ms is the HIP-event '
-                             'duration of one launch while other batches share the GPU'},
-        'stage_ms_per_step': stages, 'mutate_passes_per_step': sum(a['passes'] for a in acc) / args.steps,
+                     'note': 'integer-ALU / latency bound path: see DESIGN.md section 5; one launch per device batch; '
+                             'launch_ms is the HIP-event duration of one launch while other batches share the GPU'},
+        'stage_ms_per_device_batch': stages, 'mutate_passes_per_device_batch': sum(a['passes'] for a in acc) / (args.steps * C),
         'traceback_window_misses_per_step': sum(a['misses'] for a in acc) / args.steps,
     }
     if d2h is not None:
