@@ -496,7 +496,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     hipLaunchKernelGGL(k_emit, dim3(n_reads), dim3(64), 0, st, dev, rs, pieces, seqbuf, d_out);
     hipLaunchKernelGGL(k_stats, dim3(nb64), dim3(64), 0, st, dev, rs, d_stats);
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_EMIT], st));
-    { int rcw = wait_stream(c, st, "k_final/k_emit"); if (rcw) return rcw; }
+    { int rcw = wait_stream(c, st, "final stage / k_emit"); if (rcw) return rcw; }
     HIPCHK(c, hipGetLastError());
     for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
         float ms = 0.f;

@@ -5,9 +5,12 @@
  * Work decomposition ("one read per wavefront"):
  *   k_plan      1 lane  = 1 read   sequential draws of build_fragment (tiny, divergent)
  *   k_build     1 wave  = 1 read   fragment bytes from the 2-bit reference, coalesced
- *   k_mutate    1 wave  = 1 read   64 k-mer proposals per step, survivors applied in lane order,
- *                                  in-loop windowed Myers alignment by the whole wave
- *   k_fin_align 1 wave  = 1 read   join -> banded Myers + traceback (one instantiation per band class)
+ *   k_mutate_seg / k_win_lane / k_win_wave   (brx_mutate.h) the mutate loop as passes: 64 k-mer proposals per
+ *                                  step, survivors applied in lane order, every 25th change a window alignment
+ *   k_mutate    1 wave  = 1 read   the same loop run whole by one wave with inline alignments: only for reads
+ *                                  whose window does not fit a pass slot
+ *   k_fin_join  1 wave  = 1 read   join of the mutated read, band class, traceback size
+ *   k_fin_align 1 wave  = 1 read   banded Myers + traceback, windowed store (one instantiation per band class)
  *   k_fin_qscore 1 wave = 1 read   qscore windows -> quals
  *   k_emit      1 wave  = 1 read   FASTQ bytes
  * Waves of the heavy kernels are persistent and pull reads (longest first) from a device queue.
@@ -706,7 +709,7 @@ __global__ void __launch_bounds__(64) k_set_tboff(uint32_t n, RS *rs, const uint
 }
 
 /* =============================================================================================
- * k_final: the tail of sequence_fragment (simulate.py:348-356) and get_qscores
+ * final stage: the tail of sequence_fragment (simulate.py:348-356) and get_qscores
  * (qscore_model.py:32-75): join the mutated read, align it against the perfect fragment, walk the
  * per-column ops to give every read base its <=k-op cigar window, look the window up with the
  * centre-preserving fallback of get_qscore (:273-287) and sample a score.
