@@ -148,14 +148,18 @@ else:
 '''
 
 
-def test_two_ranks_over_gloo_give_the_single_process_bytes(tmp_path, monkeypatch):
+@pytest.mark.parametrize('world,port', [(2, 29611), (3, 29613)])
+def test_ranks_over_gloo_give_the_single_process_bytes(tmp_path, monkeypatch, world, port):
+    """SURVEY.md 8d gate 5 / 8e: read indices sharded over `world` processes (one per GPU in production, gloo and
+    the CPU checker here), no collective on the data path, output byte-identical to the single-process run --
+    also for a world size that does not divide the batch evenly."""
     single, _, _, _ = run(Args(), max_batch=24, monkeypatch=monkeypatch)
     outfile = str(tmp_path / 'ranks.fastq')
     script = tmp_path / 'worker.py'
     script.write_text(WORKER.format(repo=os.path.dirname(HERE), outfile=outfile))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29611')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-                        '--master-addr', '127.0.0.1', '--master-port', '29611', str(script)],
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert open(outfile, 'rb').read() == single
