@@ -65,6 +65,9 @@ SIMULATE_OPTIONS = [
     ('MI355X', 'Device options (additive; no effect on the simulated reads)', [
         ('--gpu-batch', dict(type=int, default=None, dest='gpu_batch',
                              help='Maximum reads per device batch and GPU (default: 16384)')),
+        ('--gzip', dict(type=int, default=None, dest='gzip_level', metavar='LEVEL',
+                        help='Write gzip-compressed FASTQ to stdout, compressed on all host cores (level 0-9); '
+                             'default: plain text, as the reference')),
         ('--gpu-streams', dict(type=int, default=None, dest='gpu_streams',
                                help='Device batches in flight per GPU, each on its own HIP stream (default: 4)')),
     ]),

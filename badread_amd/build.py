@@ -46,16 +46,16 @@ def build(force=False, verbose=False):
 
 
 HOST_OUT = os.path.join(CSRC, 'libbrx_host.so')
-HOST_DEPS = ['brx_fasta.cpp', os.path.join('..', '..', 'include', 'brx_host.h'), os.path.join('..', '..', 'include', 'brx.h')]
+HOST_DEPS = ['brx_fasta.cpp', 'brx_gzip.cpp', os.path.join('..', '..', 'include', 'brx_host.h'), os.path.join('..', '..', 'include', 'brx.h')]
 
 
 def build_host(force=False):
-    """libbrx_host.so: the CPU-side helpers (FASTA packer); g++ + zlib, no HIP."""
+    """libbrx_host.so: the CPU-side helpers (FASTA packer, parallel gzip of the output); g++ + zlib, no HIP."""
     if not force and os.path.exists(HOST_OUT) and \
             all(os.path.getmtime(os.path.join(CSRC, d)) <= os.path.getmtime(HOST_OUT) for d in HOST_DEPS):
         return HOST_OUT
     cmd = [os.environ.get('CXX', 'g++'), '-O2', '-std=c++17', '-fPIC', '-shared', '-Wall', '-Wextra',
-           os.path.join(CSRC, 'brx_fasta.cpp'), '-o', HOST_OUT, '-lz']
+           os.path.join(CSRC, 'brx_fasta.cpp'), os.path.join(CSRC, 'brx_gzip.cpp'), '-o', HOST_OUT, '-lz', '-pthread']
     subprocess.check_call(cmd, cwd=CSRC)
     return HOST_OUT
 

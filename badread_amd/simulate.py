@@ -417,6 +417,10 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
     engine.set_params(sim_params_from_args(args, frag_lengths, identities, start_rate, start_amount,
                                            end_rate, end_amount))
     sink = stdout if stdout is not None else getattr(sys.stdout, 'buffer', None)
+    gzip_level = getattr(args, 'gzip_level', None)
+    if gzip_level is not None and sink is not None and shard.rank == 0:
+        from .output import GzipSink
+        sink = GzipSink(sink, gzip_level)          # multi-threaded gzip members (libbrx_host.so)
     if sink is not None:
         def write(part):
             sink.write(memoryview(part))

@@ -15,6 +15,8 @@
  *     plus a sorted list of maximal same-symbol runs in packed coordinates.
  * The packed form can be saved next to the FASTA and reloaded (brx_fasta_save / brx_fasta_load): the sidecar
  * records the source's size and mtime and is ignored when they no longer match.
+ *
+ * brx_gzip_* is the host output stage: multi-threaded gzip of the FASTQ bytes (see below).
  */
 #ifndef BRX_HOST_H
 #define BRX_HOST_H
@@ -55,6 +57,16 @@ void brx_fasta_free(brx_fasta *f);
  * the sidecar is missing, malformed, or was made from a file with another size or modification time */
 int brx_fasta_save(const brx_fasta *f, const char *source_path, const char *sidecar_path, char *err, size_t err_cap);
 int brx_fasta_load(const char *source_path, const char *sidecar_path, brx_fasta **out, char *err, size_t err_cap);
+
+/* ---- output stage -------------------------------------------------------------
+ * The reference prints FASTQ text (simulate.py:79-82) and its documentation pipes it through `gzip`, one core of
+ * deflate (~30 MB/s) behind a simulator that now emits GB/s.  brx_gzip_parallel compresses a buffer as a sequence
+ * of independent gzip members (RFC 1952 allows concatenation: `gzip -d`, zlib's gz* layer and Python's gzip module
+ * read the result as one stream), `block_bytes` of input per member, `threads` members at a time.
+ * Returns 0 and *out_bytes; BRX_E_OUTPUT with *out_bytes = a sufficient capacity when `cap` is too small. */
+size_t brx_gzip_bound(size_t n_bytes, size_t block_bytes);
+int brx_gzip_parallel(const uint8_t *in, size_t n_bytes, int level, int threads, size_t block_bytes,
+                      uint8_t *out, size_t cap, size_t *out_bytes);
 
 #ifdef __cplusplus
 }

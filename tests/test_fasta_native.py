@@ -129,8 +129,9 @@ def test_library_exports_every_symbol_of_brx_host_h():
     import re
     text = open(os.path.join(os.path.dirname(HERE), 'include', 'brx_host.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    names = sorted(set(re.findall(r'\b(brx_fasta_[a-z0-9_]+)\s*\(', text)))
-    assert {'brx_fasta_pack', 'brx_fasta_view_of', 'brx_fasta_free', 'brx_fasta_save', 'brx_fasta_load'} <= set(names)
+    names = sorted(set(re.findall(r'\b(brx_(?:fasta|gzip)_[a-z0-9_]+)\s*\(', text)))
+    assert {'brx_fasta_pack', 'brx_fasta_view_of', 'brx_fasta_free', 'brx_fasta_save', 'brx_fasta_load',
+            'brx_gzip_bound', 'brx_gzip_parallel'} <= set(names)
     lib = host_library()
     for name in names:
         assert getattr(lib, name) is not None, name
