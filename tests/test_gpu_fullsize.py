@@ -1,0 +1,100 @@
+"""
+BASELINE.json configs[1] at full batch size on the GPU (16384 reads of ~15 kb from the 5.5 Mb reference of bench.py),
+checked through properties that do not need the oracle at that size, plus oracle spot checks:
+
+  * batch-split invariance: one 16384-read call == two 8192-read calls, byte for byte;
+  * the windowed traceback store is invisible: the first 2048 reads with BRX_TB_WINDOW=0 (full store) and with the
+    8-row window (most reads repeat in the second phase) give the same bytes as the default window;
+  * every record is well formed: four lines, len(seq) == len(qual) == stats.seq_len, the header's length=,
+    error-free_length= and read_identity= fields equal the statistics (identity = n_match / n_cols to 3 decimals),
+    qualities inside the model's range, no status bits other than EMPTY;
+  * alignment sanity per read: n_cols >= max(fragment, read) length, distance <= number of changes applied x 58;
+  * 24 reads spread over the batch and the longest read: the oracle reproduces their records exactly.
+"""
+import io
+import re
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+N = 16384
+SEED = 42
+HEADER = re.compile(rb'length=(\d+) error-free_length=(\d+) read_identity=([0-9.]+)%$')
+
+
+@pytest.fixture(scope='module')
+def workload():
+    import bench
+    return bench, bench.build_workload(io.StringIO())
+
+
+def test_configs1_full_batch_properties(workload, monkeypatch):
+    from badread_amd.engine import HipEngine, RS_EMPTY
+    bench, wl = workload
+    eng = bench.configure(HipEngine(0, scratch_bytes=30 << 30), wl)
+    out, st = eng.simulate_batch(SEED, 0, N)
+    out, st = out.copy(), st.copy()
+    assert eng.final_launches() >= 1
+
+    # ---- batch-split invariance at full size
+    a, sa = eng.simulate_batch(SEED, 0, N // 2)
+    a, sa = a.copy(), sa.copy()
+    b, sb = eng.simulate_batch(SEED, N // 2, N // 2)
+    assert len(a) + len(b) == len(out)
+    assert H.first_diff(out[:len(a)], a) < 0 and H.first_diff(out[len(a):], b) < 0
+    for f in ('seq_len', 'n_cols', 'n_match', 'change_count', 'n_alignments', 'qerr_sum'):
+        assert (np.concatenate([sa[f], sb[f]]) == st[f]).all(), f
+
+    # ---- record structure and header fields
+    assert (st['status'] & ~np.uint32(RS_EMPTY) == 0).all()
+    live = np.flatnonzero(st['rec_len'] > 0)
+    assert len(live) > 0.99 * N
+    raw = out.tobytes()
+    total = 0
+    for r in live[:: max(1, len(live) // 4096)].tolist() + live[-3:].tolist():       # every 4th record + the last ones
+        rec = raw[int(st['rec_off'][r]): int(st['rec_off'][r]) + int(st['rec_len'][r])]
+        lines = rec.split(b'\n')
+        assert len(lines) == 5 and lines[4] == b'' and lines[0].startswith(b'@') and lines[2] == b'+'
+        L = int(st['seq_len'][r])
+        assert len(lines[1]) == L == len(lines[3]) and L > 0
+        m = HEADER.search(lines[0])
+        assert m and int(m.group(1)) == L and int(m.group(2)) == int(st['frag_len'][r])
+        ident = 100.0 * int(st['n_match'][r]) / int(st['n_cols'][r])
+        assert abs(float(m.group(3)) - ident) <= 0.00051
+        q = np.frombuffer(lines[3], dtype=np.uint8)
+        assert q.min() >= 33 and q.max() <= 33 + 93
+        assert set(lines[1]) <= set(b'ACGT')                      # the reference is pure ACGT here
+        total += L
+    assert int(st['rec_off'][live[-1]] + st['rec_len'][live[-1]]) == len(out)
+    # ---- alignment sanity
+    n = st['frag_len'].astype(np.int64)[live]
+    assert (st['n_cols'][live] >= np.maximum(n, st['padded_len'][live])).all()
+    dist = st['n_cols'].astype(np.int64)[live] - st['n_match'][live]
+    assert (dist <= st['change_count'].astype(np.int64)[live] * 58).all()
+    # identities land where the identity law puts them (mean 95, max 99)
+    ident = st['n_match'][live] / st['n_cols'][live]
+    assert 0.93 < float(np.mean(ident)) < 0.97 and float(ident.max()) <= 1.0
+
+    # ---- oracle spot checks
+    orc = bench.configure(H.oracle_engine(), wl)
+    picks = list(range(0, N, N // 24))[:24] + [int(np.argmax(st['seq_len']))]
+    for r in picks:
+        o, so = orc.simulate_batch(SEED, r, 1)
+        mine = raw[int(st['rec_off'][r]): int(st['rec_off'][r]) + int(st['rec_len'][r])]
+        assert bytes(o) == mine, f'read {r} differs from the oracle'
+        assert int(so['n_cols'][0]) == int(st['n_cols'][r]) and int(so['n_match'][0]) == int(st['n_match'][r])
+    eng.close()
+
+    # ---- the traceback window does not show in the output
+    head = raw[: int(st['rec_off'][2047] + st['rec_len'][2047])]
+    for window, want_misses in (('0', False), ('-1', True)):
+        monkeypatch.setenv('BRX_TB_WINDOW', window)
+        e2 = bench.configure(HipEngine(0, scratch_bytes=30 << 30), wl)
+        o2, s2 = e2.simulate_batch(SEED, 0, 2048)
+        assert bytes(o2) == head, f'BRX_TB_WINDOW={window}'
+        assert (e2.window_misses() > 1000) == want_misses
+        e2.close()
