@@ -394,8 +394,11 @@ __global__ void __launch_bounds__(64) k_build(BrxDev d, const RS *rs, const PSeg
         if (type == SEG_REF) {
             const brx_contig ct = d.ref.d_contigs[a];
             for (uint32_t x = lane; x < sg.len; x += 64) dst[x] = (uint8_t)ref_code_acgt(d.ref, ct, b, sg.start + x);
-            /* non-ACGT runs overlapping the forward range of this segment */
+            /* non-ACGT runs overlapping the forward range of this segment: OTHER lanes overwrite the 2-bit codes stored
+               above, so those stores must be complete first (do not lean on same-address store order across lanes) */
             if (d.ref.n_exceptions) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
                 uint64_t g0, g1;
                 if (b == 0) { g0 = ct.base_off + sg.start; g1 = g0 + sg.len; }
                 else { g1 = ct.base_off + ((uint64_t)ct.length - sg.start); g0 = g1 - sg.len; }

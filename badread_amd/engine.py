@@ -202,7 +202,12 @@ def load_library():
         raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m badread_amd.build` '
                            '(hipcc, --offload-arch=gfx950).  There is no CPU fallback.')
     import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime torch ships, not a second copy
-    lib = ctypes.CDLL(LIB_PATH)
+    _lib = bind_library(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def bind_library(lib):
+    """ctypes prototypes of every entry point of include/brx.h on an opened library."""
     lib.brx_create.restype = ctypes.c_int
     lib.brx_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     lib.brx_destroy.restype = None
@@ -243,7 +248,6 @@ def load_library():
     lib.brx_last_final_launches.argtypes = [ctypes.c_void_p]
     lib.brx_last_window_misses.restype = ctypes.c_uint32
     lib.brx_last_window_misses.argtypes = [ctypes.c_void_p]
-    _lib = lib
     return lib
 
 

@@ -1,0 +1,56 @@
+"""
+TEST INFRASTRUCTURE: the product's HIP sources interpreted on the CPU.
+
+`build()` compiles badread_amd/csrc/brx_hip.hip (+ brx_kernels.h, brx_mutate.h, brx_align.h) with g++ against
+tests/native/emu/hip/hip_runtime.h -- every lane a fiber, cross-lane operations as rendezvous, device memory = host
+memory -- into a library in a temporary directory, and `EmuEngine` drives it through the same ctypes binding as
+HipEngine (CPU torch tensors stand in for device buffers).  tests/test_emulated_device.py runs the GPU parity checks
+against it, so the kernels' logic is exercised by `pytest -m "not gpu"` too.  Nothing under badread_amd/ knows this
+exists; it is ~1000x slower than the oracle and is not a fallback.
+"""
+import ctypes
+import os
+import subprocess
+import tempfile
+
+from badread_amd import engine as E
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+_lib = None
+
+
+def build():
+    global _lib
+    if _lib is not None:
+        return _lib
+    out_dir = tempfile.mkdtemp(prefix='brx_emu_')
+    out = os.path.join(out_dir, 'libbrx_emu.so')
+    cmd = [os.environ.get('CXX', 'g++'), '-O1', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-w', '-x', 'c++',
+           '-I', os.path.join(HERE, 'native', 'emu'), '-I', os.path.join(REPO, 'include'),
+           os.path.join(REPO, 'badread_amd', 'csrc', 'brx_hip.hip'), '-o', out]
+    subprocess.check_call(cmd)
+    _lib = E.bind_library(ctypes.CDLL(out))
+    return _lib
+
+
+class EmuEngine(E.HipEngine):
+    """HipEngine's binding over the emulated library; buffers are CPU tensors."""
+
+    def __init__(self, scratch_bytes=1 << 28):
+        E.EngineBase.__init__(self)
+        import torch
+        self.torch = torch
+        self.device = torch.device('cpu')
+        self.lib = build()
+        ctx = ctypes.c_void_p()
+        rc = self.lib.brx_create(0, ctypes.byref(ctx))
+        if rc != 0:
+            raise E.BrxError(rc, self.lib.brx_last_error(None).decode('latin-1', 'replace'))
+        self.ctx = ctx
+        self._scratch = self._out = self._stats = None
+        self._structs = {}
+        self._ensure_scratch(scratch_bytes)
+
+    def _stream(self):
+        return ctypes.c_void_p(None)

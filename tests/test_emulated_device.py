@@ -1,0 +1,139 @@
+"""
+The product's HIP sources run on the CPU (tests/emu_engine.py, tests/native/emu/hip/hip_runtime.h: lanes as fibers,
+cross-lane operations as rendezvous) and held to the same parity bar as on the GPU: bit-identical to the oracle
+through the C-ABI.  This is the `-m "not gpu"` counterpart of tests/test_gpu_align.py / test_gpu_pipeline.py /
+test_gpu_golden.py -- it cannot say anything about speed, occupancy or memory-ordering on real hardware, but a logic
+error in a kernel (band geometry, LDS ring indexing, traceback addressing, the mutate pass state machine, the
+windowed traceback store and its retry phase) fails here without a GPU.
+"""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+import pyoracle
+from badread_amd.engine import SimParams
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STAT_FIELDS = ('status', 'frag_len', 'seq_len', 'n_cols', 'n_match', 'padded_len', 'loop_count', 'change_count',
+               'n_alignments', 'rec_len', 'rec_off', 'target_identity', 'qerr_sum')
+
+
+def emu_engine(monkeypatch=None, scratch=1 << 29, **env):
+    import emu_engine as EE
+    if monkeypatch is not None:
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+    return EE.EmuEngine(scratch)
+
+
+def check_pairs(eng, queries, targets, k_hint=None):
+    ops, dist, ncols, nmatch = eng.align_batch(queries, targets, k_hint=k_hint)
+    for i, (q, t) in enumerate(zip(queries, targets)):
+        d, o = pyoracle.align(q, t)
+        assert dist[i] == d, (i, len(q), len(t), int(dist[i]), d)
+        assert np.array_equal(ops[i], o), (i, len(q), len(t))
+        assert ncols[i] == len(o) and nmatch[i] == int((o == 0).sum())
+
+
+def test_aligner_small_pairs_and_edge_cases():
+    eng = emu_engine()
+    rng = np.random.default_rng(11)
+    qs, ts = [b'', b'ACGT', b'', b'A', b'CG', b'GATTACA', b'A' * 128, b'A' * 40, b'ACGT' * 8], \
+             [b'', b'', b'TTGA', b'A', b'CGT', b'GATACA', b'C' * 28, b'C' * 8, b'ACGT' * 7]
+    for _ in range(60):
+        n = int(rng.choice([1, 2, 5, 31, 32, 33, 64, 65, 100, 257, 700]))
+        q = H.random_dna(rng, n)
+        t = H.mutate_seq(rng, q, float(rng.choice([0.0, 0.03, 0.15, 0.4]))) or 'A'
+        qs.append(q.encode()); ts.append(t.encode())
+    check_pairs(eng, qs, ts)
+
+
+def test_aligner_band_classes_iupac_and_hints():
+    eng = emu_engine()
+    rng = np.random.default_rng(12)
+    qs, ts, hints = [], [], []
+    # one word per lane with four columns per trip (long ring refills), two and four words per lane (wide bands)
+    for n, rate in ((3000, 0.05), (2600, 0.30), (5200, 0.33), (1000, 0.9)):
+        q = H.random_dna(rng, n)
+        t = H.mutate_seq(rng, q, rate)
+        qs.append(q.encode()); ts.append(t.encode()); hints.append(-1)
+    # very different lengths (the band is all offset), symbols outside ACGT (rare equality path)
+    qs += [H.random_dna(rng, 1000).encode(), H.random_dna(rng, 300, 'ACGTNRYK').encode()]
+    ts += [H.random_dna(rng, 2794).encode(), H.random_dna(rng, 320, 'ACGTNRYK').encode()]
+    hints += [-1, -1]
+    check_pairs(eng, qs, ts)
+    # a proven bound given by the caller: one round, same path
+    d = [pyoracle.align(q, t)[0] for q, t in zip(qs[:2], ts[:2])]
+    check_pairs(eng, qs[:2], ts[:2], k_hint=[d[0] + 7, d[1]])
+
+
+ROUTES = [
+    {},                                                        # defaults: in-place tail (few reads), windowed store
+    {'BRX_TAIL_READS': 0, 'BRX_LANE_THRESHOLD': 0},            # passes: every window through the lane kernel
+    {'BRX_TAIL_READS': 0, 'BRX_LANE_THRESHOLD': 1000000},      # passes: every window through the wave kernel
+    {'BRX_TB_WINDOW': -1},                                     # 8-row traceback window: most reads repeat (phase 1)
+    {'BRX_TB_WINDOW': 0, 'BRX_FIN_BALANCE': 0},                # full store, wide classes all on the side stream
+]
+
+
+@pytest.mark.parametrize('env', ROUTES)
+def test_pipeline_routes_equal_the_oracle(env, monkeypatch):
+    pref, _ = H.small_reference()
+    p = SimParams(frag_mean=1100, frag_stdev=900)
+    eng = H.configure(emu_engine(monkeypatch, **env), pref, 'nanopore2023', 'nanopore2023', p)
+    orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
+    n = 40
+    out_h, st_h = eng.simulate_batch(42, 0, n)
+    out_o, st_o = orc.simulate_batch(42, 0, n)
+    for f in STAT_FIELDS:
+        assert (st_h[f] == st_o[f]).all(), (env, f)
+    assert H.first_diff(out_h, out_o) < 0, env
+    if env.get('BRX_TB_WINDOW') == -1:
+        assert eng.window_misses() >= 3                     # the retry phase ran (short reads: few windows are narrower than the band)
+    if env.get('BRX_TAIL_READS') == 0:
+        assert eng.mutate_passes() > 3
+
+
+def test_pipeline_other_models_and_fragment_kinds():
+    """random / ideal models (k = 1), low identity, chimeras, junk and random reads, glitches, N runs and hairpins."""
+    pref, _ = H.small_reference(with_n=True)
+    p = SimParams(frag_mean=700, frag_stdev=0, identity_mode=0, id_max=0.88, glitch_rate=400, glitch_size=10, glitch_skip=10,
+                  chimera_rate=0.2, junk_rate=0.1, random_rate=0.1)
+    for em, qm, seed in (('random', 'random', 7), ('pacbio2021', 'pacbio2021', 9)):
+        eng = H.configure(emu_engine(), pref, em, qm, p)
+        orc = H.configure(H.oracle_engine(), pref, em, qm, p)
+        out_h, st_h = eng.simulate_batch(seed, 100, 30)
+        out_o, st_o = orc.simulate_batch(seed, 100, 30)
+        for f in STAT_FIELDS:
+            assert (st_h[f] == st_o[f]).all(), (em, f)
+        assert H.first_diff(out_h, out_o) < 0, em
+
+
+def test_sequence_fragment_golden_vectors_from_the_running_reference():
+    """tests/golden/sequence_fragment.json.gz (the reference's own sequence_fragment replayed with our draws) through the
+    emulated device: every case up to 4 kb (N-containing fragments, every model pair)."""
+    with gzip.open(os.path.join(HERE, 'golden', 'sequence_fragment.json.gz'), 'rt') as f:
+        g = json.load(f)
+    eng = emu_engine()
+    pref, _ = H.small_reference()
+    H.configure(eng, pref)
+    models, n = None, 0
+    for c in sorted(g['cases'], key=lambda c: (c['em'], c['qm'])):
+        if len(c['fragment']) > 4000:
+            continue
+        if models != (c['em'], c['qm']):
+            models = (c['em'], c['qm'])
+            eng.set_error_model(H.error_tables(c['em']))
+            eng.set_qscore_model(H.qscore_tables(c['qm']))
+        codes = np.array(['ACGTN'.index(ch) for ch in c['fragment']], dtype=np.uint8)
+        res, st = eng.sequence_fragments(c['seed'], c['read'], [codes], [c['target']])
+        tag = (c['em'], c['qm'], len(c['fragment']), c['target'])
+        assert ''.join('ACGTN'[x] for x in res[0][0]) == c['seq'], tag
+        assert res[0][1].tobytes().decode() == c['qual'], tag
+        assert st['n_match'][0] / st['n_cols'][0] == c['identity'], tag
+        n += 1
+    assert n >= 15
