@@ -261,8 +261,9 @@ class _BatchPool(object):
         self.engines = [engine]
         self.streams = [None]
         if in_flight > 1 and hasattr(engine, 'clone'):
-            torch = getattr(engine, 'torch', None)           # absent on the tests' CPU checker engine
-            self.streams = [torch.cuda.Stream(device=engine.device) if torch else None for _ in range(in_flight)]
+            torch = getattr(engine, 'torch', None)           # absent on the tests' CPU checker engines
+            on_gpu = torch is not None and getattr(engine, 'device', None) is not None and engine.device.type == 'cuda'
+            self.streams = [torch.cuda.Stream(device=engine.device) if on_gpu else None for _ in range(in_flight)]
             self.engines += [engine.clone() for _ in range(in_flight - 1)]
         self.free = list(range(len(self.engines)))
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=len(self.engines)) if len(self.engines) > 1 else None

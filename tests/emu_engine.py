@@ -54,3 +54,15 @@ class EmuEngine(E.HipEngine):
 
     def _stream(self):
         return ctypes.c_void_p(None)
+
+    def clone(self, scratch_bytes=None):
+        """Second context over the same tables (what HipEngine.clone does for batches in flight)."""
+        other = EmuEngine(scratch_bytes or self._scratch.numel())
+        other._keep = dict(self._keep)
+        other.sym = self.sym
+        setters = {'ref': self.lib.brx_set_reference, 'em': self.lib.brx_set_error_model,
+                   'qm': self.lib.brx_set_qscore_model, 'params': self.lib.brx_set_params}
+        for key, st in self._structs.items():
+            other._check(setters[key](other.ctx, ctypes.byref(st)))
+            other._structs[key] = st
+        return other

@@ -40,7 +40,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
-#define __shared__ static            /* one workgroup runs at a time: a static IS the workgroup's LDS */
+#define __shared__ static thread_local   /* one workgroup runs at a time per host thread: a static IS its LDS */
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint2 { unsigned x, y; };
@@ -65,7 +65,7 @@ struct State {
     unsigned long long spins = 0;
     unsigned long long clock = 0;
 };
-inline State &S() { static State s; return s; }
+inline State &S() { static thread_local State s; return s; }     /* host threads (contexts in flight) do not share it */
 
 inline void yield_to_scheduler() { State &s = S(); swapcontext(&s.lane_ctx[s.cur], &s.sched); }
 

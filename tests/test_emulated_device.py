@@ -137,3 +137,18 @@ def test_sequence_fragment_golden_vectors_from_the_running_reference():
         assert st['n_match'][0] / st['n_cols'][0] == c['identity'], tag
         n += 1
     assert n >= 15
+
+
+def test_driver_on_the_emulated_device_equals_the_oracle_driver(monkeypatch):
+    """`badread simulate` end to end (reference loading, depth adjustment, stop rule, batches in flight on engine clones)
+    with the emulated device as the engine: the FASTQ stream of the oracle-driven run, byte for byte."""
+    import io
+    from badread_amd import simulate as S
+    from test_host_simulate import Args
+    monkeypatch.setattr(S, 'DEFAULT_MAX_BATCH', 12)
+    args = dict(quantity='6x', mean_frag_length=350.0, frag_length_stdev=250.0, error_model='nanopore2023',
+                qscore_model='nanopore2023', mean_identity=92.0, max_identity=98.0, identity_stdev=3.0, seed=3)
+    a, b = io.BytesIO(), io.BytesIO()
+    S.simulate(Args(gpu_streams=3, **args), output=io.StringIO(), engine=emu_engine(), stdout=a, shard=S.Shard())
+    S.simulate(Args(gpu_streams=1, **args), output=io.StringIO(), engine=H.oracle_engine(), stdout=b, shard=S.Shard())
+    assert a.getvalue() == b.getvalue() and a.getvalue().count(b'\n') >= 4 * 20
