@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
                     uint32_t w = wave_bcast_u32(mine, l);
                     if (!w) continue;
                     uint64_t pos = i0 + (uint64_t)j;
-                    uint32_t cur = rp[pos];
+                    const uint32_t cur = uni(rp[pos]);      /* every lane has loaded before lane 0 stores below */
                     if (cur) continue;
                     if (lane == 0) rp[pos] = w;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

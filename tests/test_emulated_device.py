@@ -152,3 +152,35 @@ def test_driver_on_the_emulated_device_equals_the_oracle_driver(monkeypatch):
     S.simulate(Args(gpu_streams=3, **args), output=io.StringIO(), engine=emu_engine(), stdout=a, shard=S.Shard())
     S.simulate(Args(gpu_streams=1, **args), output=io.StringIO(), engine=H.oracle_engine(), stdout=b, shard=S.Shard())
     assert a.getvalue() == b.getvalue() and a.getvalue().count(b'\n') >= 4 * 20
+
+
+def test_window_overflow_goes_through_the_whole_read_kernel(tmp_path):
+    """A synthetic error model whose alternatives insert 60 bases: the joined 1000-base windows outgrow their pass slots
+    (BRX_WIN_TMAX), so those reads are handed to the whole-read kernel k_mutate with inline alignments -- a route no
+    packaged model reaches.  Mutated reads of 17x the fragment length also push the final alignment into the widest
+    band classes (8 and 16 words per lane)."""
+    import io
+    import itertools
+    from badread_amd.error_model import ErrorModel
+    rng = np.random.default_rng(4)
+    lines = []
+    for kmer in map(''.join, itertools.product('ACGT', repeat=3)):
+        ins = ''.join(rng.choice(list('ACGT'), 60))
+        lines.append(f'{kmer},0.2;{kmer[0]}{kmer[1]}{ins}{kmer[2]},0.6;{kmer[0]}{kmer[2]},0.2;\n')
+    path = tmp_path / 'big_insertions_model'
+    path.write_text(''.join(lines))
+    tables = ErrorModel(str(path), io.StringIO(), aligner=pyoracle.oracle_align_batch, use_cache=False).tables()
+    pref, _ = H.small_reference()
+    eng, orc = H.configure(emu_engine(), pref), H.configure(H.oracle_engine(), pref)
+    for e in (eng, orc):
+        e.set_error_model(tables)
+        e.set_qscore_model(H.qscore_tables('ideal'))
+    frags = [rng.integers(0, 4, n).astype(np.uint8) for n in (900, 400)]
+    targets = [0.05, 0.3]
+    rh, sh = eng.sequence_fragments(9, 0, frags, targets)
+    ro, so = orc.sequence_fragments(9, 0, frags, targets)
+    for f in STAT_FIELDS:
+        assert (sh[f] == so[f]).all(), f
+    for a, b in zip(rh, ro):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert int(sh["padded_len"][0]) > 8 * 900                      # the windows really overflowed
