@@ -15,30 +15,35 @@ from .misc import float_to_str, print_in_two_columns
 
 
 class FragmentLengths(object):
+    """mean / stdev of the fragment-length law; `gamma_k`, `gamma_t` are None for a constant length."""
 
     def __init__(self, mean, stdev, output=sys.stderr):
-        self.mean = mean
-        self.stdev = stdev
+        self.mean, self.stdev = mean, stdev
+        self.gamma_k = self.gamma_t = None
+        constant = stdev == 0
+        if not constant:
+            shape, rate, self.gamma_k, self.gamma_t = gamma_parameters(mean, stdev)
+        self._announce(output, None if constant else (shape, rate))
+
+    def _announce(self, output, shape_rate):
+        """The banner of the reference (fragment_lengths.py:28-43), minus its ASCII histogram."""
         print('', file=output)
-        if self.stdev == 0:
-            self.gamma_k, self.gamma_t = None, None
-            print(f'Using a constant fragment length of {mean} bp', file=output)
-        else:
-            print('Generating fragment lengths from a gamma distribution:', file=output)
-            gamma_a, gamma_b, self.gamma_k, self.gamma_t = gamma_parameters(mean, stdev)
-            n50 = int(round(find_n_value(gamma_a, gamma_b, 50)))
-            print_in_two_columns(f'  mean  = {float_to_str(mean):>6} bp',
-                                 f'  stdev = {float_to_str(stdev):>6} bp',
-                                 f'  N50   = {n50:>6} bp',
-                                 'parameters:',
-                                 f'  k (shape)     = {self.gamma_k:.4e}',
-                                 f'  theta (scale) = {self.gamma_t:.4e}',
-                                 output=output)
+        if shape_rate is None:
+            print(f'Using a constant fragment length of {self.mean} bp', file=output)
+            return
+        print('Generating fragment lengths from a gamma distribution:', file=output)
+        n50 = int(round(find_n_value(shape_rate[0], shape_rate[1], 50)))
+        left = [f'  {label} = {value:>6} bp' for label, value in
+                (('mean ', float_to_str(self.mean)), ('stdev', float_to_str(self.stdev)), ('N50  ', n50))]
+        right = ['parameters:', f'  k (shape)     = {self.gamma_k:.4e}', f'  theta (scale) = {self.gamma_t:.4e}']
+        print_in_two_columns(*left, *right, output=output)
 
     def get_fragment_length(self):
-        if self.stdev == 0:
+        """One draw with the reference's rounding: numpy's global gamma, Python round(), at least 1."""
+        if self.gamma_k is None:
             return int(round(self.mean))
-        return max(int(round(np.random.gamma(self.gamma_k, self.gamma_t))), 1)
+        drawn = np.random.gamma(self.gamma_k, self.gamma_t)
+        return max(1, int(round(drawn)))
 
     def sample_many(self, count, rng):
         """`count` draws with the same law, from a caller-owned numpy RandomState (adjust_depths)."""
