@@ -146,6 +146,27 @@ def str_is_dna_sequence(s):
     return set(s) <= set('ACGT')
 
 
+def only_acgt(s):
+    """True when every character is an upper-case A, C, G or T (misc.py:205-206); the empty string passes."""
+    return not set(s) - set('ACGT')
+
+
+def get_sequence_file_type(filename):
+    """'FASTA' or 'FASTQ' from the first character of a plain or gzipped file (misc.py:74-94)."""
+    import os
+    if not os.path.isfile(filename):
+        sys.exit('Error: could not find {}'.format(filename))
+    with get_open_func(filename)(filename, 'rt') as handle:
+        try:
+            first = handle.read(1)
+        except UnicodeDecodeError:
+            first = ''
+    kinds = {'>': 'FASTA', '@': 'FASTQ'}
+    if first not in kinds:
+        raise ValueError('File is neither FASTA or FASTQ')
+    return kinds[first]
+
+
 _CIGAR_RE = re.compile(r'(\d+)([IDX=])')
 
 

@@ -50,6 +50,20 @@ def print_intro(output):
 
 
 def load_reference(reference, output):
+    """The reference's function (simulate.py:494-507), same return value: (seqs, depths, circular, hairpin_left,
+    hairpin_right) as Python dicts, after printing the summary.  The driver itself uses load_packed_reference."""
+    from .misc import load_fasta
+    print(f'\nLoading reference from {reference}', file=output)
+    seqs, depths, circular, hp_left, hp_right = load_fasta(reference)
+    print(f'  {len(seqs):,} contig{"" if len(seqs) == 1 else "s"}:', file=output)
+    for name, seq in seqs.items():
+        print(f'    {name}: {len(seq):,} bp, {"circular" if circular[name] else "linear"}, {depths[name]:.2f}x depth', file=output)
+    if len(seqs) > 1:
+        print(f'  total size: {sum(len(v) for v in seqs.values()):,} bp', file=output)
+    return seqs, depths, circular, hp_left, hp_right
+
+
+def load_packed_reference(reference, output):
     """FASTA(.gz) -> PackedReference through the native packer (libbrx_host.so, csrc/brx_fasta.cpp), with the
     reference's summary lines (simulate.py:494-507)."""
     print(f'\nLoading reference from {reference}', file=output)
@@ -392,7 +406,7 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
         seed = _broadcast_seed(shard, seed)
     random.seed(seed)
     host_rng = np.random.RandomState(seed % (2 ** 32))
-    pref = load_reference(args.reference, quiet)
+    pref = load_packed_reference(args.reference, quiet)
     frag_lengths = FragmentLengths(args.mean_frag_length, args.frag_length_stdev, quiet)
     depths = adjust_depths(pref, frag_lengths, args.small_plasmid_bias, host_rng)
     identities = Identities(args.mean_identity, args.identity_stdev, args.max_identity, quiet)
