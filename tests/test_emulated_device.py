@@ -184,3 +184,18 @@ def test_window_overflow_goes_through_the_whole_read_kernel(tmp_path):
     for a, b in zip(rh, ro):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert int(sh["padded_len"][0]) > 8 * 900                      # the windows really overflowed
+
+
+def test_final_stage_in_several_scratch_chunks(monkeypatch):
+    """A scratch arena that holds the largest traceback store but not all of them: the final stage runs in several
+    chunks over the same arena; same bytes."""
+    pref, _ = H.small_reference()
+    p = SimParams(frag_mean=5000, frag_stdev=2000)
+    eng = H.configure(emu_engine(monkeypatch, scratch=24 << 20, BRX_TB_WINDOW=0), pref, 'nanopore2023', 'nanopore2023', p)
+    orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
+    out_h, st_h = eng.simulate_batch(8, 0, 28)
+    out_o, st_o = orc.simulate_batch(8, 0, 28)
+    assert eng.final_launches() >= 2, eng.final_launches()
+    for f in STAT_FIELDS:
+        assert (st_h[f] == st_o[f]).all(), f
+    assert H.first_diff(out_h, out_o) < 0
