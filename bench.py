@@ -292,7 +292,7 @@ def main():
     result = {
         'metric': 'simulated bases/sec', 'value': value, 'unit': 'bases/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u64', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: 5.5 Mb K. pneumoniae-like synthetic reference (3 circular contigs), '
                                'nanopore2023 error+qscore models, default badread simulate parameters, seed 42',
                    'reads_per_step_per_gpu': R * C, 'bases_per_step_per_gpu': bases_per_step_rank0,
