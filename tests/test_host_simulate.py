@@ -148,11 +148,19 @@ else:
 '''
 
 
-@pytest.mark.parametrize('world,port', [(2, 29611), (3, 29613)])
-def test_ranks_over_gloo_give_the_single_process_bytes(tmp_path, monkeypatch, world, port):
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_ranks_over_gloo_give_the_single_process_bytes(tmp_path, monkeypatch, world):
     """SURVEY.md 8d gate 5 / 8e: read indices sharded over `world` processes (one per GPU in production, gloo and
     the CPU checker here), no collective on the data path, output byte-identical to the single-process run --
     also for a world size that does not divide the batch evenly."""
+    port = _free_port()
     single, _, _, _ = run(Args(), max_batch=24, monkeypatch=monkeypatch)
     outfile = str(tmp_path / 'ranks.fastq')
     script = tmp_path / 'worker.py'
