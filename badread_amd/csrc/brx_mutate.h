@@ -46,6 +46,39 @@ struct MS {                       /* loop state of a parked read */
 
 enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WORDS = 8 };
 
+/* Park a window in ONE pass: qb[0, b-a) = F[a:b] (+16 bytes 0xFF), tbuf[0, tl) = join(new_fragment_bases[a:b]) clipped
+ * to `tmax` bytes (+16 bytes 0xFE when it fits), *cost = edit bound of the pair, *odd = a symbol outside ACGT on either
+ * side (wave-uniform).  Returns the joined length tl (may exceed tmax: the caller hands the read to k_mutate). */
+__device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F, const uint32_t *repl, uint32_t a, uint32_t b,
+                                     uint8_t *qb, uint8_t *tbuf, uint32_t tmax, uint32_t *cost, bool *odd) {
+    const int lane = lane_id();
+    uint32_t run = 0, c = 0;
+    bool o_ = false;
+    for (uint32_t base = a; base < b; base += 64) {
+        const uint32_t p = base + lane;
+        const bool valid = p < b;
+        uint32_t w = 0, len = 0;
+        uint8_t fb = 0xFF;
+        if (valid) { fb = F[p]; w = repl[p]; len = rep_len(w); c += rep_cost(w); qb[p - a] = fb; o_ |= fb > 3; }
+        const uint32_t inc = wave_incl_scan(len);
+        if (valid) {
+            const uint32_t o = run + inc - len;
+            if (!w) { if (o < tmax) tbuf[o] = fb; }
+            else for (uint32_t x = 0; x < len; ++x) {
+                const uint8_t ch = rep_char(em, w, x);
+                o_ |= ch > 3;
+                if (o + x < tmax) tbuf[o + x] = ch;
+            }
+        }
+        run += wave_bcast_u32(inc, 63);
+    }
+    const uint32_t ql = b - a;
+    for (uint32_t x = lane; x < 16; x += 64) { qb[ql + x] = 0xFF; if (run <= tmax) tbuf[run + x] = 0xFE; }
+    *cost = wave_sum(c);
+    *odd = __ballot(o_) != 0ull;
+    return run;
+}
+
 /* -------------------------------------------------------------------------------------------------
  * k_mutate_seg
  * ----------------------------------------------------------------------------------------------- */
@@ -168,26 +201,20 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
                         }
                         nalign += 1;
                         __builtin_amdgcn_s_waitcnt(0);
+                        /* one pass over the window: F[a:b] -> query slot, join(new[a:b]) -> target slot (clipped to the
+                           slot; an overflowing window goes to the whole-read kernel), edit bound, non-ACGT flag */
                         uint32_t cost = 0;
-                        const uint32_t tl = wave_join(em, F, rp, a, b, nullptr, &cost);
+                        uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+                        bool odd = false;
+                        const uint32_t tl = wave_park(em, F, rp, a, b, qb, tbuf, BRX_WIN_TMAX, &cost, &odd);
                         const uint32_t ql = b - a;
                         uint32_t klass = MC_LEGACY;
                         if (tl <= BRX_WIN_TMAX) {
-                            uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
-                            bool odd = false;                       /* a symbol outside ACGT anywhere in the pair */
-                            for (uint32_t x = lane; x < ql + 16; x += 64) {
-                                const uint8_t c = x < ql ? F[a + x] : 0xFF;
-                                qb[x] = c;
-                                odd |= x < ql && c > 3;
-                            }
-                            for (uint32_t x = lane; x < 16; x += 64) tbuf[tl + x] = 0xFE;
-                            wave_join(em, F, rp, a, b, tbuf, nullptr);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             __builtin_amdgcn_s_waitcnt(0);
-                            for (uint32_t x = lane; x < tl; x += 64) odd |= tbuf[x] > 3;
                             const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
                             const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
-                            const bool easy = !INLINE && __ballot(odd) == 0ull && g.G == 1 && band_blocks <= BRX_LANE_W &&
+                            const bool easy = !INLINE && !odd && g.G == 1 && band_blocks <= BRX_LANE_W &&
                                               tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 && n_in > lane_threshold;
                             klass = easy ? MC_EASY : MC_HARD;
                         }
