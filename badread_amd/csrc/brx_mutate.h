@@ -387,13 +387,28 @@ __global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, c
             const uint32_t m0 = 0u - c0, m1 = 0u - c1;
             uint32_t hp = 1u, hm = 0u;
             uint2 *dstj = tbw + ((uint64_t)j * BRX_LANE_W) * 64u + (uint32_t)lane;
-            for (int x = 0; x < Wb; ++x) {
+            /* all band words of this column are fetched from LDS first (independent loads, one latency), the carry
+               chain then runs in registers, and the words go back: the loop used to pay ~6 dependent LDS round trips
+               per word with one wave per SIMD and nothing to hide them */
+            uint32_t P[BRX_LANE_W], M[BRX_LANE_W], QL[BRX_LANE_W], QH[BRX_LANE_W];
+#pragma unroll
+            for (int x = 0; x < BRX_LANE_W; ++x) {
+                const int sb = s_lo + x;
+                const bool on = act && x < Wb && sb <= s_hi;
+                const int sbc = on ? sb : 0;
+                const int slot = sbc & (BRX_LANE_W - 1);
+                P[x] = st_pv[slot][lane]; M[x] = st_mv[slot][lane];
+                QL[x] = q_lo[sbc][lane]; QH[x] = q_hi[sbc][lane];
+            }
+#pragma unroll
+            for (int x = 0; x < BRX_LANE_W; ++x) {
+                if (x >= Wb) break;
                 const int sb = s_lo + x;
                 const bool on = act && sb <= s_hi;
                 const int sbc = on ? sb : 0;
                 const int slot = sbc & (BRX_LANE_W - 1);
-                uint32_t pv = st_pv[slot][lane], mv = st_mv[slot][lane];
-                uint32_t Eq = ~((q_lo[sbc][lane] ^ m0) | (q_hi[sbc][lane] ^ m1));
+                uint32_t pv = P[x], mv = M[x];
+                uint32_t Eq = ~((QL[x] ^ m0) | (QH[x] ^ m1));
                 if (sbc == NS - 1) Eq &= lastmask;
                 const uint32_t Xv = Eq | mv;
                 const uint32_t Eq2 = Eq | hm;
