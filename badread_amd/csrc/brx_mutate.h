@@ -85,16 +85,28 @@ __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F
 /* INLINE = false: park at every alignment (bulk passes).  INLINE = true: align in place with the
  * wave-systolic aligner and run every read to completion (the last few reads of a batch, where a
  * host round trip per alignment would cost more than the alignment). */
-template <bool INLINE>
+/* PROFILE = true (BRX_PROFILE=1): shader-clock time of every phase of the loop is added to phase[8 r + i]:
+ *   0 propose (draws, k-mer bytes, table lookups)   1 apply survivors   2 park (window join + copies, state)
+ *   3 in-place alignment (INLINE)   4 everything else   5 / 6 forward / traceback part of 3
+ * The phase clock is wave-uniform scalar code; the default instantiations do not contain it. */
+#define BRX_PHASE(next)                                                                                          \
+    do { if constexpr (PROFILE) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); const uint64_t dt_ = now_ - ph_last;  \
+             ph_last = now_; ph0 += ph_cur == 0 ? dt_ : 0; ph1 += ph_cur == 1 ? dt_ : 0; ph2 += ph_cur == 2 ? dt_ : 0;   \
+             ph3 += ph_cur == 3 ? dt_ : 0; ph4 += ph_cur == 4 ? dt_ : 0; ph_cur = (next); } } while (0)
+
+template <bool INLINE, bool PROFILE = false>
 __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
                                                     const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,
                                                     uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
                                                     const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk,
-                                                    uint32_t lane_threshold, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags) {
+                                                    uint32_t lane_threshold, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags,
+                                                    uint64_t *phase) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
     const uint32_t n_in = uni(*n_in_ptr);
+    uint64_t ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph_last = 0, pclk[2] = {0, 0};
+    int ph_cur = 4;
     for (;;) {
         const uint32_t qi = wave_pop(&ctr[MC_QUEUE]);
         if (qi >= n_in) break;
@@ -102,6 +114,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
         const RS s = rs[r];
         if (s.n == 0) continue;
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        if constexpr (PROFILE) { ph0 = ph1 = ph2 = ph3 = ph4 = 0; pclk[0] = pclk[1] = 0; ph_last = t_begin; ph_cur = 4; }
         MS ms = msv[r];
         const uint64_t read = d.first_read + r;
         const uint32_t n = s.n;
@@ -145,6 +158,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
             const uint64_t room = loop_cap - loops;
             const uint32_t B = room < 64 ? (uint32_t)room : 64u;
             /* ---- propose (identical draws on a resumed round) ---- */
+            BRX_PHASE(0);
             uint32_t rep[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) rep[j] = 0;
@@ -160,6 +174,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
                 live = dev_choose_alt(em, kmer, w[2], w[3], rep);
             }
             unsigned long long surv = __ballot(live);
+            BRX_PHASE(1);
             int j0 = 0;
             if (resume) { surv &= ~((1ull << ms.surv_lane) - 1ull); j0 = (int)ms.j_next; }
             bool first = resume;
@@ -192,6 +207,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
                     errors += (double)(len < 2 ? 1u : len - 1u) * scale;
                     if (change % BRX_ALIGN_INTERVAL == 0) {
                         /* ---- park the read: the window pair goes to its slot, the loop state to MS ---- */
+                        BRX_PHASE(2);
                         uint32_t a = 0, b = n;
                         if (n > BRX_ALIGN_SIZE) {
                             uint32_t ww[4];
@@ -249,13 +265,16 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
             loops += B;
             if (B < 64) { loops += 1; break; }
         }
+        BRX_PHASE(4);
         if (INLINE && parked && ms.phase == 1u) {
             /* align the parked window here, at the top level where only MS is live, and resume the same read */
             const uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
             uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)blockIdx.x * scr_bytes);
             int ncols = 0, nmatch = 0; bool nospace = false;
+            BRX_PHASE(3);
             const bool ok = brx_wave_align<1>(qb, (int)(ms.win_b - ms.win_a), tbuf, (int)ms.tl, (int)ms.cost, tb, scr_bytes / 8, nullptr,
-                                              &ncols, &nmatch, &nospace);
+                                              &ncols, &nmatch, &nospace, nullptr, PROFILE ? pclk : nullptr);
+            BRX_PHASE(4);
             ms.res_ncols = (uint32_t)ncols; ms.res_nmatch = (uint32_t)nmatch;
             if (!ok && !nospace) ms.status |= BRX_RS_BAND;
             if (nospace && lane == 0) atomicOr(&flags[0], 1u);
@@ -264,6 +283,13 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
         break;
       }
         uint64_t *ck = clk + (uint64_t)r * 8;
+        if constexpr (PROFILE) {
+            BRX_PHASE(4);
+            if (lane == 0) {
+                uint64_t *pp = phase + (uint64_t)r * 8;
+                pp[0] += ph0; pp[1] += ph1; pp[2] += ph2; pp[3] += ph3; pp[4] += ph4; pp[5] += pclk[0]; pp[6] += pclk[1];
+            }
+        }
         if (parked) {
             if (lane == 0) ck[0] += __builtin_amdgcn_s_memtime() - t_begin;
             continue;
