@@ -352,6 +352,16 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
  * traceback.  ops_end: one past the last byte of the caller's ops area (written backwards), or
  * nullptr for counts only.  Returns true on success; *n_cols, *n_match valid for all lanes.
  * ------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ uint32_t brx_from_lane_below(uint32_t v) { return (uint32_t)__shfl_down((int)v, 1, 64); }   /* lane l <- lane l + 1 */
+
+/* Chained rounds.  A round loads, for lane l, the traceback word of cell (i - l, j - l) and the two sequence bytes --
+ * one memory round trip for 64 cells of the current diagonal.  The plain scheme used one round per run of diagonal
+ * moves: every indel cost a round trip.  But after an 'I' (up) at lane b the path continues on cells one ROW up in the
+ * SAME columns, and after a 'D' (left) on cells one COLUMN left in the same rows -- and those cells' traceback bits
+ * are, word boundaries aside, already in registers: in the lane's own word (I) or in the word of the lane below (D),
+ * which loaded the same column one row up.  So the round goes on: shift the query byte (I) or the word, its tag and the
+ * target byte (D) down one lane and keep walking, until a lane's word no longer covers the cell it needs (tags
+ * decide) or the lanes run out.  Rounds drop from (#indels + columns / 64) to about columns / 64 + word crossings. */
 __device__ inline bool brx_align_traceback(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                            const BrxGeom g, const uint2 *__restrict__ tb,
                                            uint8_t *ops_end, int *n_cols, int *n_match, uint32_t *prog = nullptr) {
@@ -360,43 +370,67 @@ __device__ inline bool brx_align_traceback(const uint8_t *__restrict__ Qs, const
     int pos = 0, nmatch = 0;
     bool ok = true;
     const int shiftR = 31 - __clz(g.R);          /* R is a power of two */
-    long long guard = (long long)g.Q + (long long)g.T + 8;   /* every round retires >= 1 column */
-    while (i > 0 && j > 0) {
+    long long guard = (long long)g.Q + (long long)g.T + 8;   /* every round retires >= 1 column or row */
+    while (ok && i > 0 && j > 0) {
         if (--guard < 0) { ok = false; break; }
         BRX_PROG(prog, 5, (uint32_t)guard);
-        int ci = i - lane, cj = j - lane;
-        bool valid = ci >= 1 && cj >= 1;
-        bool inband = false, up = false, left = false, eq = false;
-        if (valid) {
-            int s = (ci - 1) >> shiftR;
-            /* a cell the windowed store did not keep counts as outside the band: the run stops there and
-               the alignment fails if the path really needs it */
-            inband = cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s) && brx_stored(g, s, brx_jrep(g, cj));
-            if (inband) {
-                int x = ((ci - 1) & (g.R - 1)) >> 5;
-                int bit = (ci - 1) & 31;
-                uint2 v = tb[((size_t)(cj + g.K * s) * (size_t)g.WSp + (size_t)(s % g.WSp)) * (size_t)g.G + (size_t)x];
-                up = (v.x >> bit) & 1u;
-                left = (v.y >> bit) & 1u;
+        /* ---- load: lane l <- cell (i - l, j - l) ---- */
+        const int I0 = i, J0 = j;
+        uint32_t w_pv = 0, w_ph = 0, qch = 0x100u, tch = 0x200u;
+        int tag_word = -1, tag_col = -1, q_row = -1;
+        {
+            const int ci = I0 - lane, cj = J0 - lane;
+            if (ci >= 1 && cj >= 1) {
+                const int s = (ci - 1) >> shiftR;
+                if (cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s) && brx_stored(g, s, brx_jrep(g, cj))) {
+                    const int x = ((ci - 1) & (g.R - 1)) >> 5;
+                    const uint2 v = tb[((size_t)(cj + g.K * s) * (size_t)g.WSp + (size_t)(s % g.WSp)) * (size_t)g.G + (size_t)x];
+                    w_pv = v.x; w_ph = v.y; tag_word = (ci - 1) >> 5; tag_col = cj;
+                }
+                qch = Qs[ci - 1]; tch = Ts[cj - 1]; q_row = ci;
             }
-            eq = Qs[ci - 1] == Ts[cj - 1];
         }
-        bool diag = valid && inband && !up && !left;
-        unsigned long long dm = __ballot(diag);
-        unsigned long long um = __ballot(up);
-        unsigned long long vm = __ballot(valid && inband);
-        unsigned long long em = __ballot(eq);
-        int run = (~dm == 0ull) ? 64 : __ffsll((long long)~dm) - 1;
-        if (lane < run && ops_end) ops_end[-(pos + lane) - 1] = eq ? BRX_OP_EQ : BRX_OP_X;
-        unsigned long long runmask = run == 64 ? ~0ull : ((1ull << run) - 1ull);
-        nmatch += __popcll(em & runmask);
-        pos += run; i -= run; j -= run;
-        if (run < 64 && i > 0 && j > 0) {
-            if (!((vm >> run) & 1ull)) { ok = false; break; }
-            bool isup = (um >> run) & 1ull;
+        /* ---- walk: lanes >= base hold the not yet consumed part of the diagonal, shifted nI rows / nD columns ---- */
+        int base = 0, nI = 0, nD = 0;
+        for (;;) {
+            const int ci = I0 - lane - nI, cj = J0 - lane - nD;
+            const bool mine = lane >= base && ci >= 1 && cj >= 1;
+            bool cell = false;                                     /* inside the band and the stored window */
+            if (mine) {
+                const int s = (ci - 1) >> shiftR;
+                cell = cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s) && brx_stored(g, s, brx_jrep(g, cj));
+            }
+            const bool inhand = cell && tag_word == ((ci - 1) >> 5) && tag_col == cj && q_row == ci;
+            const int bit = (ci - 1) & 31;
+            const bool up = inhand && ((w_pv >> bit) & 1u), left = inhand && ((w_ph >> bit) & 1u);
+            const bool diag = inhand && !up && !left;
+            const bool eq = qch == tch;
+            const unsigned long long dm = __ballot(diag) >> base, em = __ballot(eq) >> base;
+            const int room = 64 - base;
+            int run = (~dm == 0ull) ? 64 : __ffsll((long long)~dm) - 1;
+            if (run > room) run = room;
+            if (lane >= base && lane < base + run && ops_end) ops_end[-(pos + (lane - base)) - 1] = eq ? BRX_OP_EQ : BRX_OP_X;
+            const unsigned long long runmask = run == 64 ? ~0ull : ((1ull << run) - 1ull);
+            nmatch += __popcll(em & runmask);
+            pos += run; i -= run; j -= run; base += run;
+            if (base >= 64 || i <= 0 || j <= 0) break;
+            /* lane `base` is the first cell that is not a diagonal move */
+            const unsigned long long cm = __ballot(cell), hm = __ballot(inhand), um = __ballot(up);
+            if (!((cm >> base) & 1ull)) { ok = false; break; }              /* the path leaves the band / the stored window */
+            if (!((hm >> base) & 1ull)) break;                             /* its word is not in registers: next round loads it */
+            const bool isup = (um >> base) & 1ull;
             if (lane == 0 && ops_end) ops_end[-pos - 1] = isup ? BRX_OP_I : BRX_OP_D;
             pos += 1;
-            if (isup) i -= 1; else j -= 1;
+            if (isup) {
+                i -= 1; nI += 1;
+                const uint32_t q2 = brx_from_lane_below(qch); const int r2 = (int)brx_from_lane_below((uint32_t)q_row);
+                if (lane < 63) { qch = q2; q_row = r2; } else q_row = -1;
+            } else {
+                j -= 1; nD += 1;
+                const uint32_t a2 = brx_from_lane_below(w_pv), b2 = brx_from_lane_below(w_ph), t2 = brx_from_lane_below(tch);
+                const int tw2 = (int)brx_from_lane_below((uint32_t)tag_word), tc2 = (int)brx_from_lane_below((uint32_t)tag_col);
+                if (lane < 63) { w_pv = a2; w_ph = b2; tch = t2; tag_word = tw2; tag_col = tc2; } else { tag_word = -1; tag_col = -1; }
+            }
         }
     }
     if (ok) {

@@ -50,7 +50,8 @@ struct brx_ctx {
     hipEvent_t ev_a1b[BRX_MAX_CHUNKS], ev_a1e[BRX_MAX_CHUNKS];   /* k_fin_align<1,1,1> of every scratch chunk */
     hipEvent_t ev_qsb[BRX_MAX_CHUNKS], ev_qse[BRX_MAX_CHUNKS];   /* k_fin_qscore of every scratch chunk      */
     hipEvent_t ev_fork, ev_join;
-    uint64_t *d_clk; uint32_t clk_reads;
+    uint64_t *d_clk, *d_phase; uint32_t clk_reads;
+    int profile;                 /* BRX_PROFILE=1: the mutate kernels time their phases (brx_last_phase_cycles) */
     char err[512];
 };
 
@@ -148,6 +149,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
+    { const char *pf = getenv("BRX_PROFILE"); c->profile = (pf && atoi(pf)) ? 1 : 0; }
     { const char *fb = getenv("BRX_FIN_BALANCE"); c->fin_balance = fb ? atoi(fb) : 1; }
     { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
     { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 2048u; }
@@ -221,6 +223,13 @@ extern "C" int brx_last_read_cycles(brx_ctx *c, uint64_t *h_out, uint32_t n_read
     return BRX_OK;
 }
 
+extern "C" int brx_last_phase_cycles(brx_ctx *c, uint64_t *h_out, uint32_t n_reads) {
+    if (!c || !h_out) return BRX_E_ARG;
+    if (!c->d_phase || n_reads > c->clk_reads) return fail(c, BRX_E_STATE, "no phase counters for %u reads", n_reads);
+    HIPCHK(c, hipMemcpy(h_out, c->d_phase, (size_t)n_reads * 64, hipMemcpyDeviceToHost));
+    return BRX_OK;
+}
+
 extern "C" uint32_t brx_last_mutate_passes(const brx_ctx *c) { return c ? c->mutate_passes : 0; }
 extern "C" uint32_t brx_last_final_launches(const brx_ctx *c) { return c ? c->final_launches : 0; }
 extern "C" uint32_t brx_last_window_misses(const brx_ctx *c) { return c ? c->window_misses : 0; }
@@ -261,11 +270,13 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     uint64_t *units_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *tboff_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *clk = (uint64_t *)A.take((size_t)n_reads * 64);     /* per-read cycle counters, brx_last_read_cycles() */
+    uint64_t *phase = (uint64_t *)A.take((size_t)n_reads * 64);   /* mutate phase cycles (BRX_PROFILE=1), brx_last_phase_cycles() */
     if (!A.ok()) return scratch_short(c, A.used + (size_t)n_reads * 200000);
     HIPCHK(c, hipMemsetAsync(counters, 0, 2048 * 4, st));
     HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, st));
     HIPCHK(c, hipMemsetAsync(clk, 0, (size_t)n_reads * 64, st));
-    c->d_clk = clk; c->clk_reads = n_reads;
+    HIPCHK(c, hipMemsetAsync(phase, 0, (size_t)n_reads * 64, st));
+    c->d_clk = clk; c->d_phase = phase; c->clk_reads = n_reads;
 
     /* ---- stage: plan ---- */
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_PLAN], st));
@@ -330,18 +341,28 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             uint32_t *act_out = (pass & 1u) ? active_b : active_a;
             HIPCHK(c, hipMemsetAsync(ctr, 0, MC_WORDS * sizeof(uint32_t), st));
             if (n_up <= tail_reads) {
-                hipLaunchKernelGGL((k_mutate_seg<true>), dim3(std::min(n_up, side_waves)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out, ctr,
-                                   req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                                   win, (uint64_t)c->win_bytes, counters + 1);
+                if (c->profile)
+                    hipLaunchKernelGGL((k_mutate_seg<true, true>), dim3(std::min(n_up, side_waves)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out, ctr,
+                                       req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
+                                       win, (uint64_t)c->win_bytes, counters + 1, phase);
+                else
+                    hipLaunchKernelGGL((k_mutate_seg<true, false>), dim3(std::min(n_up, side_waves)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out, ctr,
+                                       req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
+                                       win, (uint64_t)c->win_bytes, counters + 1, phase);
                 rc = read_counts(ctr);
                 if (rc) return rc;
                 n_up = h_ctr[MC_OUT];                   /* 0 unless a window overflowed its slot (then: legacy list) */
                 ++pass;
                 break;
             }
-            hipLaunchKernelGGL((k_mutate_seg<false>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                               ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                               win, (uint64_t)c->win_bytes, counters + 1);
+            if (c->profile)
+                hipLaunchKernelGGL((k_mutate_seg<false, true>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                                   ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
+                                   win, (uint64_t)c->win_bytes, counters + 1, phase);
+            else
+                hipLaunchKernelGGL((k_mutate_seg<false, false>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                                   ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
+                                   win, (uint64_t)c->win_bytes, counters + 1, phase);
             if (n_up > lane_threshold)
                 hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64)), dim3(64), 0, st, msv, req_easy,
                                    ctr + MC_EASY, winbuf, lane_tb);

@@ -46,22 +46,67 @@ struct MS {                       /* loop state of a parked read */
 
 enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WORDS = 8 };
 
+/* Park a window in ONE pass: qb[0, b-a) = F[a:b] (+16 bytes 0xFF), tbuf[0, tl) = join(new_fragment_bases[a:b]) clipped
+ * to `tmax` bytes (+16 bytes 0xFE when it fits), *cost = edit bound of the pair, *odd = a symbol outside ACGT on either
+ * side (wave-uniform).  Returns the joined length tl (may exceed tmax: the caller hands the read to k_mutate). */
+__device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F, const uint32_t *repl, uint32_t a, uint32_t b,
+                                     uint8_t *qb, uint8_t *tbuf, uint32_t tmax, uint32_t *cost, bool *odd) {
+    const int lane = lane_id();
+    uint32_t run = 0, c = 0;
+    bool o_ = false;
+    for (uint32_t base = a; base < b; base += 64) {
+        const uint32_t p = base + lane;
+        const bool valid = p < b;
+        uint32_t w = 0, len = 0;
+        uint8_t fb = 0xFF;
+        if (valid) { fb = F[p]; w = repl[p]; len = rep_len(w); c += rep_cost(w); qb[p - a] = fb; o_ |= fb > 3; }
+        const uint32_t inc = wave_incl_scan(len);
+        if (valid) {
+            const uint32_t o = run + inc - len;
+            if (!w) { if (o < tmax) tbuf[o] = fb; }
+            else for (uint32_t x = 0; x < len; ++x) {
+                const uint8_t ch = rep_char(em, w, x);
+                o_ |= ch > 3;
+                if (o + x < tmax) tbuf[o + x] = ch;
+            }
+        }
+        run += wave_bcast_u32(inc, 63);
+    }
+    const uint32_t ql = b - a;
+    for (uint32_t x = lane; x < 16; x += 64) { qb[ql + x] = 0xFF; if (run <= tmax) tbuf[run + x] = 0xFE; }
+    *cost = wave_sum(c);
+    *odd = __ballot(o_) != 0ull;
+    return run;
+}
+
 /* -------------------------------------------------------------------------------------------------
  * k_mutate_seg
  * ----------------------------------------------------------------------------------------------- */
 /* INLINE = false: park at every alignment (bulk passes).  INLINE = true: align in place with the
  * wave-systolic aligner and run every read to completion (the last few reads of a batch, where a
  * host round trip per alignment would cost more than the alignment). */
-template <bool INLINE>
+/* PROFILE = true (BRX_PROFILE=1): shader-clock time of every phase of the loop is added to phase[8 r + i]:
+ *   0 propose (draws, k-mer bytes, table lookups)   1 apply survivors   2 park (window join + copies, state)
+ *   3 in-place alignment (INLINE)   4 everything else   5 / 6 forward / traceback part of 3
+ * The phase clock is wave-uniform scalar code; the default instantiations do not contain it. */
+#define BRX_PHASE(next)                                                                                          \
+    do { if constexpr (PROFILE) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); const uint64_t dt_ = now_ - ph_last;  \
+             ph_last = now_; ph0 += ph_cur == 0 ? dt_ : 0; ph1 += ph_cur == 1 ? dt_ : 0; ph2 += ph_cur == 2 ? dt_ : 0;   \
+             ph3 += ph_cur == 3 ? dt_ : 0; ph4 += ph_cur == 4 ? dt_ : 0; ph_cur = (next); } } while (0)
+
+template <bool INLINE, bool PROFILE = false>
 __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
                                                     const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,
                                                     uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
                                                     const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk,
-                                                    uint32_t lane_threshold, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags) {
+                                                    uint32_t lane_threshold, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags,
+                                                    uint64_t *phase) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
     const uint32_t n_in = uni(*n_in_ptr);
+    uint64_t ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph_last = 0, pclk[2] = {0, 0};
+    int ph_cur = 4;
     for (;;) {
         const uint32_t qi = wave_pop(&ctr[MC_QUEUE]);
         if (qi >= n_in) break;
@@ -69,6 +114,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
         const RS s = rs[r];
         if (s.n == 0) continue;
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        if constexpr (PROFILE) { ph0 = ph1 = ph2 = ph3 = ph4 = 0; pclk[0] = pclk[1] = 0; ph_last = t_begin; ph_cur = 4; }
         MS ms = msv[r];
         const uint64_t read = d.first_read + r;
         const uint32_t n = s.n;
@@ -112,6 +158,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
             const uint64_t room = loop_cap - loops;
             const uint32_t B = room < 64 ? (uint32_t)room : 64u;
             /* ---- propose (identical draws on a resumed round) ---- */
+            BRX_PHASE(0);
             uint32_t rep[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) rep[j] = 0;
@@ -127,6 +174,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
                 live = dev_choose_alt(em, kmer, w[2], w[3], rep);
             }
             unsigned long long surv = __ballot(live);
+            BRX_PHASE(1);
             int j0 = 0;
             if (resume) { surv &= ~((1ull << ms.surv_lane) - 1ull); j0 = (int)ms.j_next; }
             bool first = resume;
@@ -159,6 +207,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
                     errors += (double)(len < 2 ? 1u : len - 1u) * scale;
                     if (change % BRX_ALIGN_INTERVAL == 0) {
                         /* ---- park the read: the window pair goes to its slot, the loop state to MS ---- */
+                        BRX_PHASE(2);
                         uint32_t a = 0, b = n;
                         if (n > BRX_ALIGN_SIZE) {
                             uint32_t ww[4];
@@ -168,26 +217,20 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
                         }
                         nalign += 1;
                         __builtin_amdgcn_s_waitcnt(0);
+                        /* one pass over the window: F[a:b] -> query slot, join(new[a:b]) -> target slot (clipped to the
+                           slot; an overflowing window goes to the whole-read kernel), edit bound, non-ACGT flag */
                         uint32_t cost = 0;
-                        const uint32_t tl = wave_join(em, F, rp, a, b, nullptr, &cost);
+                        uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+                        bool odd = false;
+                        const uint32_t tl = wave_park(em, F, rp, a, b, qb, tbuf, BRX_WIN_TMAX, &cost, &odd);
                         const uint32_t ql = b - a;
                         uint32_t klass = MC_LEGACY;
                         if (tl <= BRX_WIN_TMAX) {
-                            uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
-                            bool odd = false;                       /* a symbol outside ACGT anywhere in the pair */
-                            for (uint32_t x = lane; x < ql + 16; x += 64) {
-                                const uint8_t c = x < ql ? F[a + x] : 0xFF;
-                                qb[x] = c;
-                                odd |= x < ql && c > 3;
-                            }
-                            for (uint32_t x = lane; x < 16; x += 64) tbuf[tl + x] = 0xFE;
-                            wave_join(em, F, rp, a, b, tbuf, nullptr);
                             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                             __builtin_amdgcn_s_waitcnt(0);
-                            for (uint32_t x = lane; x < tl; x += 64) odd |= tbuf[x] > 3;
                             const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
                             const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
-                            const bool easy = !INLINE && __ballot(odd) == 0ull && g.G == 1 && band_blocks <= BRX_LANE_W &&
+                            const bool easy = !INLINE && !odd && g.G == 1 && band_blocks <= BRX_LANE_W &&
                                               tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 && n_in > lane_threshold;
                             klass = easy ? MC_EASY : MC_HARD;
                         }
@@ -222,13 +265,16 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
             loops += B;
             if (B < 64) { loops += 1; break; }
         }
+        BRX_PHASE(4);
         if (INLINE && parked && ms.phase == 1u) {
             /* align the parked window here, at the top level where only MS is live, and resume the same read */
             const uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
             uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)blockIdx.x * scr_bytes);
             int ncols = 0, nmatch = 0; bool nospace = false;
+            BRX_PHASE(3);
             const bool ok = brx_wave_align<1>(qb, (int)(ms.win_b - ms.win_a), tbuf, (int)ms.tl, (int)ms.cost, tb, scr_bytes / 8, nullptr,
-                                              &ncols, &nmatch, &nospace);
+                                              &ncols, &nmatch, &nospace, nullptr, PROFILE ? pclk : nullptr);
+            BRX_PHASE(4);
             ms.res_ncols = (uint32_t)ncols; ms.res_nmatch = (uint32_t)nmatch;
             if (!ok && !nospace) ms.status |= BRX_RS_BAND;
             if (nospace && lane == 0) atomicOr(&flags[0], 1u);
@@ -237,6 +283,13 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
         break;
       }
         uint64_t *ck = clk + (uint64_t)r * 8;
+        if constexpr (PROFILE) {
+            BRX_PHASE(4);
+            if (lane == 0) {
+                uint64_t *pp = phase + (uint64_t)r * 8;
+                pp[0] += ph0; pp[1] += ph1; pp[2] += ph2; pp[3] += ph3; pp[4] += ph4; pp[5] += pclk[0]; pp[6] += pclk[1];
+            }
+        }
         if (parked) {
             if (lane == 0) ck[0] += __builtin_amdgcn_s_memtime() - t_begin;
             continue;
@@ -360,13 +413,28 @@ __global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, c
             const uint32_t m0 = 0u - c0, m1 = 0u - c1;
             uint32_t hp = 1u, hm = 0u;
             uint2 *dstj = tbw + ((uint64_t)j * BRX_LANE_W) * 64u + (uint32_t)lane;
-            for (int x = 0; x < Wb; ++x) {
+            /* all band words of this column are fetched from LDS first (independent loads, one latency), the carry
+               chain then runs in registers, and the words go back: the loop used to pay ~6 dependent LDS round trips
+               per word with one wave per SIMD and nothing to hide them */
+            uint32_t P[BRX_LANE_W], M[BRX_LANE_W], QL[BRX_LANE_W], QH[BRX_LANE_W];
+#pragma unroll
+            for (int x = 0; x < BRX_LANE_W; ++x) {
+                const int sb = s_lo + x;
+                const bool on = act && x < Wb && sb <= s_hi;
+                const int sbc = on ? sb : 0;
+                const int slot = sbc & (BRX_LANE_W - 1);
+                P[x] = st_pv[slot][lane]; M[x] = st_mv[slot][lane];
+                QL[x] = q_lo[sbc][lane]; QH[x] = q_hi[sbc][lane];
+            }
+#pragma unroll
+            for (int x = 0; x < BRX_LANE_W; ++x) {
+                if (x >= Wb) break;
                 const int sb = s_lo + x;
                 const bool on = act && sb <= s_hi;
                 const int sbc = on ? sb : 0;
                 const int slot = sbc & (BRX_LANE_W - 1);
-                uint32_t pv = st_pv[slot][lane], mv = st_mv[slot][lane];
-                uint32_t Eq = ~((q_lo[sbc][lane] ^ m0) | (q_hi[sbc][lane] ^ m1));
+                uint32_t pv = P[x], mv = M[x];
+                uint32_t Eq = ~((QL[x] ^ m0) | (QH[x] ^ m1));
                 if (sbc == NS - 1) Eq &= lastmask;
                 const uint32_t Xv = Eq | mv;
                 const uint32_t Eq2 = Eq | hm;

@@ -242,6 +242,8 @@ def bind_library(lib):
     lib.brx_last_stage_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float * 8)]
     lib.brx_last_read_cycles.restype = ctypes.c_int
     lib.brx_last_read_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    lib.brx_last_phase_cycles.restype = ctypes.c_int
+    lib.brx_last_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
     lib.brx_last_mutate_passes.restype = ctypes.c_uint32
     lib.brx_last_mutate_passes.argtypes = [ctypes.c_void_p]
     lib.brx_last_final_launches.restype = ctypes.c_uint32
@@ -466,6 +468,12 @@ class HipEngine(EngineBase):
         """(n_reads, 8) uint64 shader-clock counters of the last pipeline call (see include/brx.h)."""
         out = np.zeros((n_reads, 8), dtype=np.uint64)
         self._check(self.lib.brx_last_read_cycles(self.ctx, out.ctypes.data, n_reads))
+        return out
+
+    def phase_cycles(self, n_reads):
+        """(n_reads, 8) uint64: shader-clock time per mutate phase of the last batch (BRX_PROFILE=1 at creation)."""
+        out = np.zeros((n_reads, 8), dtype=np.uint64)
+        self._check(self.lib.brx_last_phase_cycles(self.ctx, out.ctypes.data, n_reads))
         return out
 
     def mutate_passes(self):

@@ -243,6 +243,12 @@ int brx_last_stage_ms(const brx_ctx *ctx, float ms[BRX_STAGE_COUNT]);
  *   [7] words per lane (G) of the final alignment's band geometry                                */
 int brx_last_read_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
 /* number of scratch chunks (sets of final-stage launches) and of mutate passes of the last call */
+/* With BRX_PROFILE=1 in the environment at brx_create the mutate kernels time their phases (shader clock, per read,
+ * summed over passes), 8 x u64 per read to HOST memory h_out:
+ *   [0] proposals (draws, k-mer bytes, table lookups)  [1] applying survivors  [2] parking a window (join, copies)
+ *   [3] in-place window alignment  [4] everything else  [5] / [6] forward / traceback share of [3]  [7] unused
+ * Zeros without BRX_PROFILE (the default kernels do not contain the clock reads). */
+int brx_last_phase_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
 uint32_t brx_last_mutate_passes(const brx_ctx *ctx);
 uint32_t brx_last_final_launches(const brx_ctx *ctx);
 /* Reads of the last call whose final traceback asked for a cell outside the windowed traceback store and were

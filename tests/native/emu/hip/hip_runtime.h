@@ -176,6 +176,7 @@ static inline unsigned long long __ballot(int pred) {
 static inline int __shfl(int v, int src, int width = 64) { (void)width; const int me = emu::S().cur; const uint64_t *a = emu::exchange((uint32_t)v); (void)me; return (int)(uint32_t)a[src & 63]; }
 static inline int __shfl_xor(int v, int mask, int width = 64) { (void)width; const int me = emu::S().cur; const uint64_t *a = emu::exchange((uint32_t)v); return (int)(uint32_t)a[(me ^ mask) & 63]; }
 static inline int __shfl_up(int v, unsigned delta, int width = 64) { (void)width; const int me = emu::S().cur; const uint64_t *a = emu::exchange((uint32_t)v); return me >= (int)delta ? (int)(uint32_t)a[me - (int)delta] : v; }
+static inline int __shfl_down(int v, unsigned delta, int width = 64) { (void)width; const int me = emu::S().cur; const uint64_t *a = emu::exchange((uint32_t)v); return me + (int)delta < 64 ? (int)(uint32_t)a[me + (int)delta] : v; }
 static inline unsigned __shfl(unsigned v, int src, int width = 64) { return (unsigned)__shfl((int)v, src, width); }
 static inline unsigned __shfl_xor(unsigned v, int mask, int width = 64) { return (unsigned)__shfl_xor((int)v, mask, width); }
 static inline unsigned __shfl_up(unsigned v, unsigned delta, int width = 64) { return (unsigned)__shfl_up((int)v, delta, width); }
