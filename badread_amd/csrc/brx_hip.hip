@@ -22,6 +22,7 @@
 #include "brx_kernels.h"
 
 #define BRX_MAX_CHUNKS 60
+#define BRX_KEV_MAX 768
 
 struct brx_ctx {
     int device;
@@ -39,18 +40,26 @@ struct brx_ctx {
     float stage_ms[BRX_STAGE_COUNT];
     uint32_t final_launches, mutate_passes;
     int mutate_inline;
-    int fin_balance;             /* BRX_FIN_BALANCE: 1 = the two-word band class runs on the main stream behind the one-word class */
     uint32_t seg_waves_per_cu;   /* BRX_SEG_WAVES_PER_CU: persistent waves of k_mutate_seg per CU */
     uint32_t tail_reads;         /* BRX_TAIL_READS: this few reads left in the mutate stage -> one in-place launch */
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
+    int mutate_wg;               /* BRX_MUTATE_WG (default 1): the mutate stage is one launch of k_mutate_wg (brx_mutate_wg.h); 0 = the pass pipeline */
+    uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
+    int wide_stream;             /* BRX_WIDE_STREAM: the head set's widest band class aligns on a third stream */
+    hipStream_t side2;
+    hipEvent_t ev_fork2[2], ev_join2[2], ev_head_mut;
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
                                     three wide classes: a stream per class measured 30 % slower, r01d) */
-    hipEvent_t ev_a1b[BRX_MAX_CHUNKS], ev_a1e[BRX_MAX_CHUNKS];   /* k_fin_align<1,1,1> of every scratch chunk */
-    hipEvent_t ev_qsb[BRX_MAX_CHUNKS], ev_qse[BRX_MAX_CHUNKS];   /* k_fin_qscore of every scratch chunk      */
     hipEvent_t ev_fork, ev_join;
     uint64_t *d_clk, *d_phase; uint32_t clk_reads;
+    /* per-kernel launch timing (brx_set_kernel_timing / brx_last_kernel_stats): event pairs around every launch */
+    int ktiming;
+    hipEvent_t kev_b[BRX_KEV_MAX], kev_e[BRX_KEV_MAX];
+    uint8_t kev_kind[BRX_KEV_MAX];
+    int kev_n, kev_dropped;
+    brx_kernel_stat kstat[BRX_KERN_COUNT];
     int profile;                 /* BRX_PROFILE=1: the mutate kernels time their phases (brx_last_phase_cycles) */
     char err[512];
 };
@@ -93,14 +102,15 @@ static void release(brx_ctx *c) {
         if (c->ev_b[i]) (void)hipEventDestroy(c->ev_b[i]);
         if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]);
     }
-    for (int i = 0; i < BRX_MAX_CHUNKS; ++i) {
-        if (c->ev_a1b[i]) (void)hipEventDestroy(c->ev_a1b[i]);
-        if (c->ev_a1e[i]) (void)hipEventDestroy(c->ev_a1e[i]);
-        if (c->ev_qsb[i]) (void)hipEventDestroy(c->ev_qsb[i]);
-        if (c->ev_qse[i]) (void)hipEventDestroy(c->ev_qse[i]);
+    for (int i = 0; i < BRX_KEV_MAX; ++i) {
+        if (c->kev_b[i]) (void)hipEventDestroy(c->kev_b[i]);
+        if (c->kev_e[i]) (void)hipEventDestroy(c->kev_e[i]);
     }
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->side2) (void)hipStreamDestroy(c->side2);
+    for (int i = 0; i < 2; ++i) { if (c->ev_fork2[i]) (void)hipEventDestroy(c->ev_fork2[i]); if (c->ev_join2[i]) (void)hipEventDestroy(c->ev_join2[i]); }
+    if (c->ev_head_mut) (void)hipEventDestroy(c->ev_head_mut);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     free(c);
@@ -141,16 +151,18 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         if ((e = hipEventCreate(&c->ev_e[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     }
     if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
-    for (int i = 0; i < BRX_MAX_CHUNKS; ++i) {
-        if ((e = hipEventCreate(&c->ev_a1b[i])) != hipSuccess || (e = hipEventCreate(&c->ev_a1e[i])) != hipSuccess ||
-            (e = hipEventCreate(&c->ev_qsb[i])) != hipSuccess || (e = hipEventCreate(&c->ev_qse[i])) != hipSuccess)
-            return create_fail(c, "hipEventCreate", e);
-    }
+    if ((e = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
+    for (int i = 0; i < 2; ++i)
+        if ((e = hipEventCreateWithFlags(&c->ev_fork2[i], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    { const char *mw = getenv("BRX_MUTATE_WG"); c->mutate_wg = mw ? atoi(mw) : 1; }
+    { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 2048u; }
+    { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
     { const char *pf = getenv("BRX_PROFILE"); c->profile = (pf && atoi(pf)) ? 1 : 0; }
-    { const char *fb = getenv("BRX_FIN_BALANCE"); c->fin_balance = fb ? atoi(fb) : 1; }
     { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
     { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 2048u; }
     { const char *sw = getenv("BRX_SEG_WAVES_PER_CU"); c->seg_waves_per_cu = sw && atoi(sw) > 0 ? (uint32_t)atoi(sw) : 8u; }
@@ -230,6 +242,37 @@ extern "C" int brx_last_phase_cycles(brx_ctx *c, uint64_t *h_out, uint32_t n_rea
     return BRX_OK;
 }
 
+extern "C" int brx_set_kernel_timing(brx_ctx *c, int on) {
+    if (!c) return BRX_E_ARG;
+    if (on && !c->kev_b[0]) {
+        HIPCHK(c, hipSetDevice(c->device));
+        for (int i = 0; i < BRX_KEV_MAX; ++i) {
+            HIPCHK(c, hipEventCreate(&c->kev_b[i]));
+            HIPCHK(c, hipEventCreate(&c->kev_e[i]));
+        }
+    }
+    c->ktiming = on ? 1 : 0;
+    return BRX_OK;
+}
+extern "C" int brx_last_kernel_stats(const brx_ctx *c, brx_kernel_stat out[BRX_KERN_COUNT]) {
+    if (!c || !out) return BRX_E_ARG;
+    for (int i = 0; i < BRX_KERN_COUNT; ++i) out[i] = c->kstat[i];
+    return BRX_OK;
+}
+/* bracket one launch (or a short group of launches) on `stream` with an event pair of kernel class `kind` */
+struct KTimer {
+    brx_ctx *c; hipStream_t st; int slot;
+    KTimer(brx_ctx *c_, int kind, hipStream_t st_) : c(c_), st(st_), slot(-1) {
+        if (!c->ktiming) return;
+        if (c->kev_n >= BRX_KEV_MAX) { c->kev_dropped += 1; return; }
+        slot = c->kev_n++;
+        c->kev_kind[slot] = (uint8_t)kind;
+        (void)hipEventRecord(c->kev_b[slot], st);
+    }
+    ~KTimer() { if (slot >= 0) (void)hipEventRecord(c->kev_e[slot], st); }
+};
+#define KTIMED(kind, stream) KTimer ktimer_##__LINE__(c, (kind), (stream))
+
 extern "C" uint32_t brx_last_mutate_passes(const brx_ctx *c) { return c ? c->mutate_passes : 0; }
 extern "C" uint32_t brx_last_final_launches(const brx_ctx *c) { return c ? c->final_launches : 0; }
 extern "C" uint32_t brx_last_window_misses(const brx_ctx *c) { return c ? c->window_misses : 0; }
@@ -266,23 +309,28 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     RS *rs = (RS *)A.take((size_t)n_reads * sizeof(RS));
     uint64_t *totals = (uint64_t *)A.take(16 * sizeof(uint64_t));
     uint32_t *order = (uint32_t *)A.take((size_t)n_reads * 4);
-    uint32_t *counters = (uint32_t *)A.take(2048 * 4);      /* [0] join queue, [1] flags, [2] window misses of the final stage, [16 + 16 x (phase, chunk)] final-stage queue heads */
+    uint32_t *counters = (uint32_t *)A.take(4096 * 4);      /* [0] join queue, [1] flags, [2] window misses of the final stage, [16 + 16 x (phase, chunk)] final-stage queue heads */
     uint64_t *units_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *tboff_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *clk = (uint64_t *)A.take((size_t)n_reads * 64);     /* per-read cycle counters, brx_last_read_cycles() */
     uint64_t *phase = (uint64_t *)A.take((size_t)n_reads * 64);   /* mutate phase cycles (BRX_PROFILE=1), brx_last_phase_cycles() */
     if (!A.ok()) return scratch_short(c, A.used + (size_t)n_reads * 200000);
-    HIPCHK(c, hipMemsetAsync(counters, 0, 2048 * 4, st));
+    HIPCHK(c, hipMemsetAsync(counters, 0, 4096 * 4, st));
     HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, st));
     HIPCHK(c, hipMemsetAsync(clk, 0, (size_t)n_reads * 64, st));
     HIPCHK(c, hipMemsetAsync(phase, 0, (size_t)n_reads * 64, st));
     c->d_clk = clk; c->d_phase = phase; c->clk_reads = n_reads;
+    c->kev_n = 0; c->kev_dropped = 0;
+    memset(c->kstat, 0, sizeof(c->kstat));
 
     /* ---- stage: plan ---- */
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_PLAN], st));
-    if (raw) hipLaunchKernelGGL(k_init_raw, dim3(nb64), dim3(64), 0, st, dev, rs, d_frag_off, d_target);
-    else hipLaunchKernelGGL(k_plan_count, dim3(nb64), dim3(64), 0, st, dev, rs);
-    hipLaunchKernelGGL(k_scan_plan, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
+    {
+        KTIMED(BRX_KERN_PLAN, st);
+        if (raw) hipLaunchKernelGGL(k_init_raw, dim3(nb64), dim3(64), 0, st, dev, rs, d_frag_off, d_target);
+        else hipLaunchKernelGGL(k_plan_count, dim3(nb64), dim3(64), 0, st, dev, rs);
+        hipLaunchKernelGGL(k_scan_plan, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
+    }
     int rc = read_totals(c, st, totals, 3);
     if (rc) return rc;
     const uint64_t tot_segs = c->h_totals[0], tot_pieces = c->h_totals[1], f_bytes = c->h_totals[2];
@@ -294,148 +342,79 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, 512u);      /* lane-level window aligner          */
     uint8_t *win = (uint8_t *)A.take((size_t)side_waves * c->win_bytes);
     MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
-    uint32_t *mctr = (uint32_t *)A.take(4 * MC_WORDS * sizeof(uint32_t));
+    uint32_t *mctr = (uint32_t *)A.take(8 * MC_WORDS * sizeof(uint32_t));   /* pass counters 0/1, 2 first bulk input, 3 bulk legacy, 4 head input, 5 head legacy, 6 head pass */
     uint32_t *active_a = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *active_b = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_easy = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_hard = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy = (uint32_t *)A.take((size_t)n_reads * 4);
+    uint32_t *req_legacy_head = (uint32_t *)A.take((size_t)n_reads * 4);
+    uint32_t *active_head = (uint32_t *)A.take((size_t)n_reads * 4);
     uint8_t *winbuf = (uint8_t *)A.take((size_t)n_reads * BRX_WIN_STRIDE + 64);
-    uint2 *lane_tb = (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
+    const bool use_wg = c->mutate_wg && !c->mutate_inline;
+    const uint32_t wg_blocks = std::min<uint32_t>((n_reads + BRX_WG_WAVES - 1) / BRX_WG_WAVES, (uint32_t)c->n_cu * 2u);
+    uint2 *lane_tb = use_wg ? nullptr : (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
+    uint2 *pack_tb = use_wg ? (uint2 *)A.take((size_t)wg_blocks * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2)) : nullptr;
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
-    if (!raw) hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces);
+    if (!raw) { KTIMED(BRX_KERN_PLAN, st); hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces); }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_PLAN], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_BUILD], st));
 
     /* ---- stage: build ---- */
     if (raw) hipLaunchKernelGGL(k_copy_frags, dim3(n_reads), dim3(64), 0, st, dev, rs, d_frags, d_frag_off, Fbuf);
-    hipLaunchKernelGGL(k_build, dim3(n_reads), dim3(64), 0, st, dev, rs, segs, Fbuf, repl);
+    { KTIMED(BRX_KERN_BUILD, st); hipLaunchKernelGGL(k_build, dim3(n_reads), dim3(64), 0, st, dev, rs, segs, Fbuf, repl); }
     hipLaunchKernelGGL(k_order, dim3(1), dim3(64), 0, st, n_reads, rs, order);
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_BUILD], st));
-    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_MUTATE], st));
 
-    /* ---- stage: mutate (multi-pass: segments of the loop, parked window alignments; brx_mutate.h) ---- */
-    {
-        const uint32_t seg_waves = std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * (uint64_t)c->seg_waves_per_cu);
-        HIPCHK(c, hipMemsetAsync(msv, 0, (size_t)n_reads * sizeof(MS), st));
-        HIPCHK(c, hipMemsetAsync(mctr, 0, 4 * MC_WORDS * sizeof(uint32_t), st));
-        uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
-        memset(h_ctr, 0, MC_WORDS * sizeof(uint32_t));
-        h_ctr[MC_OUT] = n_reads;
-        HIPCHK(c, hipMemcpyAsync(mctr + 2 * MC_WORDS, h_ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;                                 /* [0] count, [1] queue; not reset per pass */
-        const uint32_t *n_in = mctr + 2 * MC_WORDS + MC_OUT;
-        const uint32_t *act_in = order;
-        uint32_t n_up = n_reads, pass = 0;
-        const uint32_t lane_threshold = c->lane_threshold;   /* fewer active reads than this: one wave per window (lower latency) */
-        /* this few reads left: run them to completion on the GPU, aligning in place (no host round trips).
-           BRX_MUTATE_INLINE=1 does that for the whole batch: one launch, no passes. */
-        const uint32_t tail_reads = c->mutate_inline ? 0xFFFFFFFFu : c->tail_reads;
-        auto read_counts = [&](uint32_t *ctr) -> int {
-            HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            return wait_stream(c, st, "mutate pass");
-        };
-        for (; n_up > 0 && pass < (1u << 20); ++pass) {
-            uint32_t *ctr = mctr + (pass & 1u) * MC_WORDS;
-            uint32_t *act_out = (pass & 1u) ? active_b : active_a;
-            HIPCHK(c, hipMemsetAsync(ctr, 0, MC_WORDS * sizeof(uint32_t), st));
-            if (n_up <= tail_reads) {
-                if (c->profile)
-                    hipLaunchKernelGGL((k_mutate_seg<true, true>), dim3(std::min(n_up, side_waves)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out, ctr,
-                                       req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                                       win, (uint64_t)c->win_bytes, counters + 1, phase);
-                else
-                    hipLaunchKernelGGL((k_mutate_seg<true, false>), dim3(std::min(n_up, side_waves)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out, ctr,
-                                       req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                                       win, (uint64_t)c->win_bytes, counters + 1, phase);
-                rc = read_counts(ctr);
-                if (rc) return rc;
-                n_up = h_ctr[MC_OUT];                   /* 0 unless a window overflowed its slot (then: legacy list) */
-                ++pass;
-                break;
-            }
-            if (c->profile)
-                hipLaunchKernelGGL((k_mutate_seg<false, true>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                                   ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                                   win, (uint64_t)c->win_bytes, counters + 1, phase);
-            else
-                hipLaunchKernelGGL((k_mutate_seg<false, false>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                                   ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                                   win, (uint64_t)c->win_bytes, counters + 1, phase);
-            if (n_up > lane_threshold)
-                hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64)), dim3(64), 0, st, msv, req_easy,
-                                   ctr + MC_EASY, winbuf, lane_tb);
-            hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
-                               ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1);
-            /* the active count only shrinks: look at it every 4th pass while it is large, every pass near the end */
-            if (n_up <= 4 * std::min<uint32_t>(tail_reads, 48u) || n_up <= tail_reads + 64 || (pass & 3u) == 3u) {
-                rc = read_counts(ctr);
-                if (rc) return rc;
-                n_up = h_ctr[MC_OUT];
-            }
-            n_in = ctr + MC_OUT;
-            act_in = act_out;
-        }
-        c->mutate_passes = pass;
-        if (n_up > 0) return fail(c, BRX_E_INTERNAL, "mutate pipeline did not converge after %u passes", pass);
-        /* reads whose window did not fit a slot: the whole-read kernel with the inline wave aligner */
-        HIPCHK(c, hipMemcpyAsync(h_ctr, legacy_ctr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        if (h_ctr[0] > 0)
-            hipLaunchKernelGGL(k_mutate, dim3(std::min(side_waves, h_ctr[0])), dim3(64), 0, st, dev, rs, req_legacy, legacy_ctr,
-                               legacy_ctr + 1, Fbuf, repl, win, (uint64_t)c->win_bytes, counters + 1, clk);
-    }
-    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_MUTATE], st));
-    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_SCAN], st));
-    hipLaunchKernelGGL(k_scan_mut, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
-    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_SCAN], st));
-    rc = read_totals(c, st, totals, 5);
-    if (rc) return rc;
-    {
-        uint32_t flags = 0;
-        HIPCHK(c, hipMemcpyAsync(&flags, counters + 1, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        if (flags & 1u) {                              /* an in-loop alignment did not fit its window scratch */
-            c->win_bytes *= 4;
-            return scratch_short(c, c->scratch_bytes + (size_t)side_waves * c->win_bytes);
-        }
-    }
-    const uint64_t seq_bytes = c->h_totals[3], ops_bytes = c->h_totals[4];
-    uint8_t *seqbuf = (uint8_t *)A.take((size_t)seq_bytes + 64);
-    uint8_t *opsbuf = (uint8_t *)A.take((size_t)ops_bytes + 64);
-    if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
-
-    /* ---- stage: final alignment + qscores, in chunks that fit the remaining arena ----
-     * phase 0: every read, windowed traceback store (sizes computed on the device at the end of mutate);
-     * phase 1: only the reads whose traceback left the stored window (normally none), full store. */
-    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_FINAL], st));
-    hipLaunchKernelGGL(k_fin_join, dim3(std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 16u)), dim3(64), 0, st, dev, rs, counters + 0,
-                       Fbuf, repl, pieces, seqbuf);
+    /* ---- stages: mutate + final, as TWO CHAINS per batch ------------------------------------------------------
+     * `order` lists the reads longest first.  The first n_head of them (the HEAD set: BRX_HEAD_READS, default 2048)
+     * are the batch's critical path: a 150 kb read is ~300 dependent {mutate segment, window alignment} cycles and
+     * then a final alignment with 8-16 band words per lane.  They run on the side stream from the start: one launch
+     * of k_mutate_seg<true> takes each of them to completion with in-place window alignments, and their final
+     * alignment + qscores follow on that stream as soon as they are done.  The BULK set (everything else) runs
+     * beside them on the caller's stream: passes of {k_mutate_seg<false>, k_win_lane, k_win_wave}, an in-place tail
+     * once few reads are left, then its own final stage.  The chains share nothing but read-only inputs and the
+     * arena's bump allocator (host side), and join before the records are written.  A batch that is small
+     * (n_reads <= BRX_TAIL_READS) or BRX_MUTATE_INLINE=1 is all head.  (Round 1 ran the sets one after the other:
+     * bulk passes, THEN the in-place tail, THEN all final kernels -- 930 ms per batch with 8 batches in flight, of
+     * which 230 ms tail and 270 ms wide-band alignments during which the batch used a few dozen waves.) */
     std::vector<uint32_t> h_order(n_reads);
     std::vector<RS> h_rs(n_reads);
-    HIPCHK(c, hipMemcpyAsync(h_order.data(), order, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    const size_t tb_at = (A.used + 255) & ~(size_t)255;
-    const size_t tb_cap = c->scratch_bytes > tb_at ? c->scratch_bytes - tb_at : 0;
-    uint8_t *tb_base = c->scratch + tb_at;
-    std::vector<uint64_t> h_tboff(n_reads), h_units(n_reads);
-    size_t timed_chunks = 0;
     c->final_launches = 0;
     c->window_misses = 0;
-    for (int phase = 0; phase < 2; ++phase) {
-        if (phase == 1) {
-            uint32_t misses = 0;
-            HIPCHK(c, hipMemcpyAsync(&misses, counters + 2, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            c->window_misses = misses;
-            if (!misses) break;
-            HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-        }
+    const uint32_t n_head = (c->mutate_inline || (!use_wg && n_reads <= c->tail_reads)) ? n_reads
+                            : (use_wg && n_reads <= 2 * c->head_reads) ? 0u : std::min<uint32_t>(c->head_reads, n_reads);
+    const uint32_t n_bulk = n_reads - n_head;
+    uint8_t *win_head = nullptr;
+    if (n_head && n_bulk && !use_wg) {
+        win_head = (uint8_t *)A.take((size_t)std::min(n_head, side_waves) * c->win_bytes);
+        if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
+    } else win_head = win;
+    hipStream_t s_head = n_bulk ? c->side : st;            /* an all-head batch stays on the caller's stream */
+
+    struct FinalSet {
+        uint32_t b, e;                 /* range of `order` */
+        hipStream_t st, wide;          /* its stream; the stream of the widest band class (may be the same) */
+        int id;                        /* 0 head, 1 bulk: selects counter slots and events */
+        bool launched, wide_forked;
+        size_t tb_at, tb_cap;
+        uint64_t bases_by_class[5];    /* G = 1, 2, 4, 8+, all */
+    };
+    FinalSet sets[2];
+    sets[0] = FinalSet{0, n_head, s_head, (c->wide_stream && n_bulk) ? c->side2 : s_head, 0, false, false, 0, 0, {0, 0, 0, 0, 0}};
+    sets[1] = FinalSet{n_head, n_reads, st, st, 1, false, false, 0, 0, {0, 0, 0, 0, 0}};
+    uint64_t *set_units = units_sorted, *set_tboff = tboff_sorted;      /* staging arrays, indexed by order position */
+    std::vector<uint64_t> h_tboff(n_reads), h_units(n_reads);
+    /* counters: [0],[3] join queues of head / bulk; [1] flags; [2],[4] window misses of head / bulk;
+       [16 + 16 x ((set x 2 + phase) x BRX_MAX_CHUNKS + chunk)] final-stage queue heads */
+    auto set_counter = [&](const FinalSet &S, int which) -> uint32_t * { return counters + (which == 0 ? (S.id ? 3 : 0) : (S.id ? 4 : 2)); };
+    uint64_t tail_bases = 0;           /* kernel statistics: bases of the bulk reads that finished in the in-place tail */
+
+    /* launches of one phase of one set (phase 0: windowed store for every read; phase 1: full store for the misses) */
+    auto launch_final_phase = [&](FinalSet &S, int phase) -> int {
+        const uint32_t ns = S.e - S.b;
         uint64_t max_units = 0, sum_units = 0;
-        for (uint32_t i = 0; i < n_reads; ++i) {
+        for (uint32_t i = S.b; i < S.e; ++i) {
             const RS &r = h_rs[h_order[i]];
             uint64_t u = r.units;
             if (phase == 1) {
@@ -445,68 +424,326 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             h_units[i] = u;
             max_units = std::max(max_units, u); sum_units += u;
         }
-        if ((max_units + 64) * 8 > tb_cap) {
-            size_t want = std::min<uint64_t>((sum_units + 64ull * n_reads) * 8, (uint64_t)8 << 30);
-            return scratch_short(c, tb_at + std::max<size_t>((size_t)(max_units + 64) * 8, want));
+        if (phase == 0) {
+            /* this set's share of the arena: everything that is left, minus (for whichever set comes first) an
+               estimate of what the other set will ask for */
+            const size_t at = (A.used + 255) & ~(size_t)255;
+            size_t left = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
+            const FinalSet &O = sets[1 - S.id];
+            if (!O.launched && O.e > O.b) {
+                uint64_t other = 0;
+                for (uint32_t i = O.b; i < O.e; ++i) other += h_rs[h_order[i]].n;
+                const size_t reserve = (size_t)std::min<uint64_t>(other * (O.id == 0 ? 260ull : 110ull) + ((uint64_t)64 << 20), (uint64_t)left / 2);
+                left -= reserve;
+            }
+            const size_t want = (size_t)std::min<uint64_t>((sum_units + 32ull * ns) * 8 + 4096, (uint64_t)left);
+            if ((max_units + 64) * 8 > want) {
+                size_t ask = std::min<uint64_t>((sum_units + 64ull * n_reads) * 8, (uint64_t)8 << 30);
+                return scratch_short(c, c->scratch_bytes + std::max<size_t>((size_t)(max_units + 64) * 8, ask));
+            }
+            S.tb_at = at; S.tb_cap = want;
+            (void)A.take(want);
+        } else if ((sum_units + 32ull * ns) * 8 > S.tb_cap) {
+            /* the full stores of the misses do not fit the region phase 0 used: by now both sets have taken what they
+               need, so the rest of the arena is free */
+            const size_t at = (A.used + 255) & ~(size_t)255;
+            const size_t left = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
+            if (left > S.tb_cap) {
+                const size_t want = (size_t)std::min<uint64_t>((sum_units + 32ull * ns) * 8 + 4096, (uint64_t)left);
+                S.tb_at = at; S.tb_cap = want;
+                (void)A.take(want);
+            }
+            if ((max_units + 64) * 8 > S.tb_cap) return scratch_short(c, c->scratch_bytes + (size_t)(max_units + 64) * 8);
         }
+        uint8_t *tb_base = c->scratch + S.tb_at;
         std::vector<std::pair<uint32_t, uint32_t>> chunks;
         {
-            uint32_t begin = 0; uint64_t used = 0;
-            for (uint32_t i = 0; i < n_reads; ++i) {
+            uint32_t begin = S.b; uint64_t used = 0;
+            for (uint32_t i = S.b; i < S.e; ++i) {
                 uint64_t need = ((h_units[i] + 31) & ~31ull) * 8;      /* 256-byte granules */
-                if (used + need > tb_cap) { chunks.push_back({begin, i}); begin = i; used = 0; }
+                if (used + need > S.tb_cap) { chunks.push_back({begin, i}); begin = i; used = 0; }
                 h_tboff[i] = used; used += need;
             }
-            chunks.push_back({begin, n_reads});
+            chunks.push_back({begin, S.e});
         }
-        if (chunks.size() > BRX_MAX_CHUNKS) return scratch_short(c, tb_at + (size_t)std::min<uint64_t>((sum_units + 64ull * n_reads) * 8 / 8 + 1, (uint64_t)64 << 30));
+        if (chunks.size() > BRX_MAX_CHUNKS) return scratch_short(c, c->scratch_bytes + (size_t)std::min<uint64_t>((sum_units + 64ull * ns) * 8 / 8 + 1, (uint64_t)64 << 30));
         /* tb_off (and, in phase 1, the full-band units) go back through staging arrays in processing order */
-        HIPCHK(c, hipMemcpyAsync(tboff_sorted, h_tboff.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, st));
-        if (phase == 1) HIPCHK(c, hipMemcpyAsync(units_sorted, h_units.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_set_tboff, dim3(nb64), dim3(64), 0, st, n_reads, rs, order, tboff_sorted, phase == 1 ? units_sorted : (uint64_t *)nullptr);
+        HIPCHK(c, hipMemcpyAsync(set_tboff + S.b, h_tboff.data() + S.b, (size_t)ns * 8, hipMemcpyHostToDevice, S.st));
+        if (phase == 1) HIPCHK(c, hipMemcpyAsync(set_units + S.b, h_units.data() + S.b, (size_t)ns * 8, hipMemcpyHostToDevice, S.st));
+        hipLaunchKernelGGL(k_set_tboff, dim3((ns + 63) / 64), dim3(64), 0, S.st, ns, rs, order + S.b, set_tboff + S.b,
+                           phase == 1 ? set_units + S.b : (uint64_t *)nullptr);
         for (size_t ci = 0; ci < chunks.size(); ++ci) {
             uint32_t b = chunks[ci].first, e = chunks[ci].second;
             if (e == b) continue;
             uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
-            uint32_t *cq = counters + 16 + 16 * ((size_t)phase * BRX_MAX_CHUNKS + ci);     /* this chunk's queue heads */
-            /* The widest bands (8+ words per lane: a few dozen reads, but each a chain of ~100 k column steps of
-               ~2 us) and the 4-word class start first, on the side stream; the main stream aligns the one- and
-               two-word classes (most of the reads) beside them and scores those reads without waiting; the wide
-               reads are scored after the join. */
-            HIPCHK(c, hipEventRecord(c->ev_fork, st));
-            HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-            hipLaunchKernelGGL((k_fin_align<16, 8, 64>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, c->side,
-                               dev, rs, order, b, e, cq + 0, counters + 2, phase, Fbuf, seqbuf, opsbuf, tb_base, clk);
-            hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, c->side,
-                               dev, rs, order, b, e, cq + 4, counters + 2, phase, Fbuf, seqbuf, opsbuf, tb_base, clk);
-            if (!c->fin_balance)
-                hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, c->side,
-                                   dev, rs, order, b, e, cq + 1, counters + 2, phase, Fbuf, seqbuf, opsbuf, tb_base, clk);
-            HIPCHK(c, hipEventRecord(c->ev_join, c->side));
-            const bool timed = phase == 0;
-            if (timed) HIPCHK(c, hipEventRecord(c->ev_a1b[ci], st));
-            hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, cq + 2, counters + 2, phase,
-                               Fbuf, seqbuf, opsbuf, tb_base, clk);
-            if (timed) HIPCHK(c, hipEventRecord(c->ev_a1e[ci], st));
-            if (c->fin_balance)
-                hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, st,
-                                   dev, rs, order, b, e, cq + 1, counters + 2, phase, Fbuf, seqbuf, opsbuf, tb_base, clk);
-            if (timed) HIPCHK(c, hipEventRecord(c->ev_qsb[ci], st));
-            hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, st, dev, rs, order, b, e, cq + 3, phase, 1, c->fin_balance ? 2 : 1,
-                               seqbuf, opsbuf, tb_base, clk);
-            if (timed) HIPCHK(c, hipEventRecord(c->ev_qse[ci], st));
-            HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
-            hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, st, dev, rs, order, b, e,
-                               cq + 5, phase, c->fin_balance ? 3 : 2, 0xFFFF, seqbuf, opsbuf, tb_base, clk);
+            uint32_t *cq = counters + 16 + 16 * (((size_t)S.id * 2 + (size_t)phase) * BRX_MAX_CHUNKS + ci);     /* this chunk's queue heads */
+            uint32_t *misses = set_counter(S, 1);
+            /* The widest bands (8+ words per lane: a few dozen reads, each a chain of ~100 k column steps of ~2 us)
+               go first, on the set's wide stream when it has one; then the 4-, 2- and 1-word classes on the set's
+               own stream, each scored (k_fin_qscore) as soon as its class is aligned. */
+            const bool fork = S.wide != S.st;
+            if (fork) {
+                HIPCHK(c, hipEventRecord(c->ev_fork2[S.id], S.st));
+                HIPCHK(c, hipStreamWaitEvent(S.wide, c->ev_fork2[S.id], 0));
+            }
+            if (S.bases_by_class[3] || phase == 1) {
+                KTIMED(BRX_KERN_FIN_ALIGN16, S.wide);
+                hipLaunchKernelGGL((k_fin_align<16, 8, 64>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
+                                   dev, rs, order, b, e, cq + 0, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
+            }
+            if (fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
+            if (S.bases_by_class[2] || phase == 1) {
+                KTIMED(BRX_KERN_FIN_ALIGN4, S.st);
+                hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st,
+                                   dev, rs, order, b, e, cq + 4, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
+            }
+            if (S.bases_by_class[1] || phase == 1) {
+                KTIMED(BRX_KERN_FIN_ALIGN2, S.st);
+                hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, S.st,
+                                   dev, rs, order, b, e, cq + 1, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
+            }
+            {
+                KTIMED(BRX_KERN_FIN_ALIGN1, S.st);
+                hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 2, misses, phase,
+                                   Fbuf, c->scratch, c->scratch, tb_base, clk);
+            }
+            {
+                KTIMED(BRX_KERN_FIN_QSCORE, S.st);
+                hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 3, phase, 1, 4,
+                                   c->scratch, c->scratch, tb_base, clk);
+            }
+            if (fork) HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join2[S.id], 0));
+            if (S.bases_by_class[3] || phase == 1) {
+                KTIMED(BRX_KERN_FIN_QSCORE, S.st);
+                hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
+                                   cq + 5, phase, 5, 0xFFFF, c->scratch, c->scratch, tb_base, clk);
+            }
         }
-        if (phase == 0) { timed_chunks = chunks.size(); c->final_launches = (uint32_t)chunks.size(); }
+        if (phase == 0) c->final_launches += (uint32_t)chunks.size();
+        return BRX_OK;
+    };
+
+    /* a set whose mutate kernels are all enqueued on its stream: legacy fallback, sizes, join, phase 0 of the final stage */
+    auto start_final = [&](FinalSet &S) -> int {
+        const uint32_t ns = S.e - S.b;
+        S.launched = true;
+        if (ns == 0) return BRX_OK;
+        uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
+        uint32_t *legacy = mctr + (S.id ? 3 : 5) * MC_WORDS;                       /* [0] count, [1] queue */
+        HIPCHK(c, hipMemcpyAsync(h_ctr, legacy, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, S.st));
+        HIPCHK(c, hipMemcpyAsync(h_ctr + 2, counters + 1, 4, hipMemcpyDeviceToHost, S.st));
+        { int rcw = wait_stream(c, S.st, S.id ? "mutate stage (bulk)" : "mutate stage (head)"); if (rcw) return rcw; }
+        if (h_ctr[2] & 1u) {                              /* an in-loop alignment did not fit its window scratch */
+            c->win_bytes *= 4;
+            return scratch_short(c, c->scratch_bytes + (size_t)side_waves * c->win_bytes);
+        }
+        /* reads whose window did not fit a slot: the whole-read kernel with the inline wave aligner */
+        DBG("set %d: %u reads, %u to the whole-read kernel", S.id, ns, h_ctr[0]);
+        if (h_ctr[0] > 0 && !use_wg)
+            hipLaunchKernelGGL(k_mutate, dim3(std::min(S.id ? side_waves : std::min(n_head, side_waves), h_ctr[0])), dim3(64), 0, S.st, dev, rs,
+                               S.id ? req_legacy : req_legacy_head, legacy, legacy + 1, Fbuf, repl, S.id ? win : win_head,
+                               (uint64_t)c->win_bytes, counters + 1, clk);
+        hipLaunchKernelGGL(k_scan_mut, dim3(1), dim3(64), 0, S.st, ns, rs, order + S.b, totals + (S.id ? 3 : 8));
+        HIPCHK(c, hipMemcpyAsync(c->h_totals + (S.id ? 3 : 6), totals + (S.id ? 3 : 8), 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, S.st));
+        HIPCHK(c, hipMemcpyAsync(h_ctr + 2, counters + 1, 4, hipMemcpyDeviceToHost, S.st));
+        { int rcw = wait_stream(c, S.st, "k_scan_mut"); if (rcw) return rcw; }
+        if (h_ctr[2] & 1u) {                              /* ... nor did an alignment of the whole-read kernel */
+            c->win_bytes *= 4;
+            return scratch_short(c, c->scratch_bytes + (size_t)side_waves * c->win_bytes);
+        }
+        const uint64_t seq_bytes = c->h_totals[S.id ? 3 : 6], ops_bytes = c->h_totals[S.id ? 4 : 7];
+        uint8_t *seqbuf = (uint8_t *)A.take((size_t)seq_bytes + 64);
+        uint8_t *opsbuf = (uint8_t *)A.take((size_t)ops_bytes + 64);
+        if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
+        {
+            KTIMED(BRX_KERN_FIN_JOIN, S.st);
+            hipLaunchKernelGGL(k_fin_join, dim3(std::min<uint64_t>(ns, (uint64_t)c->n_cu * 16u)), dim3(64), 0, S.st, dev, rs, order, S.b, S.e,
+                               set_counter(S, 0), (uint64_t)(seqbuf - c->scratch), (uint64_t)(opsbuf - c->scratch), Fbuf, repl, pieces, c->scratch);
+        }
+        HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, S.st));
+        { int rcw = wait_stream(c, S.st, "k_fin_join"); if (rcw) return rcw; }
+        for (uint32_t i = S.b; i < S.e; ++i) {
+            const RS &r = h_rs[h_order[i]];
+            if (!r.n) continue;
+            const uint32_t kl = r.klass & 0xFFFFu;
+            S.bases_by_class[kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3] += r.n;
+            S.bases_by_class[4] += r.n;
+        }
+        return launch_final_phase(S, 0);
+    };
+
+    /* blocking: phase 0 of the set is done; repeat its window misses with the full store */
+    auto finish_final = [&](FinalSet &S) -> int {
+        if (S.e == S.b) return BRX_OK;
+        uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);
+        HIPCHK(c, hipMemcpyAsync(h_ctr, set_counter(S, 1), 4, hipMemcpyDeviceToHost, S.st));
+        { int rcw = wait_stream(c, S.st, S.id ? "final stage (bulk)" : "final stage (head)"); if (rcw) return rcw; }
+        const uint32_t misses = h_ctr[0];
+        c->window_misses += misses;
+        if (!misses) return BRX_OK;
+        HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, S.st));
+        HIPCHK(c, hipStreamSynchronize(S.st));
+        int rcp = launch_final_phase(S, 1);
+        if (rcp) return rcp;
+        return wait_stream(c, S.st, "final stage, second phase");
+    };
+
+    HIPCHK(c, hipMemcpyAsync(h_order.data(), order, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemsetAsync(msv, 0, (size_t)n_reads * sizeof(MS), st));
+    HIPCHK(c, hipMemsetAsync(mctr, 0, 8 * MC_WORDS * sizeof(uint32_t), st));
+    {
+        uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
+        memset(h_ctr, 0, 2 * MC_WORDS * sizeof(uint32_t));
+        h_ctr[MC_OUT] = n_bulk;                    /* block 2: "previous pass" of the first bulk pass */
+        h_ctr[MC_WORDS + MC_OUT] = n_head;         /* block 4 (copied below): the head launch's input count */
+        HIPCHK(c, hipMemcpyAsync(mctr + 2 * MC_WORDS, h_ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(mctr + 4 * MC_WORDS, h_ctr + MC_WORDS, MC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    const uint32_t lane_threshold = c->lane_threshold;   /* fewer active reads than this: one wave per window (lower latency) */
+    auto launch_run = [&](hipStream_t s, uint32_t count, const uint32_t *act_in, const uint32_t *n_in, uint32_t *act_out, uint32_t *ctr,
+                          uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr) {
+        KTIMED(BRX_KERN_MUTATE_RUN, s);
+        if (c->profile)
+            hipLaunchKernelGGL((k_mutate_seg<true, true>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
+                               req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
+                               winscr, (uint64_t)c->win_bytes, counters + 1, phase);
+        else
+            hipLaunchKernelGGL((k_mutate_seg<true, false>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
+                               req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
+                               winscr, (uint64_t)c->win_bytes, counters + 1, phase);
+    };
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_MUTATE], st));
+    /* ---- BRX_MUTATE_WG (default): the whole mutate stage is one launch (brx_mutate_wg.h); the two sets only split the final stage ---- */
+    if (use_wg) {
+        uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
+        uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;
+        {
+            KTIMED(BRX_KERN_MUTATE_RUN, st);
+            if (c->profile)
+                hipLaunchKernelGGL((k_mutate_wg<true>), dim3(wg_blocks), dim3(64 * BRX_WG_WAVES), 0, st, dev, rs, order, n_reads, mctr + MC_QUEUE,
+                                   req_legacy, legacy_ctr, Fbuf, repl, winbuf, pack_tb, win, (uint64_t)c->win_bytes, counters + 1, clk, phase);
+            else
+                hipLaunchKernelGGL((k_mutate_wg<false>), dim3(wg_blocks), dim3(64 * BRX_WG_WAVES), 0, st, dev, rs, order, n_reads, mctr + MC_QUEUE,
+                                   req_legacy, legacy_ctr, Fbuf, repl, winbuf, pack_tb, win, (uint64_t)c->win_bytes, counters + 1, clk, phase);
+        }
+        c->mutate_passes = 1;
+        HIPCHK(c, hipMemcpyAsync(h_ctr, legacy_ctr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        { int rcw = wait_stream(c, st, "k_mutate_wg"); if (rcw) return rcw; }
+        if (h_ctr[0] > 0)            /* reads whose window did not fit a slot: the whole-read kernel with the inline wave aligner */
+            hipLaunchKernelGGL(k_mutate, dim3(std::min(side_waves, h_ctr[0])), dim3(64), 0, st, dev, rs, req_legacy, legacy_ctr,
+                               legacy_ctr + 1, Fbuf, repl, win, (uint64_t)c->win_bytes, counters + 1, clk);
+        if (n_head && n_bulk) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, st));
+            HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
+        }
+        tail_bases = 0;
+    }
+    /* ---- head chain: mutate to completion ---- */
+    if (n_head && !use_wg) {
+        if (n_bulk) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, st));
+            HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
+        }
+        launch_run(s_head, n_head, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, req_legacy_head,
+                   mctr + 5 * MC_WORDS, win_head);
+        if (n_bulk) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
+        c->mutate_passes = 1;
+    }
+    /* ---- bulk chain: passes ---- */
+    int rc2 = BRX_OK;
+    if (n_bulk && !use_wg) {
+        const uint32_t seg_waves = std::min<uint64_t>(n_bulk, (uint64_t)c->n_cu * (uint64_t)c->seg_waves_per_cu);
+        uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
+        uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;                                 /* [0] count, [1] queue; not reset per pass */
+        const uint32_t *n_in = mctr + 2 * MC_WORDS + MC_OUT;
+        const uint32_t *act_in = order + n_head;
+        uint32_t n_up = n_bulk, pass = 0;
+        const uint32_t tail_reads = c->tail_reads;   /* this few reads left: run them to completion in place (no host round trips) */
+        auto read_counts = [&](uint32_t *ctr) -> int {
+            HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            return wait_stream(c, st, "mutate pass");
+        };
+        auto poll_head = [&]() -> int {      /* the head set's final stage starts as soon as its reads are mutated */
+            if (sets[0].launched || hipEventQuery(c->ev_head_mut) != hipSuccess) return BRX_OK;
+            return start_final(sets[0]);
+        };
+        for (; n_up > 0 && pass < (1u << 20); ++pass) {
+            uint32_t *ctr = mctr + (pass & 1u) * MC_WORDS;
+            uint32_t *act_out = (pass & 1u) ? active_b : active_a;
+            HIPCHK(c, hipMemsetAsync(ctr, 0, MC_WORDS * sizeof(uint32_t), st));
+            if (n_up <= tail_reads) {
+                if (c->ktiming) {
+                    std::vector<uint32_t> h_act(n_up);
+                    HIPCHK(c, hipMemcpyAsync(h_act.data(), act_in, (size_t)n_up * 4, hipMemcpyDeviceToHost, st));
+                    HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, st));
+                    HIPCHK(c, hipStreamSynchronize(st));
+                    for (uint32_t x : h_act) if (x < n_reads) tail_bases += h_rs[x].n;
+                }
+                launch_run(st, n_up, act_in, n_in, act_out, ctr, req_legacy, legacy_ctr, win);
+                rc2 = read_counts(ctr);
+                if (rc2) return rc2;
+                n_up = h_ctr[MC_OUT];                   /* 0 unless a window overflowed its slot (then: legacy list) */
+                ++pass;
+                break;
+            }
+            {
+                KTIMED(BRX_KERN_MUTATE_SEG, st);
+                if (c->profile)
+                    hipLaunchKernelGGL((k_mutate_seg<false, true>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                                       ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
+                                       win, (uint64_t)c->win_bytes, counters + 1, phase);
+                else
+                    hipLaunchKernelGGL((k_mutate_seg<false, false>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                                       ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
+                                       win, (uint64_t)c->win_bytes, counters + 1, phase);
+            }
+            if (n_up > lane_threshold) {
+                KTIMED(BRX_KERN_WIN_LANE, st);
+                hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64)), dim3(64), 0, st, msv, req_easy,
+                                   ctr + MC_EASY, winbuf, lane_tb);
+            }
+            {
+                KTIMED(BRX_KERN_WIN_WAVE, st);
+                hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
+                                   ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1);
+            }
+            /* the active count only shrinks: look at it every 4th pass while it is large, every pass near the end */
+            if (n_up <= 4 * std::min<uint32_t>(tail_reads, 48u) || n_up <= tail_reads + 64 || (pass & 3u) == 3u) {
+                rc2 = read_counts(ctr);
+                if (rc2) return rc2;
+                n_up = h_ctr[MC_OUT];
+                rc2 = poll_head();
+                if (rc2) return rc2;
+            }
+            n_in = ctr + MC_OUT;
+            act_in = act_out;
+        }
+        c->mutate_passes += pass;
+        if (n_up > 0) return fail(c, BRX_E_INTERNAL, "mutate pipeline did not converge after %u passes", pass);
+    }
+    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_MUTATE], st));
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_SCAN], st));
+    HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_SCAN], st));
+    HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_FINAL], st));
+    /* ---- final stages: whichever set is not started yet (head first: it is the longer chain), then wait for both ---- */
+    if (!sets[0].launched) { rc2 = start_final(sets[0]); if (rc2) return rc2; }
+    rc2 = start_final(sets[1]); if (rc2) return rc2;
+    rc2 = finish_final(sets[0]); if (rc2) return rc2;
+    rc2 = finish_final(sets[1]); if (rc2) return rc2;
+    if (n_head && n_bulk) {                           /* join: the records need both sets */
+        HIPCHK(c, hipEventRecord(c->ev_join, s_head));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
     }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_FINAL], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_EMIT], st));
 
     /* ---- stage: records ---- */
-    hipLaunchKernelGGL(k_recsize, dim3(nb64), dim3(64), 0, st, dev, rs, pieces);
-    hipLaunchKernelGGL(k_scan_rec, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
+    {
+        KTIMED(BRX_KERN_EMIT, st);
+        hipLaunchKernelGGL(k_recsize, dim3(nb64), dim3(64), 0, st, dev, rs, pieces);
+        hipLaunchKernelGGL(k_scan_rec, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
+    }
     rc = read_totals(c, st, totals, 6);
     if (rc) return rc;
     const uint64_t rec_bytes = c->h_totals[5];
@@ -514,8 +751,11 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         c->output_needed = rec_bytes;
         return fail(c, BRX_E_OUTPUT, "output buffer too small: need %llu bytes", (unsigned long long)rec_bytes);
     }
-    hipLaunchKernelGGL(k_emit, dim3(n_reads), dim3(64), 0, st, dev, rs, pieces, seqbuf, d_out);
-    hipLaunchKernelGGL(k_stats, dim3(nb64), dim3(64), 0, st, dev, rs, d_stats);
+    {
+        KTIMED(BRX_KERN_EMIT, st);
+        hipLaunchKernelGGL(k_emit, dim3(n_reads), dim3(64), 0, st, dev, rs, pieces, c->scratch, d_out);
+        hipLaunchKernelGGL(k_stats, dim3(nb64), dim3(64), 0, st, dev, rs, d_stats);
+    }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_EMIT], st));
     { int rcw = wait_stream(c, st, "final stage / k_emit"); if (rcw) return rcw; }
     HIPCHK(c, hipGetLastError());
@@ -524,13 +764,29 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         if (i != BRX_STAGE_ALIGN1 && i != BRX_STAGE_QSCORE) (void)hipEventElapsedTime(&ms, c->ev_b[i], c->ev_e[i]);
         c->stage_ms[i] = ms;
     }
-    /* per-launch AVERAGE over the scratch chunks, which is what a kernel trace reports */
-    for (size_t ci = 0; ci < timed_chunks; ++ci) {
-        float a = 0.f, q = 0.f;
-        (void)hipEventElapsedTime(&a, c->ev_a1b[ci], c->ev_a1e[ci]);
-        (void)hipEventElapsedTime(&q, c->ev_qsb[ci], c->ev_qse[ci]);
-        c->stage_ms[BRX_STAGE_ALIGN1] += a / (float)timed_chunks;
-        c->stage_ms[BRX_STAGE_QSCORE] += q / (float)timed_chunks;
+    /* per-kernel launch statistics (brx_set_kernel_timing): every event pair recorded by KTIMED above */
+    if (c->ktiming) {
+        if (n_head && n_bulk) HIPCHK(c, hipStreamSynchronize(c->side));
+        if (sets[0].wide_forked) HIPCHK(c, hipStreamSynchronize(c->side2));
+        for (int i = 0; i < c->kev_n; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->kev_b[i], c->kev_e[i]) != hipSuccess) continue;
+            c->kstat[c->kev_kind[i]].launches += 1;
+            c->kstat[c->kev_kind[i]].ms += ms;
+        }
+        uint64_t all = 0, head_b = 0;
+        for (uint32_t i = 0; i < n_reads; ++i) { all += h_rs[h_order[i]].n; if (i < n_head) head_b += h_rs[h_order[i]].n; }
+        const double by_class[4] = {(double)(sets[0].bases_by_class[0] + sets[1].bases_by_class[0]), (double)(sets[0].bases_by_class[1] + sets[1].bases_by_class[1]),
+                                    (double)(sets[0].bases_by_class[2] + sets[1].bases_by_class[2]), (double)(sets[0].bases_by_class[3] + sets[1].bases_by_class[3])};
+        c->kstat[BRX_KERN_PLAN].bases = c->kstat[BRX_KERN_BUILD].bases = c->kstat[BRX_KERN_FIN_JOIN].bases =
+            c->kstat[BRX_KERN_FIN_QSCORE].bases = c->kstat[BRX_KERN_EMIT].bases = (double)all;
+        c->kstat[BRX_KERN_MUTATE_RUN].bases = (double)(head_b + tail_bases);
+        c->kstat[BRX_KERN_MUTATE_SEG].bases = c->kstat[BRX_KERN_WIN_LANE].bases = c->kstat[BRX_KERN_WIN_WAVE].bases = (double)(all - head_b);
+        c->kstat[BRX_KERN_FIN_ALIGN1].bases = by_class[0]; c->kstat[BRX_KERN_FIN_ALIGN2].bases = by_class[1];
+        c->kstat[BRX_KERN_FIN_ALIGN4].bases = by_class[2]; c->kstat[BRX_KERN_FIN_ALIGN16].bases = by_class[3];
+        /* compatibility: the two per-launch stage entries of brx_last_stage_ms */
+        if (c->kstat[BRX_KERN_FIN_ALIGN1].launches) c->stage_ms[BRX_STAGE_ALIGN1] = c->kstat[BRX_KERN_FIN_ALIGN1].ms / (float)c->kstat[BRX_KERN_FIN_ALIGN1].launches;
+        if (c->kstat[BRX_KERN_FIN_QSCORE].launches) c->stage_ms[BRX_STAGE_QSCORE] = c->kstat[BRX_KERN_FIN_QSCORE].ms / (float)c->kstat[BRX_KERN_FIN_QSCORE].launches;
     }
     if (out_bytes) *out_bytes = (size_t)rec_bytes;
     /* a read that exhausted its 1000 tries is fatal in the reference (simulate.py:164) */

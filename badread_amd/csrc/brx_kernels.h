@@ -468,15 +468,25 @@ __device__ inline void dev_random_change(const uint8_t *kmer, int k, uint32_t w3
 }
 
 /* returns false if the k-mer is unchanged */
-__device__ inline bool dev_choose_alt(const brx_error_model &em, const uint8_t *kmer, uint32_t w2, uint32_t w3, uint32_t *rep) {
+/* thr16: the high halves of self_thr[] staged in LDS (k_mutate_wg; nullptr elsewhere).  hi(w2) < thr16[row] proves
+   w2 < self_thr[row] and hi(w2) > thr16[row] the opposite: the ~93 % of draws that leave the k-mer unchanged
+   (simulate.py:300) are rejected without touching global memory; one draw in 65536 needs the full word. */
+__device__ inline bool dev_choose_alt(const brx_error_model &em, const uint8_t *kmer, uint32_t w2, uint32_t w3, uint32_t *rep,
+                                      const uint16_t *thr16 = nullptr) {
     const int k = em.k;
     if (em.type == 0) { dev_random_change(kmer, k, w3, rep); return true; }
     uint32_t row = 0; bool bad = false;
 #pragma unroll
     for (int j = 0; j < 16; ++j) if (j < k) { bad |= kmer[j] > 3; row = (row << 2) | (kmer[j] & 3u); }
     if (bad) { dev_random_change(kmer, k, w3, rep); return true; }
-    uint32_t st = em.d_self_thr[row];
-    if (w2 < st) return false;                                   /* the common case: unchanged */
+    if (thr16) {
+        const uint32_t h = thr16[row], wh = w2 >> 16;
+        if (wh < h) return false;                                /* the common case: unchanged */
+        if (wh == h && w2 < em.d_self_thr[row]) return false;
+    } else {
+        uint32_t st = em.d_self_thr[row];
+        if (w2 < st) return false;                               /* the common case: unchanged */
+    }
     uint32_t a0 = em.d_row_off[row], a1 = em.d_row_off[row + 1];
     if (a0 == a1) { dev_random_change(kmer, k, w3, rep); return true; }
     /* first alternative whose cumulative threshold exceeds the draw (thresholds are non-decreasing):
@@ -685,23 +695,27 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
 }
 
 #include "brx_mutate.h"
+#include "brx_pack.h"
+#include "brx_mutate_wg.h"
 
-/* offsets for the final stage.  totals: [3]=seq bytes [4]=ops bytes */
-__global__ void __launch_bounds__(64) k_scan_mut(uint32_t n_reads, RS *rs, uint64_t *totals) {
+/* offsets for the final stage of one SET of reads (list[0..n): a range of the processing order), relative to the
+   set's seq / ops buffers.  totals: [0]=seq bytes [1]=ops bytes */
+__global__ void __launch_bounds__(64) k_scan_mut(uint32_t n, RS *rs, const uint32_t *list, uint64_t *totals) {
     const int lane = lane_id();
     uint64_t seq_run = 0, ops_run = 0;
-    for (uint32_t base = 0; base < n_reads; base += 64) {
-        uint32_t r = base + lane;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t r = i < n ? list[i] : 0u;
         uint32_t sb = 0, ob = 0;
-        if (r < n_reads && rs[r].n) {
+        if (i < n && rs[r].n) {
             sb = 2u * ((rs[r].m + 16u + 15u) >> 4);                 /* seq + qual, 16-byte units */
             ob = (rs[r].m + rs[r].n + 16u + 15u) >> 4;
         }
         uint32_t is = wave_incl_scan(sb), io = wave_incl_scan(ob);
-        if (r < n_reads) { rs[r].seq_off = (seq_run + is - sb) << 4; rs[r].ops_off = (ops_run + io - ob) << 4; }
+        if (i < n) { rs[r].seq_off = (seq_run + is - sb) << 4; rs[r].ops_off = (ops_run + io - ob) << 4; }
         seq_run += wave_bcast_u32(is, 63); ops_run += wave_bcast_u32(io, 63);
     }
-    if (lane == 0) { totals[3] = seq_run << 4; totals[4] = ops_run << 4; }
+    if (lane == 0) { totals[0] = seq_run << 4; totals[1] = ops_run << 4; }
 }
 
 /* rs[order[i]].tb_off = off[i] (and .units = units[i] when given): the host lays traceback stores out in
@@ -745,16 +759,23 @@ __device__ inline int64_t qs_lookup(const brx_qscore_model &qm, uint64_t key) {
 #define BRX_KL_FULL 0x20000u      /* never windowed: the read holds a junk piece (low-complexity repeats, where
                                      the canonical traceback collects every indel at one end of the repeat) */
 
-__global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, uint32_t *queue, const uint8_t *Fbuf, const uint32_t *repl,
-                                                  const PPiece *pieces, uint8_t *seqbuf) {
+/* One set of reads (order[q_begin..q_end)).  seq_base / ops_base: where the set's seq and ops buffers start in the
+   arena; from here on RS.seq_off / RS.ops_off are offsets from the arena base (`arena`), whichever set a read is in. */
+__global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end, uint32_t *queue,
+                                                  uint64_t seq_base, uint64_t ops_base, const uint8_t *Fbuf, const uint32_t *repl,
+                                                  const PPiece *pieces, uint8_t *arena) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     for (;;) {
-        const uint32_t r = wave_pop(queue);
-        if (r >= d.n_reads) break;
+        const uint32_t qi = q_begin + wave_pop(queue);
+        if (qi >= q_end) break;
+        const uint32_t r = order[qi];
         const RS s = rs[r];
-        if (s.n == 0) continue;
-        uint8_t *seq = seqbuf + s.seq_off;
+        if (s.n == 0) {
+            if (lane == 0) { rs[r].seq_off = seq_base; rs[r].ops_off = ops_base; }
+            continue;
+        }
+        uint8_t *seq = arena + seq_base + s.seq_off;
         wave_join(em, Fbuf + s.F_off, repl + s.F_off, 0, s.n, seq, nullptr);
         for (uint32_t x = lane; x < 16; x += 64) seq[s.m + x] = 0xFE;        /* the aligner reads up to 16 bytes past the end */
         if (lane == 0) {
@@ -762,6 +783,7 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, uint32_t *que
             bool junk = false, too_wide;
             if (!d.raw_mode) for (uint32_t i = 0; i < s.n_pieces; ++i) junk |= (pieces[s.piece_off + i].w0 & 3u) == PC_JUNK;
             RS *o = &rs[r];
+            o->seq_off = seq_base + s.seq_off; o->ops_off = ops_base + s.ops_off;
             o->klass = (g.G ? (uint32_t)g.G : 64u) | (junk ? BRX_KL_FULL : 0u);
             o->units = brx_final_units(s.m, s.n, s.ub, junk ? 0 : d.tb_hmul, &too_wide);     /* traceback store + col_of[] */
             if (too_wide) o->status = s.status | BRX_RS_BAND;

@@ -79,6 +79,14 @@ assert READ_STATS_DTYPE.itemsize == 64
 RS_NOFRAG, RS_TOO_MANY_SEGS, RS_BAND, RS_QMISS, RS_EMPTY = 1, 2, 4, 8, 16
 E_SCRATCH, E_OUTPUT, E_NOFRAG = -3, -4, -5
 STAGE_NAMES = ('plan', 'build', 'mutate', 'scan', 'final', 'emit', 'align1', 'qscore')
+# kernel classes of brx_last_kernel_stats (include/brx.h: BRX_KERN_*), with the names a rocprofv3 kernel trace shows
+KERNEL_NAMES = ('k_plan_*', 'k_build', 'k_mutate_seg<false>', 'k_mutate_seg<true>', 'k_win_lane', 'k_win_wave', 'k_fin_join',
+                'k_fin_align<1,1,1>', 'k_fin_align<2,2,2>', 'k_fin_align<4,4,4>', 'k_fin_align<16,8,64>', 'k_fin_qscore',
+                'k_emit+k_recsize')
+
+
+class BrxKernelStat(ctypes.Structure):
+    _fields_ = [('launches', ctypes.c_uint32), ('ms', ctypes.c_float), ('bases', ctypes.c_double)]
 
 
 class SimParams(object):
@@ -244,6 +252,10 @@ def bind_library(lib):
     lib.brx_last_read_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
     lib.brx_last_phase_cycles.restype = ctypes.c_int
     lib.brx_last_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    lib.brx_set_kernel_timing.restype = ctypes.c_int
+    lib.brx_set_kernel_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.brx_last_kernel_stats.restype = ctypes.c_int
+    lib.brx_last_kernel_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(BrxKernelStat * len(KERNEL_NAMES))]
     lib.brx_last_mutate_passes.restype = ctypes.c_uint32
     lib.brx_last_mutate_passes.argtypes = [ctypes.c_void_p]
     lib.brx_last_final_launches.restype = ctypes.c_uint32
@@ -475,6 +487,16 @@ class HipEngine(EngineBase):
         out = np.zeros((n_reads, 8), dtype=np.uint64)
         self._check(self.lib.brx_last_phase_cycles(self.ctx, out.ctypes.data, n_reads))
         return out
+
+    def set_kernel_timing(self, on=True):
+        """Bracket every kernel launch of the following batches with HIP events (brx_last_kernel_stats)."""
+        self._check(self.lib.brx_set_kernel_timing(self.ctx, 1 if on else 0))
+
+    def kernel_stats(self):
+        """{kernel name: (launches, total ms, bases handled)} of the last batch (zeros unless set_kernel_timing)."""
+        arr = (BrxKernelStat * len(KERNEL_NAMES))()
+        self._check(self.lib.brx_last_kernel_stats(self.ctx, ctypes.byref(arr)))
+        return {name: (int(a.launches), float(a.ms), float(a.bases)) for name, a in zip(KERNEL_NAMES, arr)}
 
     def mutate_passes(self):
         return int(self.lib.brx_last_mutate_passes(self.ctx))

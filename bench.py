@@ -2,30 +2,44 @@
 """
 bench.py -- simulated bases per second of the HIP hot path on N MI355X (one process per GPU).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--workload human|hifi|kpn]
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on that fits one GPU):
-a synthetic "K. pneumoniae-like" reference -- one circular 5.3 Mb chromosome plus two circular
-plasmids (200 kb depth=2, 5 kb depth=10), uniform ACGT from numpy default_rng(1) -- default
-`badread simulate` parameters (length 15000,13000; identity 95,99,2.5; nanopore2023 error and
-qscore models; default adapters, junk/random/chimera 1 %, glitches 10000,25,25), seed 42.
-A "step" is ONE pass of the whole hot path (plan -> fragments -> mutate -> align -> qscores ->
-FASTQ bytes) over one batch of `--reads-per-step` read indices per GPU (default 131072 reads x 15 kb
-~ 2 Gbases, seven times the 50x job).  The batch goes through the C-ABI as `--streams` device
-batches (brx_simulate_batch, 16384 reads each by default) that are in flight together, one context
-+ HIP stream + host thread each; device batches of consecutive steps follow each other without a
-barrier, exactly as the CLI driver runs them (badread_amd.simulate.run_batches).  Inputs (packed
-reference, model tables) are resident in HBM before the timed region; the FASTQ bytes stay in HBM
-(the PCIe-inclusive rate is reported separately as `value_incl_d2h`).  Weak scaling: every rank
-processes its own slices of the read-index space, no collective on the data path.
+With N > 1 and no WORLD_SIZE in the environment the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU; a
+WORLD_SIZE that differs from --gpus is an error (it never silently measures fewer GPUs than asked for).
 
-The JSON line carries `roofline` (dominant kernel, HBM bound, algorithmic bytes = 2.26 B per
-simulated base) and `cpu_baseline` (the C oracle -- a single-threaded port of
-the same algorithm -- run on all host cores of this box on a bounded sample of the same workload).
+Workloads (BASELINE.json configs; tools/synth_refs.py writes the references as FASTA and they
+are loaded through the native packer brx_fasta_pack + its sidecar, like a user's genome):
+  human  (default) configs[3], the configuration the metric is quoted on: synthetic GRCh38-like reference -- 24 LINEAR
+         contigs with the GRCh38 primary chromosome lengths (3 088 269 832 bp = 772 MB packed, one replica per GPU),
+         uniform ACGT, 10 kb of N at both ends of every contig, a 1 Mb N run inside chr1, chr9, chrX -- default
+         `badread simulate` parameters (--length 15000,13000 --identity 95,99,2.5, nanopore2023 error + qscore models,
+         default adapters, junk/random/chimera 1 %, glitches 10000,25,25), seed 42
+  hifi   configs[4]: the same reference, --error_model pacbio2021 --qscore_model pacbio2021 --identity 30,3
+  kpn    configs[1]: 5.5 Mb K. pneumoniae-like reference (3 circular contigs, numpy default_rng(1)), defaults (round 1's line)
+
+A "step" is ONE pass of the whole hot path (plan -> fragments -> mutate -> align -> qscores -> FASTQ bytes) over
+one batch of `--reads-per-step` read indices per GPU (default 131072 reads x 15 kb ~ 2 Gbases; the 30x job is 47 such
+steps per GPU on 8 GPUs).  The batch goes through the C-ABI as `--streams` device batches (brx_simulate_batch, 16384
+reads each by default) that are in flight together, one context + HIP stream + host thread each; device batches of
+consecutive steps follow each other without a barrier, exactly as the CLI driver runs them
+(badread_amd.simulate.run_batches).  Inputs (packed reference, model tables) are resident in HBM before the timed
+region; the FASTQ bytes stay in HBM (`--d2h` adds the PCIe-inclusive rate as `value_incl_d2h`).  Weak scaling: every
+rank processes its own slices of the read-index space; no collective on the data path.
+
+The JSON line carries
+  roofline       the kernel with the largest summed launch time in this very run (per-kernel HIP events around
+                 every launch, on the stream the kernel is launched on: brx_last_kernel_stats), HBM bound, algorithmic
+                 bytes = 2.26 B per simulated base x the bases that kernel handled / its launches
+  roofline_alu   wave-level VALU instructions issued per second (from the committed SQ_INSTS_VALU count per base,
+                 profiles/) against the chip's VALU issue rate -- the roofline that actually bounds this integer path
+  cpu_baseline   the C oracle (a single-threaded port of the same algorithm) on every usable host core of this box,
+                 on a bounded sample of the same workload; `reference` inside it is the UNMODIFIED Python reference +
+                 edlib shim measured in the CPU container by tools/ref_cpu_baseline.py (profiles/cpu_reference_baseline.json)
 """
 import argparse
 import os as _os
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '40')      # a hardware queue per stream of every in-flight batch: main + side stream each (HIP's default of 4 serialises them)
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '40')      # a hardware queue per stream of every in-flight batch (HIP's default of 4 serialises them)
 import json
 import os
 import sys
@@ -35,45 +49,96 @@ import time
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
-if REPO not in sys.path:
-    sys.path.insert(0, REPO)
+for _p in (REPO, os.path.join(REPO, 'tools')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 ALGO_BYTES_PER_BASE = 2.26          # 0.25 B packed reference read + 2 B FASTQ written + header share
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_PER_S = 256 * 4 * 2.4e9 / 2      # 1024 SIMDs x 2.4 GHz, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md)
 SEED = 42
+
+WORKLOADS = {
+    'human': dict(ref='grch38', em='nanopore2023', qm='nanopore2023', identity=(95.0, 99.0, 2.5),
+                  text='configs[3]: synthetic GRCh38-like 3.09 Gb reference (24 linear contigs, N runs at contig ends '
+                       'and inside chr1/chr9/chrX), nanopore2023 error+qscore models, --identity 95,99,2.5 --length '
+                       '15000,13000, other badread simulate parameters at their defaults, seed 42'),
+    'hifi': dict(ref='grch38', em='pacbio2021', qm='pacbio2021', identity=(30.0, None, 3.0),
+                 text='configs[4]: synthetic GRCh38-like 3.09 Gb reference, pacbio2021 error+qscore models, '
+                      '--identity 30,3 (qscore-distributed), --length 15000,13000, other parameters default, seed 42'),
+    'kpn': dict(ref='kpn', em='nanopore2023', qm='nanopore2023', identity=(95.0, 99.0, 2.5),
+                text='configs[1]: 5.5 Mb K. pneumoniae-like synthetic reference (3 circular contigs), nanopore2023 '
+                     'error+qscore models, default badread simulate parameters, seed 42'),
+}
 
 
 def kpneumoniae_like():
-    """configs[1] reference: names, sequences, depths, circular flags."""
+    """configs[1] reference as Python strings (tests and tools): names, sequences, depths, circular flags."""
     import collections
-    rng = np.random.default_rng(1)
+    import synth_refs
     seqs = collections.OrderedDict()
     depths, circular = {}, {}
-    for name, length, depth in (('chromosome', 5300000, 1.0), ('plasmid_1', 200000, 2.0), ('plasmid_2', 5000, 10.0)):
-        seqs[name] = np.frombuffer(b'ACGT', dtype=np.uint8)[rng.integers(0, 4, length)].tobytes().decode()
-        depths[name], circular[name] = depth, True
+    for name, seq, depth in synth_refs.kpneumoniae_like_seqs():
+        seqs[name] = seq.tobytes().decode()
+        depths[name], circular[name] = float(depth), True
     return seqs, depths, circular
 
 
-def build_workload(io_null):
+def reference_fasta(kind, ref_dir, scale=1.0):
+    """Path of the workload's FASTA under ref_dir, written on first use (atomically)."""
+    import synth_refs
+    os.makedirs(ref_dir, exist_ok=True)
+    if kind == 'kpn':
+        path = os.path.join(ref_dir, 'kpneumoniae_like.fa')
+        if not os.path.isfile(path):
+            synth_refs.write_kpneumoniae_like(path)
+        return path
+    tag = 'grch38_like' if scale == 1.0 else f'grch38_like_x{scale:.5f}'
+    path = os.path.join(ref_dir, tag + '.fa')
+    if not os.path.isfile(path):
+        synth_refs.write_grch38_like(path, scale=scale)
+    return path
+
+
+def load_reference(kind, ref_dir, scale=1.0, timing=None):
+    """PackedReference of the workload through the native packer; the packed form is cached beside the FASTA
+    (`.brx2bit` sidecar), so the ranks of one node and the CPU-baseline workers read it instead of re-packing."""
+    from badread_amd.reference import PackedReference
+    t0 = time.perf_counter()
+    fasta = reference_fasta(kind, ref_dir, scale)
+    t1 = time.perf_counter()
+    had_sidecar = os.path.isfile(fasta + '.brx2bit')
+    pref = PackedReference.from_fasta(fasta, cache=True)
+    t2 = time.perf_counter()
+    if timing is not None:
+        timing.update({'fasta_write_s': round(t1 - t0, 2), 'fasta_pack_or_sidecar_load_s': round(t2 - t1, 2),
+                       'sidecar_hit': had_sidecar, 'fasta_bytes': os.path.getsize(fasta)})
+    return pref
+
+
+def build_workload(io_null, workload='kpn', ref_dir=None, scale=1.0, timing=None):
     from badread_amd.engine import SimParams
     from badread_amd.error_model import ErrorModel
     from badread_amd.fragment_lengths import FragmentLengths
     from badread_amd.identities import Identities
     from badread_amd.qscore_model import QScoreModel
-    from badread_amd.reference import PackedReference
     from badread_amd.simulate import adjust_depths
-    seqs, depths, circular = kpneumoniae_like()
-    pref = PackedReference.from_seqs(seqs, depths, circular)
+    w = WORKLOADS[workload]
+    pref = load_reference(w['ref'], ref_dir or default_ref_dir(), scale, timing)
     frag = FragmentLengths(15000, 13000, io_null)
-    ident = Identities(95, 2.5, 99, io_null)
+    mean, mx, sd = w['identity']
+    ident = Identities(mean, sd, mx, io_null)
     depths = adjust_depths(pref, frag, False, np.random.RandomState(SEED))
     _, cum = pref.contig_weights(depths)
-    mode, a, b, mx = ident.device_mode()
-    params = SimParams(frag_mean=15000, frag_stdev=13000, identity_mode=mode, id_a=a, id_b=b, id_max=mx)
-    em = ErrorModel('nanopore2023', io_null).tables()
-    qm = QScoreModel('nanopore2023', io_null).tables()
+    mode, a, b, mx_ = ident.device_mode()
+    params = SimParams(frag_mean=15000, frag_stdev=13000, identity_mode=mode, id_a=a, id_b=b, id_max=mx_)
+    em = ErrorModel(w['em'], io_null).tables()
+    qm = QScoreModel(w['qm'], io_null).tables()
     return pref, cum, em, qm, params
+
+
+def default_ref_dir():
+    return os.environ.get('BRX_BENCH_REF_DIR', '/tmp/brx_bench_refs')
 
 
 def configure(engine, wl):
@@ -85,12 +150,13 @@ def configure(engine, wl):
     return engine
 
 
-def cpu_worker(first_read, budget_s, out_path):
+# ------------------------------------------------------------------------------------------------ CPU baseline leg
+def cpu_worker(first_read, budget_s, out_path, workload, ref_dir):
     """One process = one core: the oracle over 16-read chunks of the same read-index stream for `budget_s` seconds."""
     import io
     sys.path.insert(0, os.path.join(REPO, 'oracle'))
     import pyoracle
-    eng = configure(pyoracle.OracleEngine(), build_workload(io.StringIO()))
+    eng = configure(pyoracle.OracleEngine(), build_workload(io.StringIO(), workload, ref_dir))
     eng.simulate_batch(SEED, first_read, 2)                      # page everything in before the clock starts
     bases = reads = 0
     t0 = time.perf_counter()
@@ -115,10 +181,11 @@ def usable_cores():
     return cores
 
 
-def cpu_baseline(first_read, budget_s):
+def cpu_baseline(first_read, budget_s, workload, ref_dir):
     """The oracle (oracle/brx_oracle.c, a scalar C port of the same path: gamma/beta draws, fragment build, mutate
-    loop with block-Myers window alignments, final alignment + traceback, qscore lookup, FASTQ record) on EVERY host
-    usable core (usable_cores()): one single-threaded process per core, disjoint slices of the same read-index stream, own clock each."""
+    loop with block-Myers window alignments, final alignment + traceback, qscore lookup, FASTQ record) on EVERY
+    usable host core (usable_cores()): one single-threaded process per core, disjoint slices of the same read-index
+    stream, own clock each.  `reference` = the unmodified Python reference measured in the CPU container."""
     import subprocess
     import tempfile
     cores = usable_cores()
@@ -128,7 +195,7 @@ def cpu_baseline(first_read, budget_s):
     for i in range(cores):
         out = os.path.join(tmp, f'{i}.json')
         procs.append((out, subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(first_read + i * 100000),
-                                             str(budget_s), out], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+                                             str(budget_s), out, workload, ref_dir], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
     bases = reads = 0
     rate = 0.0
     done = 0
@@ -137,20 +204,53 @@ def cpu_baseline(first_read, budget_s):
         if os.path.isfile(out):
             rec = json.load(open(out))
             bases += rec['bases']; reads += rec['reads']; rate += rec['bases'] / rec['seconds']; done += 1
-    return {'value': rate, 'unit': 'bases/s', 'cores': done, 'kind': 'port',
-            'sample': f'{reads} reads / {bases} bases of the same workload and seed, {budget_s:.0f} s of CPU time per core, '
-                      f'oracle/brx_oracle.c (gcc -O2) as one single-threaded process per host core; value = sum of the '
-                      f'per-process rates'}
+    result = {'value': rate, 'unit': 'bases/s', 'cores': done, 'kind': 'port',
+              'sample': f'{reads} reads / {bases} bases of the same workload ({workload}: full reference, same seed and '
+                        f'read-index stream), {budget_s:.0f} s of CPU time per core, oracle/brx_oracle.c (gcc -O2) as one '
+                        f'single-threaded process per host core; value = sum of the per-process rates'}
+    ref_file = os.path.join(REPO, 'profiles', 'cpu_reference_baseline.json')
+    if os.path.isfile(ref_file):
+        try:
+            rec = json.load(open(ref_file)).get(workload)
+            if rec:
+                result['reference'] = {k: rec[k] for k in ('value', 'unit', 'cores', 'kind', 'per_core', 'reference_genome', 'sample', 'host', 'measured_by') if k in rec}
+                result['port_over_reference_per_core'] = (rate / max(done, 1)) / rec['per_core']
+        except (OSError, ValueError, KeyError):
+            pass
+    return result
+
+
+def valu_per_base(workload):
+    """SQ_INSTS_VALU per simulated base of this workload from the committed counter pass (profiles/), or None."""
+    path = os.path.join(REPO, 'profiles', 'valu_per_base.json')
+    try:
+        return json.load(open(path)).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+# ------------------------------------------------------------------------------------------------ launch
+def respawn_under_torchrun(args_list, n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) and wait."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + args_list
+    return subprocess.call(cmd)
 
 
 def main():
-    if len(sys.argv) >= 5 and sys.argv[1] == '--cpu-worker':
-        cpu_worker(int(sys.argv[2]), float(sys.argv[3]), sys.argv[4])
+    if len(sys.argv) >= 7 and sys.argv[1] == '--cpu-worker':
+        cpu_worker(int(sys.argv[2]), float(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6])
         return
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='human', choices=sorted(WORKLOADS))
     ap.add_argument('--reads-per-step', type=int, default=131072,
                     help='read indices per GPU per step; split into --streams device batches')
     ap.add_argument('--scratch-gb', type=float, default=30.0, help='scratch arena per in-flight batch')
@@ -159,66 +259,115 @@ def main():
                          'read of one device batch overlaps the bulk of the others')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='seconds each host core runs the cpu_baseline leg (0 = skip)')
     ap.add_argument('--d2h', action='store_true', help='also time steps that copy the FASTQ bytes to pinned host memory')
+    ap.add_argument('--ref-dir', default=default_ref_dir(), help='where the synthetic reference FASTA and its packed sidecar live')
+    ap.add_argument('--ref-scale', type=float, default=1.0, help='shrink the GRCh38-like reference (tests, dry runs); 1.0 = the metric\'s 3.09 Gb')
+    ap.add_argument('--cpu-engine', action='store_true',
+                    help='DRY RUN of the launch / sharding / reporting logic on the CPU checker engine over gloo (tests only: '
+                         'the line it prints is marked invalid and measures nothing)')
     args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '0') or 0)
+    if world == 0 and args.gpus > 1:
+        sys.exit(respawn_under_torchrun(sys.argv[1:], args.gpus))
+    world = max(world, 1)
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure a different number of GPUs than asked for')
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
 
     import io
     import torch
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
+    dry = args.cpu_engine
+    if not dry and not torch.cuda.is_available():
         sys.exit('bench.py needs a ROCm device: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local)
+    if not dry:
+        if torch.cuda.device_count() < world:
+            sys.exit(f'bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) visible')
+        torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+        if dry:
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
 
-    from badread_amd.engine import HipEngine
-    wl = build_workload(io.StringIO())
-    C = max(1, args.streams)
-    R = max(64, args.reads_per_step // C)              # reads per device batch (one brx_simulate_batch call)
-    engines = [configure(HipEngine(local, scratch_bytes=int(args.scratch_gb * (1 << 30))), wl) for _ in range(C)]
-    streams = [torch.cuda.Stream(device=local) for _ in range(C)]
-    eng = engines[0]
-    for e, st_ in zip(engines, streams):              # prime every context (lazy module load, buffers) -- not a step
-        with torch.cuda.stream(st_):
-            e.simulate_batch_device(SEED, 2 ** 40, 64, expected_bytes=R * 36000)
-    torch.cuda.synchronize()
-
-    def step(index, e=None):
-        first = (index * world + rank) * R
-        out, stats = (e or eng).simulate_batch_device(SEED, first, R, expected_bytes=R * 36000)
-        return out, stats
-
-    def sync():
-        torch.cuda.synchronize()
+    def barrier():
+        if not dry:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not dry:
+                torch.cuda.synchronize()
+
+    # ---- reference: rank 0 writes the FASTA and packs it (sidecar), the other ranks then load the sidecar ----
+    ref_timing = {}
+    wl = None
+    if rank == 0:
+        wl = build_workload(io.StringIO(), args.workload, args.ref_dir, args.ref_scale, ref_timing)
+    barrier()
+    if rank != 0:
+        wl = build_workload(io.StringIO(), args.workload, args.ref_dir, args.ref_scale, None)
+    pref = wl[0]
+
+    C = max(1, args.streams)
+    R = max(64, args.reads_per_step // C)              # reads per device batch (one brx_simulate_batch call)
+    if dry:
+        sys.path.insert(0, os.path.join(REPO, 'oracle'))
+        import pyoracle
+        engines = [configure(pyoracle.OracleEngine(), wl)]
+        engines += [engines[0].clone() for _ in range(C - 1)]
+        streams = [None] * C
+    else:
+        from badread_amd.engine import HipEngine
+        t_up = time.perf_counter()
+        first = configure(HipEngine(local, scratch_bytes=int(args.scratch_gb * (1 << 30))), wl)
+        torch.cuda.synchronize()
+        ref_timing['h2d_tables_s'] = round(time.perf_counter() - t_up, 2)
+        engines = [first] + [first.clone() for _ in range(C - 1)]       # clones share the device tables: ONE replica of the reference per GPU
+        streams = [torch.cuda.Stream(device=local) for _ in range(C)]
+        for e, st_ in zip(engines, streams):              # prime every context (lazy module load, buffers) -- not a step
+            e.set_kernel_timing(True)
+            with torch.cuda.stream(st_):
+                e.simulate_batch_device(SEED, 2 ** 40, 64, expected_bytes=R * 36000)
+        torch.cuda.synchronize()
+
+    def run_one(e, index):
+        first_read = (index * world + rank) * R
+        if dry:
+            _, stats = e.simulate_batch(SEED, first_read, R)
+            return stats
+        _, stats = e.simulate_batch_device(SEED, first_read, R, expected_bytes=R * 36000)
+        return stats
 
     def run_steps(step_indices):
         """The device batches of steps `step_indices`, C in flight: worker i owns context i / stream i and takes
         every C-th device batch; batch b of step k covers read indices ((k*C + b)*world + rank)*R ..."""
         indices = [k * C + b for k in step_indices for b in range(C)]
-        acc = [{'bases': 0, 'g1_bases': 0, 'passes': 0, 'stages': {}, 'final_launches': 0, 'misses': 0, 'error': None} for _ in range(C)]
+        acc = [{'bases': 0, 'passes': 0, 'stages': {}, 'kernels': {}, 'final_launches': 0, 'misses': 0, 'bad': 0, 'error': None} for _ in range(C)]
 
         def worker(i):
             try:
-                torch.cuda.set_device(local)
-                with torch.cuda.stream(streams[i]):
+                if not dry:
+                    torch.cuda.set_device(local)
+                ctx = torch.cuda.stream(streams[i]) if not dry else _Null()
+                with ctx:
                     for idx in indices[i::C]:
-                        _, stats = step(idx, engines[i])
+                        stats = run_one(engines[i], idx)
                         acc[i]['bases'] += int(stats['seq_len'].sum())
-                        g_words = engines[i].read_cycles(R)[:, 7]
-                        acc[i]['g1_bases'] += int(stats['seq_len'][g_words == 1].sum())
+                        acc[i]['bad'] += int((stats['status'] & 0xE).astype(bool).sum())     # RS_TOO_MANY_SEGS | RS_BAND | RS_QMISS
+                        if dry:
+                            continue
                         acc[i]['passes'] += engines[i].mutate_passes()
                         for name, ms in engines[i].stage_ms().items():
                             acc[i]['stages'][name] = acc[i]['stages'].get(name, 0.0) + ms
+                        for name, (n_l, ms, b) in engines[i].kernel_stats().items():
+                            k = acc[i]['kernels'].setdefault(name, [0, 0.0, 0.0])
+                            k[0] += n_l; k[1] += ms; k[2] += b
                         acc[i]['final_launches'] += engines[i].final_launches()
                         acc[i]['misses'] += engines[i].window_misses()
-                    streams[i].synchronize()
+                    if not dry:
+                        streams[i].synchronize()
             except BaseException as ex:          # surfaced on the main thread
                 acc[i]['error'] = ex
 
@@ -233,34 +382,30 @@ def main():
         return acc
 
     run_steps(list(range(args.warmup)) if args.warmup else [])
-    sync()
+    barrier()
     t0 = time.perf_counter()
     acc = run_steps([args.warmup + k for k in range(args.steps)])
-    sync()
+    barrier()
     elapsed = time.perf_counter() - t0
     bases = sum(a['bases'] for a in acc)
-    final_launches = sum(a['final_launches'] for a in acc)
-    stage_sum = {}
-    for a in acc:
-        for name, ms in a['stages'].items():
-            stage_sum[name] = stage_sum.get(name, 0.0) + ms
+    bad = sum(a['bad'] for a in acc)
 
-    t = torch.tensor([elapsed, float(bases)], dtype=torch.float64, device='cuda')
+    t = torch.tensor([elapsed, float(bases), float(bad)], dtype=torch.float64, device='cpu' if dry else 'cuda')
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, bases = float(tmax[0].item()), float(t[1].item())
+        elapsed, bases, bad = float(tmax[0].item()), float(t[1].item()), float(t[2].item())
     value = bases / elapsed
 
     d2h = None
-    if args.d2h and rank == 0:
+    if args.d2h and rank == 0 and not dry:
         host = torch.empty(R * 40000, dtype=torch.uint8).pin_memory()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         b2 = 0
         for k in range(args.steps):
-            out, stats = step(args.warmup + k)
+            out, stats = engines[0].simulate_batch_device(SEED, ((args.warmup + k) * world + rank) * R, R, expected_bytes=R * 36000)
             host[:out.numel()].copy_(out, non_blocking=False)
             b2 += int(stats['seq_len'].sum())
         torch.cuda.synchronize()
@@ -270,53 +415,93 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    stages = {k: v / (args.steps * C) for k, v in stage_sum.items()}          # per device batch
-    # dominant single kernel: k_fin_align<1,1,1> (final banded Myers alignment + traceback of the reads whose band
-    # fits one 32-bit word per lane); stage 'align1' is the HIP-event duration of ONE launch, averaged over launches
-    kernel = 'k_fin_align<1,1,1>'
-    launches = final_launches / args.steps
-    g1_bases_per_step = sum(a['g1_bases'] for a in acc) / args.steps
-    launch_ms = stages['align1']
-    algo_bytes = ALGO_BYTES_PER_BASE * g1_bases_per_step / launches
+    n_batches = args.steps * C
+    stage_sum, kern = {}, {}
+    for a in acc:
+        for name, ms in a['stages'].items():
+            stage_sum[name] = stage_sum.get(name, 0.0) + ms
+        for name, (n_l, ms, b) in a['kernels'].items():
+            k = kern.setdefault(name, [0, 0.0, 0.0])
+            k[0] += n_l; k[1] += ms; k[2] += b
+    stages = {k: v / n_batches for k, v in stage_sum.items()}          # per device batch
+    bases_per_step_rank0 = sum(a['bases'] for a in acc) / args.steps
+    result = {
+        'metric': 'simulated bases/sec', 'value': value, 'unit': 'bases/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
+        'config': {'workload': WORKLOADS[args.workload]['text'] + ('' if args.ref_scale == 1.0 else f' [REFERENCE SCALED x{args.ref_scale}: dry run]'),
+                   'reference_bases': int(pref.n_bases), 'reference_contigs': len(pref.names), 'reference_non_acgt_runs': int(len(pref.exceptions)),
+                   'reads_per_step_per_gpu': R * C, 'bases_per_step_per_gpu': bases_per_step_rank0,
+                   'device_batches_per_step': C, 'reads_per_device_batch': R,
+                   'parallelism': f'reads sharded by index over {world} GPU(s), reference replicated per GPU, no collectives on the data path'},
+        'reference_load': ref_timing,
+        'reads_flagged_band_segs_qmiss': bad,
+    }
+    if dry:
+        result['INVALID'] = 'dry run on the CPU checker engine (--cpu-engine): exercises launch / sharding / reporting only'
+        result['roofline'] = result['cpu_baseline'] = None
+        print(json.dumps(result), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    # ---- roofline of the kernel that ranks first by summed launch time in THIS run (what rocprofv3 --stats ranks first) ----
+    ranked = sorted(((ms, name) for name, (n_l, ms, b) in kern.items() if n_l), reverse=True)
+    top = ranked[0][1]
+    n_l, ms, kb = kern[top]
+    launch_ms = ms / n_l
+    bases_per_launch = kb / n_l
+    algo_bytes = ALGO_BYTES_PER_BASE * bases_per_launch
     achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
-    bases_per_step_rank0 = bases / (args.steps * world)
     traffic = None
     tfile = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
     if os.path.isfile(tfile):
         try:
             rec = json.load(open(tfile))
-            if rec.get('reads_per_step') == R and rec.get('kernel') == kernel:
+            if rec.get('reads_per_step') == R and rec.get('kernel') == top and rec.get('workload', 'kpn') == args.workload:
                 traffic = rec.get('hbm_bytes_per_launch')
         except (OSError, ValueError):
             pass
-    result = {
-        'metric': 'simulated bases/sec', 'value': value, 'unit': 'bases/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
-        'config': {'workload': 'configs[1]: 5.5 Mb K. pneumoniae-like synthetic reference (3 circular contigs), '
-                               'nanopore2023 error+qscore models, default badread simulate parameters, seed 42',
-                   'reads_per_step_per_gpu': R * C, 'bases_per_step_per_gpu': bases_per_step_rank0,
-                   'device_batches_per_step': C, 'reads_per_device_batch': R,
-                   'parallelism': f'reads sharded by index over {world} GPU(s), reference replicated, no collectives'},
-        'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'algorithmic_bytes_per_launch': algo_bytes, 'bases_per_launch': g1_bases_per_step / launches,
-                     'launch_ms': launch_ms, 'launches_per_step': launches,
-                     'note': 'integer-ALU / latency bound path: see DESIGN.md section 5; one launch per device batch; '
-                             'launch_ms is the HIP-event duration of one launch while other batches share the GPU'},
-        'stage_ms_per_device_batch': stages, 'mutate_passes_per_device_batch': sum(a['passes'] for a in acc) / (args.steps * C),
-        'traceback_window_misses_per_step': sum(a['misses'] for a in acc) / args.steps,
-    }
+    result['roofline'] = {'bound': 'hbm', 'kernel': top, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                          'algorithmic_bytes_per_launch': algo_bytes, 'bases_per_launch': bases_per_launch,
+                          'launch_ms': launch_ms, 'launches_per_device_batch': n_l / n_batches,
+                          'whole_path_frac': value / world * ALGO_BYTES_PER_BASE / 1e9 / HBM_PEAK_GBS,
+                          'note': 'kernel = largest summed launch time of this run (HIP events around every launch on its own '
+                                  'stream); bases_per_launch = fragment bases of the reads the kernel class handled / launches '
+                                  '(a read counts once per class); launch_ms includes time the launch shares the GPU with '
+                                  'the other batches in flight; integer-ALU / latency bound path: see roofline_alu'}
+    result['kernels_per_device_batch'] = {name: {'launches': n_l / n_batches, 'ms': ms / n_batches, 'avg_launch_ms': ms / n_l,
+                                                  'mbases': b / n_batches / 1e6}
+                                          for name, (n_l, ms, b) in sorted(kern.items(), key=lambda kv: -kv[1][1]) if n_l}
+    vpb = valu_per_base(args.workload)
+    if vpb:
+        rate = vpb['valu_per_base'] * value / world
+        result['roofline_alu'] = {'bound': 'valu-issue', 'achieved': rate, 'peak': VALU_PEAK_PER_S, 'unit': 'wave-instructions/s',
+                                  'frac': rate / VALU_PEAK_PER_S, 'valu_per_base': vpb['valu_per_base'], 'source': vpb.get('source')}
+    result['stage_ms_per_device_batch'] = stages
+    result['mutate_passes_per_device_batch'] = sum(a['passes'] for a in acc) / n_batches
+    result['traceback_window_misses_per_step'] = sum(a['misses'] for a in acc) / args.steps
     if d2h is not None:
         result['value_incl_d2h'] = d2h
     if world == 1 and args.cpu_seconds > 0:
-        result['cpu_baseline'] = cpu_baseline(10_000_000, args.cpu_seconds)
+        result['cpu_baseline'] = cpu_baseline(10_000_000, args.cpu_seconds, args.workload, args.ref_dir)
         result['gpu_over_cpu'] = value / result['cpu_baseline']['value']
+        if 'reference' in result['cpu_baseline']:
+            ref = result['cpu_baseline']['reference']
+            result['gpu_over_reference_same_cores'] = value / (ref['per_core'] * result['cpu_baseline']['cores'])
     else:
         result['cpu_baseline'] = None
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+class _Null(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 if __name__ == '__main__':

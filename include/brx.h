@@ -250,6 +250,33 @@ int brx_last_read_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
  * Zeros without BRX_PROFILE (the default kernels do not contain the clock reads). */
 int brx_last_phase_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
 uint32_t brx_last_mutate_passes(const brx_ctx *ctx);
+/* Per-kernel launch timing, opt-in (brx_set_kernel_timing(ctx, 1); bench.py and the profiling tools use it): every
+ * launch of the kernels below is bracketed by two HIP events ON THE STREAM THE KERNEL IS LAUNCHED ON, and
+ * brx_last_kernel_stats() returns, for the last brx_simulate_batch / brx_sequence_fragments call, the number of
+ * launches of each kernel, the sum of their event durations and the bases of the reads each kernel handled
+ * (fragment bases incl. pads: a read counts ONCE per kernel class however many passes it took part in).  The
+ * average launch duration ms / launches is what a rocprofv3 kernel trace reports for the same kernel. */
+enum { BRX_KERN_PLAN = 0,        /* k_plan_count + k_scan_plan + k_plan_fill                                   */
+       BRX_KERN_BUILD = 1,       /* k_build                                                                    */
+       BRX_KERN_MUTATE_SEG = 2,  /* k_mutate_seg<false>: bulk passes of the mutate loop                        */
+       BRX_KERN_MUTATE_RUN = 3,  /* k_mutate_seg<true>: reads run to completion with in-place window alignments */
+       BRX_KERN_WIN_LANE = 4,    /* k_win_lane / k_win_pack: parked window alignments of a bulk pass            */
+       BRX_KERN_WIN_WAVE = 5,    /* k_win_wave                                                                 */
+       BRX_KERN_FIN_JOIN = 6,
+       BRX_KERN_FIN_ALIGN1 = 7,  /* k_fin_align<1,1,1>                                                         */
+       BRX_KERN_FIN_ALIGN2 = 8,  /* k_fin_align<2,2,2>                                                         */
+       BRX_KERN_FIN_ALIGN4 = 9,  /* k_fin_align<4,4,4>                                                         */
+       BRX_KERN_FIN_ALIGN16 = 10,/* k_fin_align<16,8,64>                                                       */
+       BRX_KERN_FIN_QSCORE = 11,
+       BRX_KERN_EMIT = 12,       /* k_recsize + k_scan_rec + k_emit + k_stats                                  */
+       BRX_KERN_COUNT = 13 };
+typedef struct {
+    uint32_t launches;
+    float ms;                  /* sum of the launches' event durations                                          */
+    double bases;              /* fragment bases (RS.n) of the reads this kernel class handled in the call      */
+} brx_kernel_stat;
+int brx_set_kernel_timing(brx_ctx *ctx, int on);
+int brx_last_kernel_stats(const brx_ctx *ctx, brx_kernel_stat out[BRX_KERN_COUNT]);
 uint32_t brx_last_final_launches(const brx_ctx *ctx);
 /* Reads of the last call whose final traceback asked for a cell outside the windowed traceback store and were
  * aligned a second time with the full store (environment BRX_TB_WINDOW: window height in

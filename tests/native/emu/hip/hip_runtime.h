@@ -11,7 +11,7 @@
  * What it buys: the parity tests of the real kernel source run in the CPU test suite, so a logic error in a kernel
  * is caught without a GPU (integer overflow, LDS ring indexing, traceback addressing ...).
  *
- * Limits: one wave (64 threads) per workgroup; cross-lane operations must be reached by all live lanes of the wave
+ * Limits: workgroups of up to 16 waves (64 x W threads); cross-lane operations must be reached by all live lanes of the wave
  * (true for these kernels by construction; a lane that never arrives is reported as a deadlock); no timing fidelity.
  */
 #ifndef BRX_HIP_EMU_H
@@ -49,35 +49,55 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 v; v.x = x; v.y =
 namespace emu {
 
 constexpr int WAVE = 64;
+constexpr int MAXW = 16;                          /* waves per workgroup (1024 threads) */
 constexpr size_t STACK_BYTES = 8u << 20;          /* per lane; mmap'ed, so only touched pages cost memory */
 
+/* One workgroup = up to MAXW waves.  Cross-lane operations rendezvous the live lanes of ONE wave; __syncthreads
+ * rendezvous every live lane of the workgroup.  The scheduler round-robins over all lanes of all waves, so waves of a
+ * workgroup interleave at their cross-lane operations (a wave spinning on LDS written by another wave makes progress
+ * as long as it reaches cross-lane operations or calls emu::spin_yield() inside the spin). */
+struct Wave {
+    int live = 0, arrived = 0;
+    unsigned long long gen = 0;                     /* completed cross-lane operations of this wave */
+    uint64_t slot[2][WAVE];                         /* operands, double-buffered by operation parity */
+};
 struct State {
     ucontext_t sched;
-    ucontext_t lane_ctx[WAVE];
+    ucontext_t lane_ctx[MAXW * WAVE];
     char *stacks = nullptr;
-    bool done[WAVE];
-    int live = 0, arrived = 0;
-    unsigned long long gen = 0;                     /* completed cross-lane operations of the current wave */
-    uint64_t slot[2][WAVE];                         /* operands, double-buffered by operation parity        */
-    int cur = 0;                                    /* running lane                                         */
+    int stacks_for = 0;
+    bool done[MAXW * WAVE];
+    Wave wave[MAXW];
+    int n_threads = WAVE, n_waves = 1;
+    int block_live = 0, bar_arrived = 0;
+    unsigned long long bar_gen = 0;
+    int cur = 0;                                    /* running thread of the workgroup */
     unsigned block = 0, grid = 1;
     const std::function<void()> *body = nullptr;
-    unsigned long long spins = 0;
     unsigned long long clock = 0;
+    unsigned long long yields = 0;
 };
 inline State &S() { static thread_local State s; return s; }     /* host threads (contexts in flight) do not share it */
 
 inline void yield_to_scheduler() { State &s = S(); swapcontext(&s.lane_ctx[s.cur], &s.sched); }
+inline void spin_yield() { State &s = S(); s.yields += 1; yield_to_scheduler(); }
 
-/* all live lanes deposit `v`; returns the buffer holding every lane's operand */
+/* all live lanes of the running lane's wave deposit `v`; returns the buffer holding every lane's operand */
 inline const uint64_t *exchange(uint64_t v) {
     State &s = S();
-    const unsigned long long g = s.gen;
-    uint64_t *buf = s.slot[g & 1];
-    buf[s.cur] = v;
-    if (++s.arrived >= s.live) { s.arrived = 0; s.gen = g + 1; }
-    else while (s.gen == g) yield_to_scheduler();
+    Wave &w = s.wave[s.cur / WAVE];
+    const unsigned long long g = w.gen;
+    uint64_t *buf = w.slot[g & 1];
+    buf[s.cur % WAVE] = v;
+    if (++w.arrived >= w.live) { w.arrived = 0; w.gen = g + 1; }
+    else while (w.gen == g) yield_to_scheduler();
     return buf;
+}
+inline void block_barrier() {
+    State &s = S();
+    const unsigned long long g = s.bar_gen;
+    if (++s.bar_arrived >= s.block_live) { s.bar_arrived = 0; s.bar_gen = g + 1; }
+    else while (s.bar_gen == g) yield_to_scheduler();
 }
 
 inline void lane_entry() {
@@ -85,21 +105,27 @@ inline void lane_entry() {
     (*s.body)();
     s.done[s.cur] = true;                            /* its operand slots keep their last values: slower lanes may still be
                                                         reading the operation this lane has already left */
-    s.live -= 1;
-    if (s.live > 0 && s.arrived >= s.live) { s.arrived = 0; s.gen += 1; }      /* the others were waiting for this lane */
+    Wave &w = s.wave[s.cur / WAVE];
+    w.live -= 1;
+    if (w.live > 0 && w.arrived >= w.live) { w.arrived = 0; w.gen += 1; }      /* the others were waiting for this lane */
+    s.block_live -= 1;
+    if (s.block_live > 0 && s.bar_arrived >= s.block_live) { s.bar_arrived = 0; s.bar_gen += 1; }
     yield_to_scheduler();
 }
 
-inline void run_block(unsigned block, unsigned grid, const std::function<void()> &body) {
+inline void run_block(unsigned block, unsigned grid, int n_threads, const std::function<void()> &body) {
     State &s = S();
-    if (!s.stacks) {
-        s.stacks = (char *)mmap(nullptr, STACK_BYTES * WAVE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (!s.stacks || s.stacks_for < n_threads) {
+        if (s.stacks) munmap(s.stacks, STACK_BYTES * (size_t)s.stacks_for);
+        s.stacks = (char *)mmap(nullptr, STACK_BYTES * (size_t)n_threads, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         if (s.stacks == (char *)MAP_FAILED) { perror("[hip_emu] mmap"); abort(); }
+        s.stacks_for = n_threads;
     }
     s.block = block; s.grid = grid; s.body = &body;
-    s.live = WAVE; s.arrived = 0; s.gen = 0;
-    memset(s.slot, 0, sizeof(s.slot));
-    for (int l = 0; l < WAVE; ++l) {
+    s.n_threads = n_threads; s.n_waves = n_threads / WAVE;
+    s.block_live = n_threads; s.bar_arrived = 0; s.bar_gen = 0;
+    for (int w = 0; w < s.n_waves; ++w) { s.wave[w].live = WAVE; s.wave[w].arrived = 0; s.wave[w].gen = 0; memset(s.wave[w].slot, 0, sizeof(s.wave[w].slot)); }
+    for (int l = 0; l < n_threads; ++l) {
         s.done[l] = false;
         getcontext(&s.lane_ctx[l]);
         s.lane_ctx[l].uc_stack.ss_sp = s.stacks + STACK_BYTES * l;
@@ -107,23 +133,29 @@ inline void run_block(unsigned block, unsigned grid, const std::function<void()>
         s.lane_ctx[l].uc_link = &s.sched;
         makecontext(&s.lane_ctx[l], (void (*)())lane_entry, 0);
     }
-    unsigned long long idle_rounds = 0, last_gen = 0;
-    int last_live = WAVE;
-    while (s.live > 0) {
-        for (int l = 0; l < WAVE; ++l) {
+    unsigned long long idle_rounds = 0, last_prog = ~0ull;
+    while (s.block_live > 0) {
+        for (int l = 0; l < n_threads; ++l) {
             if (s.done[l]) continue;
             s.cur = l;
             swapcontext(&s.sched, &s.lane_ctx[l]);
         }
-        if (s.gen == last_gen && s.live == last_live) {
-            if (++idle_rounds > 4) { fprintf(stderr, "[hip_emu] deadlock: %d of %d live lanes reached a cross-lane operation (block %u)\n", s.arrived, s.live, block); abort(); }
-        } else { idle_rounds = 0; last_gen = s.gen; last_live = s.live; }
+        unsigned long long prog = s.bar_gen * 1315423911ull + (unsigned long long)s.block_live + s.yields * 7919ull;
+        for (int w = 0; w < s.n_waves; ++w) prog = prog * 31ull + s.wave[w].gen;
+        if (prog == last_prog) {
+            if (++idle_rounds > 4) {
+                fprintf(stderr, "[hip_emu] deadlock in block %u: %d live threads;", block, s.block_live);
+                for (int w = 0; w < s.n_waves; ++w) fprintf(stderr, " wave %d: %d of %d at a cross-lane operation;", w, s.wave[w].arrived, s.wave[w].live);
+                fprintf(stderr, " %d at __syncthreads\n", s.bar_arrived);
+                abort();
+            }
+        } else { idle_rounds = 0; last_prog = prog; }
     }
 }
 
 inline void on_segv(int, siginfo_t *info, void *) {
     State &s = S();
-    fprintf(stderr, "[hip_emu] SIGSEGV at %p in lane %d of block %u (stack of that lane: %p..%p)\n", info->si_addr, s.cur, s.block,
+    fprintf(stderr, "[hip_emu] SIGSEGV at %p in thread %d of block %u (stack of that lane: %p..%p)\n", info->si_addr, s.cur, s.block,
             (void *)(s.stacks + STACK_BYTES * s.cur), (void *)(s.stacks + STACK_BYTES * (s.cur + 1)));
     void *frames[48];
     const int n = backtrace(frames, 48);
@@ -144,15 +176,17 @@ inline void install_segv_trace() {
 
 template <class F> inline void launch(dim3 grid, dim3 block, F &&f) {
     install_segv_trace();
-    if (block.x != (unsigned)WAVE || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) { fprintf(stderr, "[hip_emu] only 64x1x1 workgroups\n"); abort(); }
+    if (block.x % WAVE != 0 || block.x == 0 || block.x > (unsigned)(MAXW * WAVE) || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) {
+        fprintf(stderr, "[hip_emu] only (64 x W) x 1 x 1 workgroups, W <= %d\n", MAXW); abort();
+    }
     std::function<void()> body(std::forward<F>(f));
-    for (unsigned b = 0; b < grid.x; ++b) run_block(b, grid.x, body);
+    for (unsigned b = 0; b < grid.x; ++b) run_block(b, grid.x, (int)block.x, body);
 }
 
 struct Idx { unsigned x, y, z; };
 inline Idx tidx() { return Idx{(unsigned)S().cur, 0u, 0u}; }
 inline Idx bidx() { return Idx{S().block, 0u, 0u}; }
-inline Idx bdim() { return Idx{(unsigned)WAVE, 1u, 1u}; }
+inline Idx bdim() { return Idx{(unsigned)S().n_threads, 1u, 1u}; }
 inline Idx gdim() { return Idx{S().grid, 1u, 1u}; }
 
 }  // namespace emu
@@ -170,28 +204,34 @@ static inline unsigned long long __ballot(int pred) {
     const uint64_t *v = emu::exchange(pred ? 1u : 0u);
     unsigned long long m = 0;
     const emu::State &s = emu::S();
-    for (int l = 0; l < emu::WAVE; ++l) if (!s.done[l]) m |= (unsigned long long)(v[l] & 1u) << l;      /* exited lanes: EXEC off */
+    const int w0 = (s.cur / emu::WAVE) * emu::WAVE;
+    for (int l = 0; l < emu::WAVE; ++l) if (!s.done[w0 + l]) m |= (unsigned long long)(v[l] & 1u) << l;      /* exited lanes: EXEC off */
     return m;
 }
-static inline int __shfl(int v, int src, int width = 64) { (void)width; const int me = emu::S().cur; const uint64_t *a = emu::exchange((uint32_t)v); (void)me; return (int)(uint32_t)a[src & 63]; }
-static inline int __shfl_xor(int v, int mask, int width = 64) { (void)width; const int me = emu::S().cur; const uint64_t *a = emu::exchange((uint32_t)v); return (int)(uint32_t)a[(me ^ mask) & 63]; }
-static inline int __shfl_up(int v, unsigned delta, int width = 64) { (void)width; const int me = emu::S().cur; const uint64_t *a = emu::exchange((uint32_t)v); return me >= (int)delta ? (int)(uint32_t)a[me - (int)delta] : v; }
-static inline int __shfl_down(int v, unsigned delta, int width = 64) { (void)width; const int me = emu::S().cur; const uint64_t *a = emu::exchange((uint32_t)v); return me + (int)delta < 64 ? (int)(uint32_t)a[me + (int)delta] : v; }
+static inline int __shfl(int v, int src, int width = 64) { (void)width; const int me = emu::S().cur % emu::WAVE; const uint64_t *a = emu::exchange((uint32_t)v); (void)me; return (int)(uint32_t)a[src & 63]; }
+static inline int __shfl_xor(int v, int mask, int width = 64) { (void)width; const int me = emu::S().cur % emu::WAVE; const uint64_t *a = emu::exchange((uint32_t)v); return (int)(uint32_t)a[(me ^ mask) & 63]; }
+static inline int __shfl_up(int v, unsigned delta, int width = 64) { (void)width; const int me = emu::S().cur % emu::WAVE; const uint64_t *a = emu::exchange((uint32_t)v); return me >= (int)delta ? (int)(uint32_t)a[me - (int)delta] : v; }
+static inline int __shfl_down(int v, unsigned delta, int width = 64) { (void)width; const int me = emu::S().cur % emu::WAVE; const uint64_t *a = emu::exchange((uint32_t)v); return me + (int)delta < 64 ? (int)(uint32_t)a[me + (int)delta] : v; }
 static inline unsigned __shfl(unsigned v, int src, int width = 64) { return (unsigned)__shfl((int)v, src, width); }
 static inline unsigned __shfl_xor(unsigned v, int mask, int width = 64) { return (unsigned)__shfl_xor((int)v, mask, width); }
 static inline unsigned __shfl_up(unsigned v, unsigned delta, int width = 64) { return (unsigned)__shfl_up((int)v, delta, width); }
-static inline void __syncthreads() { (void)emu::exchange(0); }
+static inline void __syncthreads() { emu::block_barrier(); }
 namespace emu {
 inline int dpp(int v, int ctrl) {
+    const int me = S().cur % WAVE;
+    if ((ctrl & 0x1F0) == 0x120 && (ctrl & 15)) {                              /* row_ror:n: rotation inside rows of 16 lanes */
+        const uint64_t *a = exchange((uint32_t)v);
+        return (int)(uint32_t)a[(me & ~15) | ((me - (ctrl & 15)) & 15)];
+    }
     if (ctrl != 0x13C) { fprintf(stderr, "[hip_emu] DPP control %#x not modelled\n", ctrl); abort(); }
-    const int me = S().cur;
     const uint64_t *a = exchange((uint32_t)v);
     return (int)(uint32_t)a[(me + 63) & 63];                                  /* wave_ror:1 */
 }
 inline int readfirstlane(int v) {
     const uint64_t *a = exchange((uint32_t)v);
     State &s = S();
-    for (int l = 0; l < WAVE; ++l) if (!s.done[l]) return (int)(uint32_t)a[l];
+    const int w0 = (s.cur / WAVE) * WAVE;
+    for (int l = 0; l < WAVE; ++l) if (!s.done[w0 + l]) return (int)(uint32_t)a[l];
     return v;
 }
 }  // namespace emu
@@ -210,6 +250,8 @@ inline int readfirstlane(int v) {
 /* ---- scalar helpers ------------------------------------------------------------------------------------- */
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 template <class T, class U> static inline T atomicAdd(T *p, U v) { T old = *p; *p = (T)(old + (T)v); return old; }
@@ -235,6 +277,7 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { re
 static inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(struct emu_event *) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event{0.0}; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }

@@ -72,11 +72,16 @@ def test_aligner_band_classes_iupac_and_hints():
 
 
 ROUTES = [
-    {},                                                        # defaults: in-place tail (few reads), windowed store
-    {'BRX_TAIL_READS': 0, 'BRX_LANE_THRESHOLD': 0},            # passes: every window through the lane kernel
-    {'BRX_TAIL_READS': 0, 'BRX_LANE_THRESHOLD': 1000000},      # passes: every window through the wave kernel
+    {},                                                        # defaults: workgroup mutate kernel (packed window alignments), windowed store
     {'BRX_TB_WINDOW': -1},                                     # 8-row traceback window: most reads repeat (phase 1)
-    {'BRX_TB_WINDOW': 0, 'BRX_FIN_BALANCE': 0},                # full store, wide classes all on the side stream
+    {'BRX_TB_WINDOW': 0, 'BRX_WIDE_STREAM': 0},                # full store, no third stream for the widest class
+    {'BRX_HEAD_READS': 9},                                     # final stage split into a head and a bulk set
+    # the pass pipeline of round 1 (BRX_MUTATE_WG=0)
+    {'BRX_MUTATE_WG': 0},                                                        # in-place tail (few reads)
+    {'BRX_MUTATE_WG': 0, 'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0},         # bulk passes only: every window through the lane kernel
+    {'BRX_MUTATE_WG': 0, 'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 1000000},   # bulk passes only: every window through the wave kernel
+    {'BRX_MUTATE_WG': 0, 'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},         # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
+    {'BRX_MUTATE_WG': 0, 'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
 ]
 
 
@@ -96,6 +101,8 @@ def test_pipeline_routes_equal_the_oracle(env, monkeypatch):
         assert eng.window_misses() >= 3                     # the retry phase ran (short reads: few windows are narrower than the band)
     if env.get('BRX_TAIL_READS') == 0:
         assert eng.mutate_passes() > 3
+    if 'BRX_MUTATE_WG' not in env:
+        assert eng.mutate_passes() == 1
 
 
 def test_pipeline_other_models_and_fragment_kinds():
