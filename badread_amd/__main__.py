@@ -9,8 +9,14 @@ this build's scope and are refused with a message.  Additi
 `python -m torch.distributed.run --nproc-per-node N -m badread_amd simulate ...`; rank 0 writes stdout.
 """
 import argparse
+import os
 import pathlib
 import sys
+
+# A hardware queue per HIP stream of every batch in flight (8 batches x up to 3 streams): HIP's default of 4 queues
+# serialises kernels of different streams.  Must be in the environment before the HIP runtime starts (the first torch.cuda
+# call), which is why it is set here, at the top of the command line's module, and not where the streams are created.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '40')
 
 from . import settings
 from .misc import str_is_dna_sequence, str_is_int

@@ -176,6 +176,14 @@ __device__ __forceinline__ int brx_from_lane_above(int v) {
  * visible to the compiler (ds_read_u8 / ds_write_b32); a generic or volatile pointer to it turns
  * every access into a flat load that waits on vmcnt -- exactly what the window is there to avoid. */
 __shared__ uint32_t brx_ring32[BRX_RING_BYTES / 4];
+/* Kernels whose workgroups hold several independent waves (k_mutate_seg: 8 waves sharing the LDS copy of the error
+ * model's thresholds) give every wave its own window (template parameter MW of the forward passes); a kernel only pays
+ * for the variant it references. */
+#define BRX_RING_WAVES 8
+__shared__ uint32_t brx_ring32_mw[BRX_RING_WAVES][BRX_RING_BYTES / 4];
+template <bool MW> __device__ __forceinline__ uint32_t *brx_ring() {
+    if constexpr (MW) return brx_ring32_mw[threadIdx.x >> 6]; else return brx_ring32;
+}
 
 /* ---------------------------------------------------------------------------------------------
  * forward pass: fills tb[(t*WSp + s%WSp)*G + g] = {Pv after column j, Ph before its shift}
@@ -199,10 +207,11 @@ __device__ __forceinline__ int brx_wave_min(int v) {
 }
 __device__ __forceinline__ uint32_t brx_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   /* v_bfi_b32 */
 
-template <int G>
+template <int G, bool MW = false>
 __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                   const BrxGeom g, uint2 *__restrict__ tb, uint32_t *prog = nullptr) {
     const int lane = threadIdx.x & 63;
+    uint32_t *const ring32 = brx_ring<MW>();
     constexpr int NEVER = 0x7FFFFFFF;
     /* A lane works on superblock s during time steps [tf, tl] (column j = t - s), then hops to s + 64.
      * The band is narrower than 62 superblocks (brx_make_geom), so whenever the lane above was active
@@ -235,14 +244,14 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
         return __ballot(o) != 0ull ? 1u : 0u;
     };
     uint32_t pending = fetch_chunk(0);
-    brx_ring32[lane] = pending;
+    ring32[lane] = pending;
     uint32_t odd = chunk_odd(0, pending);
     pending = fetch_chunk(1);
-    brx_ring32[64 + lane] = pending;
+    ring32[64 + lane] = pending;
     odd |= chunk_odd(1, pending) << 1;
     int s_top = 0;                                   /* first superblock still inside the band (wave-uniform) */
     int t_top = brx_jlast(g, 0) + 1;                 /* time step at which s_top leaves the band              */
-    uint32_t cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(0 - s) & 511u];   /* column 1 - s */
+    uint32_t cnext = reinterpret_cast<const uint8_t *>(ring32)[(uint32_t)(0 - s) & 511u];   /* column 1 - s */
     int next_entry = brx_wave_min(tf);               /* next time step at which some lane's superblock enters */
     int next_hop = brx_wave_min(tl);                 /* ... or leaves the band                                  */
 
@@ -256,7 +265,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
             if ((front & 255) == 128) pending = fetch_chunk((front >> 8) + 1);
             else if ((front & 255) == 192) {
                 const int c = (front >> 8) + 1;
-                brx_ring32[(c & 1) * 64 + lane] = pending;
+                ring32[(c & 1) * 64 + lane] = pending;
                 odd = (odd & ~(1u << (c & 1))) | (chunk_odd(c, pending) << (c & 1));
             }
         }
@@ -343,7 +352,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
             next_hop = brx_wave_min(tl);
             next_entry = brx_wave_min(tf > t ? tf : NEVER);
         }
-        cnext = reinterpret_cast<const uint8_t *>(brx_ring32)[(uint32_t)(t - s) & 511u];   /* column t + 1 - s */
+        cnext = reinterpret_cast<const uint8_t *>(ring32)[(uint32_t)(t - s) & 511u];   /* column t + 1 - s */
     }
     (void)prog;
 }
@@ -526,9 +535,11 @@ __device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32
  * one-column trip) is paid once per four columns.  Traceback row of column j of superblock s is
  * j + 4s = 4 tau + c + 1: the same for every lane of a trip, so the stores stay slot-contiguous.
  * ------------------------------------------------------------------------------------------- */
+template <bool MW = false>
 __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                             const BrxGeom g, uint2 *__restrict__ tb) {
     const int lane = threadIdx.x & 63;
+    uint32_t *const ring32 = brx_ring<MW>();
     constexpr int NEVER = 0x7FFFFFFF;
     constexpr int JNEVER = 0x3FFFFFFF;              /* `j - jf` must not overflow for the (negative) j of an idle lane */
     constexpr int K = 4;
@@ -559,7 +570,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
 #pragma unroll
     for (int c = 0; c < 3; ++c) {                   /* chunks 0..2; chunk c lives in ring quarter c & 3 */
         pending = fetch_chunk(c);
-        brx_ring32[(c & 3) * 64 + lane] = pending;
+        ring32[(c & 3) * 64 + lane] = pending;
         odd |= chunk_odd(c, pending) << c;
     }
     int s_top = 0;                                  /* first superblock still inside the band (uniform) */
@@ -568,7 +579,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
     const int tau_end = (g.NS - 1) + (g.T - 1) / K;
     const size_t trip_units = (size_t)K * (size_t)g.WSp;
     uint2 *dst = tb + (size_t)1 * (size_t)g.WSp + (size_t)slot;          /* row 4 tau + 1, this lane's slot */
-    uint32_t wnext = brx_ring32[((uint32_t)(K * (0 - s)) >> 2) & (BRX_RING_BYTES / 4 - 1)];
+    uint32_t wnext = ring32[((uint32_t)(K * (0 - s)) >> 2) & (BRX_RING_BYTES / 4 - 1)];
     for (int tau = 0; tau <= tau_end; ++tau, dst += trip_units) {
         /* ---- refill of the target window, keyed on the newest byte in use (scalar code) ---- */
         while (__builtin_expect(s_top < g.NS - 1 && tau > tl_top, 0)) { s_top += 1; tl_top = s_top + (brx_jlast(g, s_top) - 1) / K; }
@@ -581,7 +592,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
             if (ph == 3) pending = fetch_chunk((fq >> 6) + 3);
             else if (ph == 0) {
                 const int c = (fq >> 6) + 2;
-                brx_ring32[(c & 3) * 64 + lane] = pending;
+                ring32[(c & 3) * 64 + lane] = pending;
                 odd = (odd & ~(1u << (c & 3))) | (chunk_odd(c, pending) << (c & 3));
             }
         }
@@ -681,7 +692,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
             next_hop = brx_wave_min(tl);
             next_entry = brx_wave_min(tf > tau ? tf : NEVER);
         }
-        wnext = brx_ring32[((uint32_t)(K * (tau + 1 - s)) >> 2) & (BRX_RING_BYTES / 4 - 1)];   /* bytes of the next trip */
+        wnext = ring32[((uint32_t)(K * (tau + 1 - s)) >> 2) & (BRX_RING_BYTES / 4 - 1)];   /* bytes of the next trip */
     }
 }
 
@@ -689,7 +700,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
  * Register use grows with it (7 VGPRs per word), so kernels that only ever meet narrow bands are
  * instantiated with a small MAXG and run at a higher occupancy; geometries above MAXG take the
  * slow memory-resident path below (correct, rare). */
-template <int MAXG, int MING = 1>
+template <int MAXG, int MING = 1, bool MW = false>
 __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *Ts, const BrxGeom &g, uint2 *tb,
                                              uint32_t *prog = nullptr) {
     if (g.G > MAXG || g.G < MING) {
@@ -701,16 +712,16 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
         brx_align_forward_wide(Qs, Ts, g, tb, peq, st);
         return;
     }
-    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_k4(Qs, Ts, g, tb); return; } }
-    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 16 && MING <= 16) { if (g.G == 16) { brx_align_forward<16>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_k4<MW>(Qs, Ts, g, tb); return; } }
+    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2, MW>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4, MW>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8, MW>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 16 && MING <= 16) { if (g.G == 16) { brx_align_forward<16, MW>(Qs, Ts, g, tb, prog); return; } }
 }
 
 /* Full alignment with a given band bound k.  Returns false if the band was too narrow.
  * Handles empty inputs.  All lanes of the wave must call; results are wave-uniform. */
-template <int MAXG = 16, int MING = 1>
+template <int MAXG = 16, int MING = 1, bool MW = false>
 __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *Ts, int T, int k,
                                       uint2 *tb, uint64_t tb_cap_units, uint8_t *ops_end,
                                       int *n_cols, int *n_match, bool *no_space, uint32_t *prog = nullptr,
@@ -730,7 +741,7 @@ __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *T
     BRX_PROG(prog, 3, 1);
     BRX_PROG(prog, 6, (uint32_t)g.t_end);
     const uint64_t c0 = __builtin_amdgcn_s_memtime();
-    brx_align_forward_any<MAXG, MING>(Qs, Ts, g, tb, prog);
+    brx_align_forward_any<MAXG, MING, MW>(Qs, Ts, g, tb, prog);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);      /* stores of this wave visible to its own later loads */
     BRX_PROG(prog, 3, 2);

@@ -45,7 +45,7 @@ struct brx_ctx {
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
-    int mutate_wg;               /* BRX_MUTATE_WG (default 1): the mutate stage is one launch of k_mutate_wg (brx_mutate_wg.h); 0 = the pass pipeline */
+    int mutate_wg;               /* BRX_MUTATE_WG=1: the mutate stage is one launch of k_mutate_wg (brx_mutate_wg.h; measured slower at batch scale); default 0 = the pass pipeline */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
     int wide_stream;             /* BRX_WIDE_STREAM: the head set's widest band class aligns on a third stream */
     hipStream_t side2;
@@ -138,7 +138,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     c->waves_per_cu = w ? atoi(w) : 16;
     if (c->waves_per_cu < 1) c->waves_per_cu = 1;
     const char *wb = getenv("BRX_WIN_KB");
-    c->win_bytes = (uint64_t)(wb ? atoi(wb) : 256) << 10;
+    c->win_bytes = (uint64_t)(wb ? atoi(wb) : 512) << 10;      /* 512 KB: a 1000 x 1900 window with the whole matrix in the band (reads inside N runs: every draw changes a base) */
     if ((e = hipHostMalloc((void **)&c->h_totals, 16 * sizeof(uint64_t) + 64 * sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess)
         return create_fail(c, "hipHostMalloc", e);
     c->h_prog = (uint32_t *)(c->h_totals + 16);
@@ -156,7 +156,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         if ((e = hipEventCreateWithFlags(&c->ev_fork2[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
-    { const char *mw = getenv("BRX_MUTATE_WG"); c->mutate_wg = mw ? atoi(mw) : 1; }
+    { const char *mw = getenv("BRX_MUTATE_WG"); c->mutate_wg = mw ? atoi(mw) : 0; }
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
@@ -340,7 +340,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     uint32_t *repl = (uint32_t *)A.take(((size_t)f_bytes + 64) * 4);
     const uint32_t side_waves = std::min<uint32_t>(n_reads, 4096u);                 /* wave-level window aligner / legacy */
     const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, 512u);      /* lane-level window aligner          */
-    uint8_t *win = (uint8_t *)A.take((size_t)side_waves * c->win_bytes);
+    uint8_t *win = (uint8_t *)A.take((size_t)(side_waves + BRX_SEG_WAVES) * c->win_bytes);      /* one slot per wave; workgroups of BRX_SEG_WAVES */
     MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
     uint32_t *mctr = (uint32_t *)A.take(8 * MC_WORDS * sizeof(uint32_t));   /* pass counters 0/1, 2 first bulk input, 3 bulk legacy, 4 head input, 5 head legacy, 6 head pass */
     uint32_t *active_a = (uint32_t *)A.take((size_t)n_reads * 4);
@@ -387,7 +387,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     const uint32_t n_bulk = n_reads - n_head;
     uint8_t *win_head = nullptr;
     if (n_head && n_bulk && !use_wg) {
-        win_head = (uint8_t *)A.take((size_t)std::min(n_head, side_waves) * c->win_bytes);
+        win_head = (uint8_t *)A.take((size_t)(std::min(n_head, side_waves) + BRX_SEG_WAVES) * c->win_bytes);
         if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
     } else win_head = win;
     hipStream_t s_head = n_bulk ? c->side : st;            /* an all-head batch stays on the caller's stream */
@@ -534,8 +534,12 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         HIPCHK(c, hipMemcpyAsync(h_ctr + 2, counters + 1, 4, hipMemcpyDeviceToHost, S.st));
         { int rcw = wait_stream(c, S.st, S.id ? "mutate stage (bulk)" : "mutate stage (head)"); if (rcw) return rcw; }
         if (h_ctr[2] & 1u) {                              /* an in-loop alignment did not fit its window scratch */
+            uint32_t w4[4] = {0, 0, 0, 0};
+            (void)hipMemcpy(w4, counters + 9, sizeof(w4), hipMemcpyDeviceToHost);
             c->win_bytes *= 4;
-            return scratch_short(c, c->scratch_bytes + (size_t)side_waves * c->win_bytes);
+            c->scratch_needed = c->scratch_bytes + (size_t)side_waves * c->win_bytes;
+            return fail(c, BRX_E_SCRATCH, "window scratch too small (read %llu: window of %u x %u bases, edit bound %u): need about %zu bytes, have %zu",
+                        (unsigned long long)(first_read + w4[0]), w4[1], w4[2], w4[3], c->scratch_needed, c->scratch_bytes);
         }
         /* reads whose window did not fit a slot: the whole-read kernel with the inline wave aligner */
         DBG("set %d: %u reads, %u to the whole-read kernel", S.id, ns, h_ctr[0]);
@@ -605,11 +609,11 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
                           uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr) {
         KTIMED(BRX_KERN_MUTATE_RUN, s);
         if (c->profile)
-            hipLaunchKernelGGL((k_mutate_seg<true, true>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
+            hipLaunchKernelGGL((k_mutate_seg<true, true>), dim3((std::min(count, side_waves) + BRX_SEG_WAVES - 1) / BRX_SEG_WAVES), dim3(64 * BRX_SEG_WAVES), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
                                req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                winscr, (uint64_t)c->win_bytes, counters + 1, phase);
         else
-            hipLaunchKernelGGL((k_mutate_seg<true, false>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
+            hipLaunchKernelGGL((k_mutate_seg<true, false>), dim3((std::min(count, side_waves) + BRX_SEG_WAVES - 1) / BRX_SEG_WAVES), dim3(64 * BRX_SEG_WAVES), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
                                req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                winscr, (uint64_t)c->win_bytes, counters + 1, phase);
     };
@@ -690,11 +694,11 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             {
                 KTIMED(BRX_KERN_MUTATE_SEG, st);
                 if (c->profile)
-                    hipLaunchKernelGGL((k_mutate_seg<false, true>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                    hipLaunchKernelGGL((k_mutate_seg<false, true>), dim3((std::min(seg_waves, n_up) + BRX_SEG_WAVES - 1) / BRX_SEG_WAVES), dim3(64 * BRX_SEG_WAVES), 0, st, dev, rs, msv, act_in, n_in, act_out,
                                        ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                        win, (uint64_t)c->win_bytes, counters + 1, phase);
                 else
-                    hipLaunchKernelGGL((k_mutate_seg<false, false>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                    hipLaunchKernelGGL((k_mutate_seg<false, false>), dim3((std::min(seg_waves, n_up) + BRX_SEG_WAVES - 1) / BRX_SEG_WAVES), dim3(64 * BRX_SEG_WAVES), 0, st, dev, rs, msv, act_in, n_in, act_out,
                                        ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                        win, (uint64_t)c->win_bytes, counters + 1, phase);
             }

@@ -94,16 +94,26 @@ __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F
              ph_last = now_; ph0 += ph_cur == 0 ? dt_ : 0; ph1 += ph_cur == 1 ? dt_ : 0; ph2 += ph_cur == 2 ? dt_ : 0;   \
              ph3 += ph_cur == 3 ? dt_ : 0; ph4 += ph_cur == 4 ? dt_ : 0; ph_cur = (next); } } while (0)
 
+/* Workgroups of BRX_SEG_WAVES independent waves (one read each, no barrier after the prologue) share an LDS copy of the
+ * high halves of the error model's self thresholds (32 KB for k = 7: SURVEY.md section 0.6 / Appendix C): the ~93 % of
+ * k-mer draws that leave the k-mer unchanged (simulate.py:300) are rejected by one 16-bit LDS compare (dev_choose_alt). */
+#define BRX_SEG_WAVES 8
+#define BRX_SEG_THR_ROWS 16384
 template <bool INLINE, bool PROFILE = false>
-__global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
+__global__ void __launch_bounds__(64 * BRX_SEG_WAVES, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
                                                     const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,
                                                     uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
                                                     const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk,
                                                     uint32_t lane_threshold, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags,
                                                     uint64_t *phase) {
+    __shared__ uint16_t s_thr16[BRX_SEG_THR_ROWS];
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
+    const bool use_thr = em.type == 1 && em.n_rows <= BRX_SEG_THR_ROWS;
+    if (use_thr) for (uint32_t x = threadIdx.x; x < em.n_rows; x += blockDim.x) s_thr16[x] = (uint16_t)(em.d_self_thr[x] >> 16);
+    __syncthreads();
+    const uint32_t wave_index = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      /* scratch slot of this wave */
     const uint32_t n_in = uni(*n_in_ptr);
     uint64_t ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph_last = 0, pclk[2] = {0, 0};
     int ph_cur = 4;
@@ -171,7 +181,7 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
                 uint8_t kmer[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) kmer[j] = j < k ? F[ipos + j] : 0;
-                live = dev_choose_alt(em, kmer, w[2], w[3], rep);
+                live = dev_choose_alt(em, kmer, w[2], w[3], rep, use_thr ? s_thr16 : (const uint16_t *)nullptr);
             }
             unsigned long long surv = __ballot(live);
             BRX_PHASE(1);
@@ -269,15 +279,15 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
         if (INLINE && parked && ms.phase == 1u) {
             /* align the parked window here, at the top level where only MS is live, and resume the same read */
             const uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
-            uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)blockIdx.x * scr_bytes);
+            uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)wave_index * scr_bytes);
             int ncols = 0, nmatch = 0; bool nospace = false;
             BRX_PHASE(3);
-            const bool ok = brx_wave_align<1>(qb, (int)(ms.win_b - ms.win_a), tbuf, (int)ms.tl, (int)ms.cost, tb, scr_bytes / 8, nullptr,
+            const bool ok = brx_wave_align<1, 1, true>(qb, (int)(ms.win_b - ms.win_a), tbuf, (int)ms.tl, (int)ms.cost, tb, scr_bytes / 8, nullptr,
                                               &ncols, &nmatch, &nospace, nullptr, PROFILE ? pclk : nullptr);
             BRX_PHASE(4);
             ms.res_ncols = (uint32_t)ncols; ms.res_nmatch = (uint32_t)nmatch;
             if (!ok && !nospace) ms.status |= BRX_RS_BAND;
-            if (nospace && lane == 0) atomicOr(&flags[0], 1u);
+            if (nospace && lane == 0) { atomicOr(&flags[0], 1u); flags[8] = r; flags[9] = ms.win_b - ms.win_a; flags[10] = ms.tl; flags[11] = ms.cost; }
             continue;
         }
         break;
@@ -332,7 +342,7 @@ __global__ void __launch_bounds__(64, 5) k_win_wave(MS *msv, const uint32_t *req
         if (lane == 0) {
             msv[r].res_ncols = (uint32_t)ncols; msv[r].res_nmatch = (uint32_t)nmatch;
             if (!ok && !nospace) msv[r].status = ms.status | BRX_RS_BAND;
-            if (nospace) atomicOr(&flags[0], 1u);
+            if (nospace) { atomicOr(&flags[0], 1u); flags[8] = r; flags[9] = ms.win_b - ms.win_a; flags[10] = ms.tl; flags[11] = ms.cost; }
         }
     }
 }

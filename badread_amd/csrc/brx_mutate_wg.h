@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(64 * BRX_WG_WAVES, 4) k_mutate_wg(BrxDev d, RS
                                                   &ncols, &nmatch, &nospace);
                 if (lane == 0) {
                     s_win[w].ncols = (uint32_t)ncols; s_win[w].nmatch = (uint32_t)nmatch; s_win[w].ok = (ok || nospace) ? 1u : 0u;
-                    if (nospace) atomicOr(&flags[0], 1u);
+                    if (nospace) { atomicOr(&flags[0], 1u); flags[8] = rr; flags[9] = ql_; flags[10] = tl_; flags[11] = cost_; }
                 }
             }
         }

@@ -378,10 +378,13 @@ class HipEngine(EngineBase):
         carry RS_NOFRAG in their stats, so the caller can apply the reference's fatal-exit rule
         (simulate.py:159-165) only to reads that precede the stop point."""
         self._ensure_out(out_guess, n_reads)
-        for _ in range(8):
+        for attempt in range(8):
+            self.retries = getattr(self, 'retries', 0) + (1 if attempt else 0)
             out_bytes = ctypes.c_size_t(0)
             rc = call(ctypes.c_void_p(self._out.data_ptr()), self._out.numel(),
                       ctypes.c_void_p(self._stats.data_ptr()), ctypes.byref(out_bytes))
+            if rc in (E_SCRATCH, E_OUTPUT):
+                self.retry_log = getattr(self, 'retry_log', []) + [self.lib.brx_last_error(self.ctx).decode('latin-1', 'replace')]
             if rc == E_SCRATCH:
                 self._ensure_scratch(int(self.lib.brx_scratch_needed(self.ctx) * 1.25) + (1 << 20))
                 continue

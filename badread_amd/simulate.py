@@ -26,7 +26,7 @@ import sys
 import numpy as np
 
 from . import settings
-from .engine import RS_NOFRAG, SimParams
+from .engine import RS_BAND, RS_NOFRAG, RS_QMISS, RS_TOO_MANY_SEGS, SimParams
 from .error_model import ErrorModel
 from .fragment_lengths import FragmentLengths
 from .identities import Identities
@@ -39,7 +39,7 @@ NOFRAG_MESSAGE = ('Error: failed to generate any sequence fragments - are your r
                   'incompatible with your reference contig lengths?')
 ADJUST_SAMPLES = 100000
 DEFAULT_MAX_BATCH = 16384
-DEFAULT_IN_FLIGHT = 4          # super-batches in flight per GPU (--gpu-streams)
+DEFAULT_IN_FLIGHT = 8          # super-batches in flight per GPU (--gpu-streams): what bench.py measures
 
 
 # ---------------------------------------------------------------------------------------------
@@ -226,24 +226,44 @@ class Shard(object):
         hi = min(lo + per, count)
         return first + lo, hi - lo
 
-    def gather_arrays(self, arr):
-        """Every rank's 1-D numpy array (any fixed-size dtype), in rank order, on every rank; sizes may differ."""
-        if self.world == 1:
-            return [arr]
+    def _device(self):
         import torch
-        dist = self.dist
-        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
-        raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)            # collectives move bytes
-        size = torch.tensor([raw.size], dtype=torch.int64, device=dev)
-        sizes = [torch.zeros_like(size) for _ in range(self.world)]
-        dist.all_gather(sizes, size)
-        sizes = [int(s.item()) for s in sizes]
-        mine = torch.zeros(max(max(sizes), 1), dtype=torch.uint8, device=dev)
-        if raw.size:
-            mine[:raw.size] = torch.from_numpy(raw.copy()).to(dev)
+        return torch.device('cuda', torch.cuda.current_device()) if self.dist.get_backend() == 'nccl' else torch.device('cpu')
+
+    def gather_words(self, words, counts):
+        """Every rank's uint32 array (rank i contributes counts[i] words, known to all ranks from the batch plan), in
+        rank order, on every rank: the ONLY collective of the driver -- 4 bytes per read (its length and two status
+        bits) plus one word per rank, which is what every rank needs to apply the stop rule identically."""
+        if self.world == 1:
+            return [words]
+        import torch
+        dev = self._device()
+        width = max(max(counts), 1)
+        mine = torch.zeros(width, dtype=torch.int32, device=dev)
+        if len(words):
+            mine[:len(words)] = torch.from_numpy(np.ascontiguousarray(words).view(np.int32)).to(dev)
         parts = [torch.zeros_like(mine) for _ in range(self.world)]
-        dist.all_gather(parts, mine)
-        return [p[:n].cpu().numpy().view(arr.dtype) for p, n in zip(parts, sizes)]
+        self.dist.all_gather(parts, mine)
+        return [p[:n].cpu().numpy().view(np.uint32) for p, n in zip(parts, counts)]
+
+    def collect_bytes(self, mine, sizes, staging):
+        """Record bytes to rank 0, point to point: rank r > 0 sends its `sizes[r]` bytes (a device tensor over RCCL /
+        xGMI in production, a CPU tensor over gloo in the tests) and rank 0 receives them in rank order into `staging`.
+        No rank other than 0 ever holds another rank's records.  Yields (rank, uint8 tensor) on rank 0."""
+        if self.world == 1 or self.rank == 0:
+            if sizes[0]:
+                yield 0, mine[:sizes[0]]
+            for r in range(1, self.world):
+                if sizes[r]:
+                    buf = staging(sizes[r])
+                    self.dist.recv(buf, src=r)
+                    yield r, buf
+        elif sizes[self.rank]:
+            self.dist.send(mine[:sizes[self.rank]].contiguous(), dst=0)
+
+
+FLAG_NOFRAG, FLAG_BAD = 1 << 31, 1 << 30          # status bits packed beside the read length in the 4 B/read gather
+BAD_STATUS = RS_TOO_MANY_SEGS | RS_BAND | RS_QMISS
 
 
 def cut_point(seq_lens, running_total, target_size):
@@ -265,20 +285,78 @@ def plan_batch(remaining_bases, mean_length, world, max_batch):
     return per_rank * world
 
 
+class _HostRing(object):
+    """Pinned host buffers for the FASTQ bytes on their way out: the device-to-host copy of
+    a finished batch lands in page-locked memory (full PCIe rate, no staging copy by the runtime) and a writer thread
+    hands it to the sink while the GPU works on the next batches.  A buffer returns to the ring when the writer is done
+    with it; `depth` buffers bound the memory and apply back-pressure when the sink is slower than the GPU."""
+
+    def __init__(self, torch, pinned, depth=3):
+        import queue
+        import threading
+        self.torch, self.pinned = torch, pinned
+        self.free = queue.Queue()
+        for _ in range(depth):
+            self.free.put(None)                     # allocated (and grown) on first use
+        self.todo = queue.Queue()
+        self.error = None
+        self.sink = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while True:
+            item = self.todo.get()
+            if item is None:
+                return
+            buf, n = item
+            try:
+                if self.error is None and n:
+                    self.sink(memoryview(buf.numpy())[:n])
+            except BaseException as ex:             # surfaced by flush()
+                self.error = ex
+            self.free.put(buf)
+
+    def stage(self, nbytes):
+        """A host buffer of at least nbytes (blocks while all buffers are with the writer)."""
+        buf = self.free.get()
+        if buf is None or buf.numel() < nbytes:
+            cap = max(int(nbytes * 1.25), 1 << 20)
+            buf = self.torch.empty(cap, dtype=self.torch.uint8, pin_memory=self.pinned)
+        return buf
+
+    def write(self, tensor):
+        """Copy a uint8 tensor (device or host) into a ring buffer and queue it for the sink."""
+        n = int(tensor.numel())
+        buf = self.stage(n)
+        if n:
+            buf[:n].copy_(tensor, non_blocking=False)
+        self.todo.put((buf, n))
+
+    def flush(self):
+        self.todo.put(None)
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+
+
 class _BatchPool(object):
     """`in_flight` engines (the given one + clones sharing its device tables), each driven by its own host thread on
-    its own HIP stream, so that several batches overlap on the GPU: a batch is a chain of short dependent kernels
-    (hundreds of mutate passes, the long reads' alignments) that cannot fill 256 CUs alone."""
+    its own HIP stream, so that several batches overlap on the GPU.  A job returns the batch's FASTQ bytes WHERE THEY
+    ARE (a device tensor on the GPU engines) and its per-read statistics; the consumer copies out only the bytes it
+    keeps and then releases the engine."""
 
     def __init__(self, engine, in_flight):
         import concurrent.futures
         self.engines = [engine]
         self.streams = [None]
+        torch = getattr(engine, 'torch', None)           # absent on the tests' CPU checker engines
+        self.on_gpu = torch is not None and getattr(engine, 'device', None) is not None and engine.device.type == 'cuda'
         if in_flight > 1 and hasattr(engine, 'clone'):
-            torch = getattr(engine, 'torch', None)           # absent on the tests' CPU checker engines
-            on_gpu = torch is not None and getattr(engine, 'device', None) is not None and engine.device.type == 'cuda'
-            self.streams = [torch.cuda.Stream(device=engine.device) if on_gpu else None for _ in range(in_flight)]
+            self.streams = [torch.cuda.Stream(device=engine.device) if self.on_gpu else None for _ in range(in_flight)]
             self.engines += [engine.clone() for _ in range(in_flight - 1)]
+        elif self.on_gpu:
+            self.streams = [torch.cuda.Stream(device=engine.device)]
         self.free = list(range(len(self.engines)))
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=len(self.engines)) if len(self.engines) > 1 else None
 
@@ -290,15 +368,17 @@ class _BatchPool(object):
         eng, stream = self.engines[i], self.streams[i]
 
         def job():
+            import torch
             if n_mine == 0:
-                return np.zeros(0, np.uint8), np.zeros(0, dtype=eng.stats_dtype)
-            if stream is None:
-                return eng.simulate_batch(seed, first, n_mine, allow_nofrag=True)
-            torch = eng.torch
+                return torch.zeros(0, dtype=torch.uint8), np.zeros(0, dtype=eng.stats_dtype)
+            if not self.on_gpu:
+                out, stats = eng.simulate_batch(seed, first, n_mine, allow_nofrag=True)
+                return torch.from_numpy(np.ascontiguousarray(out).copy()), stats.copy()
             torch.cuda.set_device(eng.device)
             with torch.cuda.stream(stream):
-                out, stats = eng.simulate_batch(seed, first, n_mine, allow_nofrag=True)
-                return out.copy(), stats.copy()          # the engine's buffers are reused by its next batch
+                out, stats = eng.simulate_batch_device(seed, first, n_mine, allow_nofrag=True)
+                stream.synchronize()
+                return out, stats.copy()                 # `out` is the engine's buffer: valid until release(i)
         if self.pool is None:
             class _Done(object):
                 def __init__(self, v): self.v = v
@@ -325,8 +405,13 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     consecutive index ranges and are CONSUMED in index order, where the stop rule is applied, so the output does
     not depend on `in_flight` or on the batch sizes; batches issued beyond the stopping read are discarded.  The
     issue schedule depends only on consumed totals, so every rank of a multi-GPU run plans the same batches.
+
+    Between ranks: one all_gather of 4 bytes per read (length + two status bits) and one word per rank (bytes kept)
+    per super-batch, then the kept record bytes travel point to point to rank 0 only.  On every rank the bytes leave the
+    GPU through a ring of pinned host buffers drained by a writer thread (_HostRing).
     """
     import collections
+    import torch
     shard = shard or Shard()
     max_batch = max_batch or DEFAULT_MAX_BATCH
     count = total = 0
@@ -335,8 +420,21 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     if shard.rank == 0:
         print_progress(count, total, target_size, output)
     pool = _BatchPool(engine, max(1, int(in_flight)))
+    ring = None
+    if shard.rank == 0:
+        ring = _HostRing(torch, pinned=pool.on_gpu)
+        ring.sink = write
+    dev_staging = {}
+
+    def staging(nbytes):                     # where rank 0 receives another rank's records (device memory under RCCL)
+        dev = shard._device()
+        buf = dev_staging.get('buf')
+        if buf is None or buf.numel() < nbytes:
+            buf = dev_staging['buf'] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
+        return buf[:nbytes]
+
     pending = collections.deque()          # (slot, future, first_of_super_batch, n_super, first, n_mine)
-    fatal = False
+    fatal = bad_read = None
     try:
         while total < target_size:
             # keep the pipeline full: what is outstanding is assumed to deliver its expected number of bases
@@ -352,28 +450,41 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
                 next_read += n_super
             slot, fut, base, n_super, first, n_mine = pending.popleft()
             out, stats = fut.result()
-            pool.release(slot)
-            lens = np.concatenate(shard.gather_arrays(stats['seq_len'].astype(np.uint32) * (stats['rec_len'] > 0)))
-            failed = np.concatenate(shard.gather_arrays((stats['status'] & RS_NOFRAG).astype(np.uint8)))
+            # ---- the 4 B/read exchange: length (0 for skipped reads) | NOFRAG << 31 | BAD << 30 ----
+            words = (stats['seq_len'].astype(np.uint32) * (stats['rec_len'] > 0)).astype(np.uint32)
+            assert not len(words) or int(words.max()) < FLAG_BAD
+            words |= np.where(stats['status'] & RS_NOFRAG, FLAG_NOFRAG, 0).astype(np.uint32)
+            words |= np.where(stats['status'] & BAD_STATUS, FLAG_BAD, 0).astype(np.uint32)
+            per_rank = [Shard(r, shard.world).slice_of(base, n_super)[1] for r in range(shard.world)]
+            allw = np.concatenate(shard.gather_words(words, per_rank)) if shard.world > 1 else words
+            lens = (allw & (FLAG_BAD - 1)).astype(np.int64)
             cut = cut_point(lens, total, target_size)
-            bad = np.flatnonzero(failed)
-            fatal = bool(len(bad) and (cut is None or bad[0] < cut))
-            last = int(bad[0]) - 1 if fatal else (cut if cut is not None else n_super - 1)
+            wrong = np.flatnonzero(allw & (FLAG_NOFRAG | FLAG_BAD))
+            stop_at = None
+            if len(wrong) and (cut is None or wrong[0] < cut):
+                stop_at = int(wrong[0])
+                if allw[stop_at] & FLAG_NOFRAG:
+                    fatal = True
+                else:
+                    bad_read = base + stop_at
+            last = stop_at - 1 if stop_at is not None else (cut if cut is not None else n_super - 1)
             # bytes of my reads with global batch position <= last
             my_lo = first - base
             keep = int(np.clip(last - my_lo + 1, 0, n_mine))
-            my_bytes = out[:int(stats['rec_off'][keep - 1] + stats['rec_len'][keep - 1])] if keep else out[:0]
-            parts = shard.gather_arrays(np.ascontiguousarray(my_bytes))
-            if shard.rank == 0:
-                for part in parts:
-                    if len(part):
-                        write(part)
+            my_bytes = int(stats['rec_off'][keep - 1] + stats['rec_len'][keep - 1]) if keep else 0
+            sizes = [my_bytes]
+            if shard.world > 1:
+                sizes = [int(x[0]) for x in shard.gather_words(np.array([my_bytes], dtype=np.uint32), [1] * shard.world)]
+                assert my_bytes < 2 ** 32
+            for _, part in shard.collect_bytes(out, sizes, staging):
+                ring.write(part)                    # rank 0: through pinned memory to the writer thread
+            pool.release(slot)                      # the engine's output buffer may be overwritten from here on
             used = lens[:last + 1]
             count += int((used > 0).sum())
             total += int(used.sum())
             if shard.rank == 0:
                 print_progress(count, total, target_size, output)
-            if fatal:
+            if fatal or bad_read is not None:
                 break
             if count:
                 expected_mean = max(total / count, 1.0)
@@ -384,12 +495,15 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             except Exception:
                 pass
         pool.close()
-    if fatal:
-        if shard.rank == 0:
-            print('\n', file=output)
-        sys.exit(NOFRAG_MESSAGE)
+        if ring is not None:
+            ring.flush()
     if shard.rank == 0:
         print('\n', file=output)
+    if fatal:
+        sys.exit(NOFRAG_MESSAGE)
+    if bad_read is not None:
+        sys.exit(f'Error: read {bad_read} exceeded an internal limit of the GPU path (status bits in its statistics); '
+                 'no output was written for it or any later read')
     return count, total
 
 

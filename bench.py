@@ -344,7 +344,7 @@ def main():
         """The device batches of steps `step_indices`, C in flight: worker i owns context i / stream i and takes
         every C-th device batch; batch b of step k covers read indices ((k*C + b)*world + rank)*R ..."""
         indices = [k * C + b for k in step_indices for b in range(C)]
-        acc = [{'bases': 0, 'passes': 0, 'stages': {}, 'kernels': {}, 'final_launches': 0, 'misses': 0, 'bad': 0, 'error': None} for _ in range(C)]
+        acc = [{'bases': 0, 'passes': 0, 'stages': {}, 'kernels': {}, 'final_launches': 0, 'misses': 0, 'bad': 0, 'host_ms': 0.0, 'error': None} for _ in range(C)]
 
         def worker(i):
             try:
@@ -353,7 +353,9 @@ def main():
                 ctx = torch.cuda.stream(streams[i]) if not dry else _Null()
                 with ctx:
                     for idx in indices[i::C]:
+                        t_call = time.perf_counter()
                         stats = run_one(engines[i], idx)
+                        acc[i]['host_ms'] += 1000.0 * (time.perf_counter() - t_call)
                         acc[i]['bases'] += int(stats['seq_len'].sum())
                         acc[i]['bad'] += int((stats['status'] & 0xE).astype(bool).sum())     # RS_TOO_MANY_SEGS | RS_BAND | RS_QMISS
                         if dry:
@@ -479,6 +481,9 @@ def main():
         result['roofline_alu'] = {'bound': 'valu-issue', 'achieved': rate, 'peak': VALU_PEAK_PER_S, 'unit': 'wave-instructions/s',
                                   'frac': rate / VALU_PEAK_PER_S, 'valu_per_base': vpb['valu_per_base'], 'source': vpb.get('source')}
     result['stage_ms_per_device_batch'] = stages
+    result['host_ms_per_device_batch'] = sum(a['host_ms'] for a in acc) / n_batches        # wall time of one brx_simulate_batch call
+    result['scratch_or_output_retries'] = sum(getattr(e, 'retries', 0) for e in engines)
+    result['retry_log'] = [m for e in engines for m in getattr(e, 'retry_log', [])][:8]
     result['mutate_passes_per_device_batch'] = sum(a['passes'] for a in acc) / n_batches
     result['traceback_window_misses_per_step'] = sum(a['misses'] for a in acc) / args.steps
     if d2h is not None:

@@ -72,16 +72,16 @@ def test_aligner_band_classes_iupac_and_hints():
 
 
 ROUTES = [
-    {},                                                        # defaults: workgroup mutate kernel (packed window alignments), windowed store
+    {},                                                        # defaults: pass pipeline (all head here: few reads), windowed store
     {'BRX_TB_WINDOW': -1},                                     # 8-row traceback window: most reads repeat (phase 1)
     {'BRX_TB_WINDOW': 0, 'BRX_WIDE_STREAM': 0},                # full store, no third stream for the widest class
-    {'BRX_HEAD_READS': 9},                                     # final stage split into a head and a bulk set
-    # the pass pipeline of round 1 (BRX_MUTATE_WG=0)
-    {'BRX_MUTATE_WG': 0},                                                        # in-place tail (few reads)
-    {'BRX_MUTATE_WG': 0, 'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0},         # bulk passes only: every window through the lane kernel
-    {'BRX_MUTATE_WG': 0, 'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 1000000},   # bulk passes only: every window through the wave kernel
-    {'BRX_MUTATE_WG': 0, 'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},         # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
-    {'BRX_MUTATE_WG': 0, 'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
+    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0},         # bulk passes only: every window through the lane kernel
+    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 1000000},   # bulk passes only: every window through the wave kernel
+    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},         # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
+    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
+    # the one-launch mutate stage (BRX_MUTATE_WG=1: workgroups of 8 reads, packed window alignments)
+    {'BRX_MUTATE_WG': 1},
+    {'BRX_MUTATE_WG': 1, 'BRX_HEAD_READS': 9, 'BRX_TB_WINDOW': -1},              # final stage split into a head and a bulk set, retry phase
 ]
 
 
@@ -101,12 +101,15 @@ def test_pipeline_routes_equal_the_oracle(env, monkeypatch):
         assert eng.window_misses() >= 3                     # the retry phase ran (short reads: few windows are narrower than the band)
     if env.get('BRX_TAIL_READS') == 0:
         assert eng.mutate_passes() > 3
-    if 'BRX_MUTATE_WG' not in env:
+    if env.get('BRX_MUTATE_WG') == 1:
         assert eng.mutate_passes() == 1
 
 
-def test_pipeline_other_models_and_fragment_kinds():
-    """random / ideal models (k = 1), low identity, chimeras, junk and random reads, glitches, N runs and hairpins."""
+@pytest.mark.parametrize('wg', [0, 1])
+def test_pipeline_other_models_and_fragment_kinds(wg, monkeypatch):
+    """random / ideal models (k = 1), low identity, chimeras, junk and random reads, glitches, N runs and hairpins;
+    through the pass pipeline and through the one-launch mutate kernel."""
+    monkeypatch.setenv('BRX_MUTATE_WG', str(wg))
     pref, _ = H.small_reference(with_n=True)
     p = SimParams(frag_mean=700, frag_stdev=0, identity_mode=0, id_max=0.88, glitch_rate=400, glitch_size=10, glitch_skip=10,
                   chimera_rate=0.2, junk_rate=0.1, random_rate=0.1)
@@ -161,7 +164,13 @@ def test_driver_on_the_emulated_device_equals_the_oracle_driver(monkeypatch):
     assert a.getvalue() == b.getvalue() and a.getvalue().count(b'\n') >= 4 * 20
 
 
-def test_window_overflow_goes_through_the_whole_read_kernel(tmp_path):
+@pytest.mark.parametrize('wg', [0, 1])
+def test_window_overflow_goes_through_the_whole_read_kernel(tmp_path, wg, monkeypatch):
+    monkeypatch.setenv('BRX_MUTATE_WG', str(wg))
+    _window_overflow(tmp_path)
+
+
+def _window_overflow(tmp_path):
     """A synthetic error model whose alternatives insert 60 bases: the joined 1000-base windows outgrow their pass slots
     (BRX_WIN_TMAX), so those reads are handed to the whole-read kernel k_mutate with inline alignments -- a route no
     packaged model reaches.  Mutated reads of 17x the fragment length also push the final alignment into the widest
@@ -198,7 +207,7 @@ def test_final_stage_in_several_scratch_chunks(monkeypatch):
     chunks over the same arena; same bytes."""
     pref, _ = H.small_reference()
     p = SimParams(frag_mean=5000, frag_stdev=2000)
-    eng = H.configure(emu_engine(monkeypatch, scratch=24 << 20, BRX_TB_WINDOW=0), pref, 'nanopore2023', 'nanopore2023', p)
+    eng = H.configure(emu_engine(monkeypatch, scratch=24 << 20, BRX_TB_WINDOW=0, BRX_WIN_KB=128), pref, 'nanopore2023', 'nanopore2023', p)
     orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
     out_h, st_h = eng.simulate_batch(8, 0, 28)
     out_o, st_o = orc.simulate_batch(8, 0, 28)
