@@ -66,7 +66,12 @@ __host__ __device__ inline uint32_t brx_isqrt(uint32_t v) {
     return r;
 }
 
-/* k must be >= |Q-T|.  Returns G = 0 if the band is wider than 64 lanes x 32 words can hold.
+/* Words per lane: 1..16 live in registers (brx_align_forward<G>); wider bands -- a read that is both very long and very
+ * inaccurate: more than 57 344 band rows -- keep the lane's words in the per-wave state array of brx_align_forward_wide,
+ * which takes any power of two.  4096 words per lane = a band of 7.3 M rows: beyond any fragment the planner can draw
+ * from a 2^32-base contig at an identity the CLI accepts; past it brx_make_geom gives up (BRX_RS_BAND). */
+#define BRX_GEOM_MAXG 4096
+/* k must be >= |Q-T|.  Returns G = 0 if the band is wider than 64 lanes x BRX_GEOM_MAXG words can hold.
  *
  * hmul != 0 (windowed store): the forward pass still computes the whole Ukkonen band (the cell values, and therefore every
  * Pv/Ph bit, are unchanged), but only the superblocks that intersect rows [c(j) - H, c(j) + H] of column j,
@@ -86,8 +91,8 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul =
     g.dhi = (dend > 0 ? dend : 0) + half;
     int bw = g.dhi - g.dlo + 1;
     int G = 1;
-    while (G <= 32 && bw > 56 * 32 * G) G *= 2;
-    if (G > 32) { g.G = 0; g.R = 0; g.NS = 0; g.NW = 0; g.WSp = 0; g.K = 1; g.t_end = 0; return g; }
+    while (G <= BRX_GEOM_MAXG && (long long)bw > 56ll * 32ll * G) G *= 2;
+    if (G > BRX_GEOM_MAXG) { g.G = 0; g.R = 0; g.NS = 0; g.NW = 0; g.WSp = 0; g.K = 1; g.t_end = 0; return g; }
     g.G = G; g.R = 32 * G;
     g.NW = (Q + 31) / 32;
     g.NS = (Q + g.R - 1) / g.R;

@@ -314,7 +314,9 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     uint64_t *tboff_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *clk = (uint64_t *)A.take((size_t)n_reads * 64);     /* per-read cycle counters, brx_last_read_cycles() */
     uint64_t *phase = (uint64_t *)A.take((size_t)n_reads * 64);   /* mutate phase cycles (BRX_PROFILE=1), brx_last_phase_cycles() */
+    PSeg *plan_ovf = (PSeg *)A.take((size_t)BRX_OVF_LISTS * BRX_OVF_SEGS * sizeof(PSeg));
     if (!A.ok()) return scratch_short(c, A.used + (size_t)n_reads * 200000);
+    dev.plan_ovf = plan_ovf; dev.plan_ovf_ctr = counters + 5;
     HIPCHK(c, hipMemsetAsync(counters, 0, 4096 * 4, st));
     HIPCHK(c, hipMemsetAsync(totals, 0, 16 * 8, st));
     HIPCHK(c, hipMemsetAsync(clk, 0, (size_t)n_reads * 64, st));
@@ -331,8 +333,14 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         else hipLaunchKernelGGL(k_plan_count, dim3(nb64), dim3(64), 0, st, dev, rs);
         hipLaunchKernelGGL(k_scan_plan, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
     }
+    uint32_t h_ovf = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_ovf, counters + 5, 4, hipMemcpyDeviceToHost, st));
     int rc = read_totals(c, st, totals, 3);
     if (rc) return rc;
+    if (h_ovf > BRX_OVF_LISTS)       /* the sizing pass ran out of overflow lists: the fill pass could overflow OTHER reads */
+        return fail(c, BRX_E_INTERNAL, "%u reads of one batch have more than %d base segments (chimera joins): only %d overflow lists",
+                    h_ovf, BRX_MAX_BASE_SEGS, BRX_OVF_LISTS);
+    HIPCHK(c, hipMemsetAsync(counters + 5, 0, 4, st));          /* the fill pass takes the same lists again */
     const uint64_t tot_segs = c->h_totals[0], tot_pieces = c->h_totals[1], f_bytes = c->h_totals[2];
     PSeg *segs = (PSeg *)A.take((size_t)(tot_segs + 1) * sizeof(PSeg));
     PPiece *pieces = (PPiece *)A.take((size_t)(tot_pieces + 1) * sizeof(PPiece));
@@ -488,7 +496,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             }
             if (S.bases_by_class[3] || phase == 1) {
                 KTIMED(BRX_KERN_FIN_ALIGN16, S.wide);
-                hipLaunchKernelGGL((k_fin_align<16, 8, 64>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
+                hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
                                    dev, rs, order, b, e, cq + 0, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
             }
             if (fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }

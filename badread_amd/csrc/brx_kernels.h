@@ -27,7 +27,11 @@
 
 #define BRX_ALIGN_INTERVAL 25     /* settings.ALIGNMENT_INTERVAL */
 #define BRX_ALIGN_SIZE 1000       /* settings.ALIGNMENT_SIZE     */
-#define BRX_MAX_BASE_SEGS 64
+#ifndef BRX_MAX_BASE_SEGS
+#define BRX_MAX_BASE_SEGS 64      /* base segments a lane keeps in private memory; longer lists continue in a global overflow list */
+#endif
+#define BRX_OVF_SEGS 4096         /* segments per overflow list */
+#define BRX_OVF_LISTS 64          /* overflow lists per batch (two per overflowing read: the planner runs twice) */
 
 enum { SEG_REF = 0, SEG_ADAPTER = 1, SEG_RANDOM = 2, SEG_JUNK = 3 };
 enum { PC_JUNK = 0, PC_RANDOM = 1, PC_REAL = 2, PC_HAIRPIN = 3 };
@@ -54,6 +58,8 @@ struct BrxDev {
     uint64_t seed, first_read;
     uint32_t n_reads, raw_mode;      /* raw_mode: sequence_fragments (no plan, raw output) */
     int tb_hmul;                     /* window of the final traceback store: H = tb_hmul sqrt(ub) + 24 rows (brx_make_geom); 0 = full */
+    PSeg *plan_ovf;                  /* BRX_OVF_LISTS x BRX_OVF_SEGS: continuation of base-segment lists longer than BRX_MAX_BASE_SEGS */
+    uint32_t *plan_ovf_ctr;
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -123,14 +129,28 @@ struct WriteEmit {
     }
 };
 
+/* The pieces of a read before glitches (simulate.py:94-113): adapters, fragments (two segments when a circular contig
+ * wraps or a hairpin turns), chimera joins -- the reference's chimera loop is unbounded (simulate.py:101-110).  The first
+ * BRX_MAX_BASE_SEGS segments live in the lane's private memory; a longer list (a read with ~20+ chimera joins: one in
+ * 10^6 at --chimeras 50) continues in one of the batch's global overflow lists, taken with an atomic on first use. */
 struct BaseList {
     PSeg s[BRX_MAX_BASE_SEGS]; int n; uint64_t len; bool overflow;
+    PSeg *ext; PSeg *ovf_pool; uint32_t *ovf_ctr;
     __device__ void push(uint32_t type, uint32_t a, uint32_t b, uint32_t start, uint32_t l) {
         if (!l) return;
-        if (n >= BRX_MAX_BASE_SEGS) { overflow = true; return; }
-        s[n].w0 = type | (b << 2) | (a << 5); s[n].start = start; s[n].len = l; s[n].dst = 0;
+        PSeg v; v.w0 = type | (b << 2) | (a << 5); v.start = start; v.len = l; v.dst = 0;
+        if (n < BRX_MAX_BASE_SEGS) s[n] = v;
+        else {
+            if (!ext && !overflow && ovf_pool) {
+                const uint32_t slot = atomicAdd(ovf_ctr, 1u);
+                if (slot < BRX_OVF_LISTS) ext = ovf_pool + (size_t)slot * BRX_OVF_SEGS;
+            }
+            if (!ext || n - BRX_MAX_BASE_SEGS >= BRX_OVF_SEGS) { overflow = true; return; }
+            ext[n - BRX_MAX_BASE_SEGS] = v;
+        }
         ++n; len += l;
     }
+    __device__ PSeg at(int i) const { return i < BRX_MAX_BASE_SEGS ? s[i] : ext[i - BRX_MAX_BASE_SEGS]; }
 };
 
 /* fragment_lengths.py:47-52 */
@@ -216,7 +236,7 @@ template <class E>
 __device__ void plan_copy_range(const BaseList &base, uint64_t a, uint64_t b, E &em) {
     uint64_t pos = 0;
     for (int s = 0; s < base.n && pos < b; ++s) {
-        const PSeg &sg = base.s[s];
+        const PSeg sg = base.at(s);
         uint64_t lo = pos, hi = pos + sg.len;
         pos = hi;
         if (hi <= a) continue;
@@ -232,6 +252,7 @@ __device__ void plan_read(const BrxDev &d, uint64_t read, E &em, uint32_t *statu
     brx_rng_init(&g, d.seed, read, BRX_ST_PLAN);
     uint32_t next_serial = 2;
     BaseList base; base.n = 0; base.len = 0; base.overflow = false;
+    base.ext = nullptr; base.ovf_pool = d.plan_ovf; base.ovf_ctr = d.plan_ovf_ctr;
     *status = 0; *target = 0.0;
 
     if (p.start_adapter_len > 0 && p.start_rate != 0.0 && p.start_amount != 0.0) {      /* simulate.py:361-370 */
@@ -784,7 +805,7 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
             if (!d.raw_mode) for (uint32_t i = 0; i < s.n_pieces; ++i) junk |= (pieces[s.piece_off + i].w0 & 3u) == PC_JUNK;
             RS *o = &rs[r];
             o->seq_off = seq_base + s.seq_off; o->ops_off = ops_base + s.ops_off;
-            o->klass = (g.G ? (uint32_t)g.G : 64u) | (junk ? BRX_KL_FULL : 0u);
+            o->klass = (g.G ? (uint32_t)g.G : 0xFFFFu) | (junk ? BRX_KL_FULL : 0u);
             o->units = brx_final_units(s.m, s.n, s.ub, junk ? 0 : d.tb_hmul, &too_wide);     /* traceback store + col_of[] */
             if (too_wide) o->status = s.status | BRX_RS_BAND;
         }

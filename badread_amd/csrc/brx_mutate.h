@@ -94,11 +94,22 @@ __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F
              ph_last = now_; ph0 += ph_cur == 0 ? dt_ : 0; ph1 += ph_cur == 1 ? dt_ : 0; ph2 += ph_cur == 2 ? dt_ : 0;   \
              ph3 += ph_cur == 3 ? dt_ : 0; ph4 += ph_cur == 4 ? dt_ : 0; ph_cur = (next); } } while (0)
 
-/* Workgroups of BRX_SEG_WAVES independent waves (one read each, no barrier after the prologue) share an LDS copy of the
- * high halves of the error model's self thresholds (32 KB for k = 7: SURVEY.md section 0.6 / Appendix C): the ~93 % of
- * k-mer draws that leave the k-mer unchanged (simulate.py:300) are rejected by one 16-bit LDS compare (dev_choose_alt). */
-#define BRX_SEG_WAVES 8
-#define BRX_SEG_THR_ROWS 16384
+/* BRX_SEG_WAVES / BRX_SEG_THR_ROWS (build macros): workgroups of BRX_SEG_WAVES independent waves (one read each, no
+ * barrier after the prologue) can share an LDS copy of the high halves of the error model's self thresholds (32 KB for
+ * k = 7: SURVEY.md section 0.6 / Appendix C), so that the ~93 % of k-mer draws that leave the k-mer unchanged
+ * (simulate.py:300) are rejected by one 16-bit LDS compare (dev_choose_alt).  MEASURED (round 2, profiles/README.md r02e,
+ * 8 batches in flight, configs[1]): 8 waves + table 1.69 Gbases/s, 8 waves without the table 1.77, 4 waves + table 1.75,
+ * one wave per workgroup and the thresholds read through L2 2.02 -- the pass kernels are short (2 ms) and run beside
+ * dozens of other kernels, and a workgroup that needs 4-8 free wave slots on ONE compute unit is dispatched much later
+ * than single waves that fill any free slot (k_mutate_seg<false>: 110 -> 320 ms per batch).  The shipped build therefore
+ * keeps one wave per workgroup and no LDS table here; the LDS variant stays buildable (-DBRX_SEG_WAVES=8
+ * -DBRX_SEG_THR_ROWS=16384), is interpreted by the CPU tests, and is what k_mutate_wg (brx_mutate_wg.h) uses. */
+#ifndef BRX_SEG_WAVES
+#define BRX_SEG_WAVES 1
+#endif
+#ifndef BRX_SEG_THR_ROWS
+#define BRX_SEG_THR_ROWS 1
+#endif
 template <bool INLINE, bool PROFILE = false>
 __global__ void __launch_bounds__(64 * BRX_SEG_WAVES, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
                                                     const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,

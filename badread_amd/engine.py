@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.realpath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libbrx_hip.so')
+LIB_PATH = os.environ.get('BRX_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libbrx_hip.so')     # BRX_HIP_LIB: A/B builds of the same sources (tools)
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -81,7 +81,7 @@ E_SCRATCH, E_OUTPUT, E_NOFRAG = -3, -4, -5
 STAGE_NAMES = ('plan', 'build', 'mutate', 'scan', 'final', 'emit', 'align1', 'qscore')
 # kernel classes of brx_last_kernel_stats (include/brx.h: BRX_KERN_*), with the names a rocprofv3 kernel trace shows
 KERNEL_NAMES = ('k_plan_*', 'k_build', 'k_mutate_seg<false>', 'k_mutate_seg<true>', 'k_win_lane', 'k_win_wave', 'k_fin_join',
-                'k_fin_align<1,1,1>', 'k_fin_align<2,2,2>', 'k_fin_align<4,4,4>', 'k_fin_align<16,8,64>', 'k_fin_qscore',
+                'k_fin_align<1,1,1>', 'k_fin_align<2,2,2>', 'k_fin_align<4,4,4>', 'k_fin_align<16,8,65535>', 'k_fin_qscore',
                 'k_emit+k_recsize')
 
 

@@ -43,8 +43,8 @@ enum {
 /* per-read status bits written to brx_read_stats.status */
 enum {
     BRX_RS_NOFRAG = 1u,       /* get_fragment gave up after 1000 tries                        */
-    BRX_RS_TOO_MANY_SEGS = 2u,/* more chimera pieces than the planner's fixed limit           */
-    BRX_RS_BAND = 4u,         /* alignment score exceeded its proven upper bound (bug)        */
+    BRX_RS_TOO_MANY_SEGS = 2u,/* more than 4096 base segments in one read AND the batch's overflow lists used up (see brx_kernels.h) */
+    BRX_RS_BAND = 4u,         /* alignment failed: score above its proven bound (bug) or a band of more than 7.3 M rows */
     BRX_RS_QMISS = 8u,        /* qscore fallback reached a 1-op cigar absent from the model   */
     BRX_RS_EMPTY = 16u        /* read trimmed to zero length: skipped, like simulate.py:70-71  */
 };
@@ -266,7 +266,7 @@ enum { BRX_KERN_PLAN = 0,        /* k_plan_count + k_scan_plan + k_plan_fill    
        BRX_KERN_FIN_ALIGN1 = 7,  /* k_fin_align<1,1,1>                                                         */
        BRX_KERN_FIN_ALIGN2 = 8,  /* k_fin_align<2,2,2>                                                         */
        BRX_KERN_FIN_ALIGN4 = 9,  /* k_fin_align<4,4,4>                                                         */
-       BRX_KERN_FIN_ALIGN16 = 10,/* k_fin_align<16,8,64>                                                       */
+       BRX_KERN_FIN_ALIGN16 = 10,/* k_fin_align<16,8,65535>: 8 or more band words per lane                  */
        BRX_KERN_FIN_QSCORE = 11,
        BRX_KERN_EMIT = 12,       /* k_recsize + k_scan_rec + k_emit + k_stats                                  */
        BRX_KERN_COUNT = 13 };

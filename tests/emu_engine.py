@@ -20,29 +20,38 @@ REPO = os.path.dirname(HERE)
 _lib = None
 
 
-def build():
+_variants = {}
+
+
+def build(defines=()):
+    """The interpreted library; `defines` selects a build variant of the kernels (e.g. ('-DBRX_SEG_WAVES=8',
+    '-DBRX_SEG_THR_ROWS=16384'): pass kernels as 8-wave workgroups with the self thresholds in LDS)."""
     global _lib
-    if _lib is not None:
-        return _lib
+    key = tuple(defines)
+    if key in _variants:
+        return _variants[key]
     out_dir = tempfile.mkdtemp(prefix='brx_emu_')
     out = os.path.join(out_dir, 'libbrx_emu.so')
     cmd = [os.environ.get('CXX', 'g++'), '-O1', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', '-w', '-x', 'c++',
-           '-I', os.path.join(HERE, 'native', 'emu'), '-I', os.path.join(REPO, 'include'),
-           os.path.join(REPO, 'badread_amd', 'csrc', 'brx_hip.hip'), '-o', out]
+           '-I', os.path.join(HERE, 'native', 'emu'), '-I', os.path.join(REPO, 'include')] + list(defines) + \
+          [os.path.join(REPO, 'badread_amd', 'csrc', 'brx_hip.hip'), '-o', out]
     subprocess.check_call(cmd)
-    _lib = E.bind_library(ctypes.CDLL(out))
-    return _lib
+    _variants[key] = E.bind_library(ctypes.CDLL(out))
+    if not key:
+        _lib = _variants[key]
+    return _variants[key]
 
 
 class EmuEngine(E.HipEngine):
     """HipEngine's binding over the emulated library; buffers are CPU tensors."""
 
-    def __init__(self, scratch_bytes=1 << 28):
+    def __init__(self, scratch_bytes=1 << 28, defines=()):
         E.EngineBase.__init__(self)
         import torch
         self.torch = torch
         self.device = torch.device('cpu')
-        self.lib = build()
+        self.defines = tuple(defines)
+        self.lib = build(self.defines)
         ctx = ctypes.c_void_p()
         rc = self.lib.brx_create(0, ctypes.byref(ctx))
         if rc != 0:
@@ -57,7 +66,7 @@ class EmuEngine(E.HipEngine):
 
     def clone(self, scratch_bytes=None):
         """Second context over the same tables (what HipEngine.clone does for batches in flight)."""
-        other = EmuEngine(scratch_bytes or self._scratch.numel())
+        other = EmuEngine(scratch_bytes or self._scratch.numel(), self.defines)
         other._keep = dict(self._keep)
         other.sym = self.sym
         setters = {'ref': self.lib.brx_set_reference, 'em': self.lib.brx_set_error_model,

@@ -52,3 +52,22 @@ class Draws(object):
     @staticmethod
     def below64(lo, hi, n):
         return mulhi64((hi << 32) | lo, n)
+
+
+def draw4_many(seed, read, stream, indices):
+    """Vectorised draw4 (numpy): (len(indices), 4) uint32 words of the blocks `indices` of one read's stream."""
+    import numpy as np
+    idx = np.asarray(indices, dtype=np.uint64)
+    c0 = idx & np.uint64(M32)
+    c1 = (idx >> np.uint64(32)) & np.uint64(M32)
+    c2 = np.full(len(idx), read & M32, dtype=np.uint64)
+    c3 = np.full(len(idx), ((read >> 32) & 0x00FFFFFF) | (stream << 24), dtype=np.uint64)
+    k0, k1 = seed & M32, (seed >> 32) & M32
+    m = np.uint64(M32)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)) & m, p1 & m, ((p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)) & m, p0 & m
+        k0 = (k0 + 0x9E3779B9) & M32
+        k1 = (k1 + 0xBB67AE85) & M32
+    return np.stack([c0, c1, c2, c3], axis=1).astype(np.uint32)

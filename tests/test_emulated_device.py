@@ -105,6 +105,23 @@ def test_pipeline_routes_equal_the_oracle(env, monkeypatch):
         assert eng.mutate_passes() == 1
 
 
+def test_lds_threshold_build_variant(monkeypatch):
+    """The pass kernels built as 8-wave workgroups with the error model's self thresholds staged in LDS (the build variant
+    measured in round 2, csrc/brx_mutate.h): same bytes, bulk passes and in-place tail."""
+    import emu_engine as EE
+    pref, _ = H.small_reference()
+    p = SimParams(frag_mean=1100, frag_stdev=900)
+    for k, v in {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0}.items():
+        monkeypatch.setenv(k, str(v))
+    eng = H.configure(EE.EmuEngine(1 << 29, defines=('-DBRX_SEG_WAVES=8', '-DBRX_SEG_THR_ROWS=16384')), pref, 'nanopore2023', 'nanopore2023', p)
+    orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
+    out_h, st_h = eng.simulate_batch(42, 0, 40)
+    out_o, st_o = orc.simulate_batch(42, 0, 40)
+    for f in STAT_FIELDS:
+        assert (st_h[f] == st_o[f]).all(), f
+    assert H.first_diff(out_h, out_o) < 0
+
+
 @pytest.mark.parametrize('wg', [0, 1])
 def test_pipeline_other_models_and_fragment_kinds(wg, monkeypatch):
     """random / ideal models (k = 1), low identity, chimeras, junk and random reads, glitches, N runs and hairpins;
@@ -215,3 +232,35 @@ def test_final_stage_in_several_scratch_chunks(monkeypatch):
     for f in STAT_FIELDS:
         assert (st_h[f] == st_o[f]).all(), f
     assert H.first_diff(out_h, out_o) < 0
+
+
+def test_long_segment_lists_continue_in_the_overflow_lists():
+    """VERDICT r1 item 8 / ADVICE: the planner's private list of base segments (BRX_MAX_BASE_SEGS) is not a limit any more --
+    longer lists continue in a global overflow list, like the reference's unbounded chimera loop (simulate.py:101-110).
+    Built here with FOUR private segments and run at --chimeras 50 so that most chimeric reads overflow: same bytes as
+    the oracle, no status flag."""
+    import emu_engine as EE
+    pref, _ = H.small_reference()
+    p = SimParams(frag_mean=300, frag_stdev=200, chimera_rate=0.5, glitch_rate=300, glitch_size=5, glitch_skip=5)
+    eng = H.configure(EE.EmuEngine(1 << 29, defines=('-DBRX_MAX_BASE_SEGS=4',)), pref, 'random', 'ideal', p)
+    orc = H.configure(H.oracle_engine(), pref, 'random', 'ideal', p)
+    out_h, st_h = eng.simulate_batch(5, 0, 48)
+    out_o, st_o = orc.simulate_batch(5, 0, 48)
+    assert (st_h['status'] & 2 == 0).all()                        # RS_TOO_MANY_SEGS
+    for f in STAT_FIELDS:
+        assert (st_h[f] == st_o[f]).all(), f
+    assert H.first_diff(out_h, out_o) < 0
+    assert out_o.tobytes().count(b'chimera') >= 30                 # the workload really chains fragments
+
+
+def test_band_wider_than_the_register_classes():
+    """A pair whose band needs more than 64 lanes x 32 words (57 344 rows: the limit of round 1, BRX_RS_BAND) goes through
+    the memory-resident wide path with 64 words per lane: distance and the whole canonical path equal the oracle's."""
+    rng = np.random.default_rng(12)
+    eng = emu_engine()
+    q = H.random_dna(rng, 60500).encode()
+    t = H.random_dna(rng, 700).encode()
+    d, ops = pyoracle.align(q, t)
+    got_ops, dist, ncols, nmatch = eng.align_batch([q], [t], k_hint=[d])
+    assert int(dist[0]) == d and int(ncols[0]) == len(ops) and int(nmatch[0]) == int((ops == 0).sum())
+    assert np.array_equal(got_ops[0], ops)

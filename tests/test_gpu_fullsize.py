@@ -98,3 +98,70 @@ def test_configs1_full_batch_properties(workload, monkeypatch):
         assert bytes(o2) == head, f'BRX_TB_WINDOW={window}'
         assert (e2.window_misses() > 1000) == want_misses
         e2.close()
+
+
+@pytest.mark.parametrize('wlname', ['human', 'hifi'])
+def test_configs3_and_4_every_read_of_a_full_batch_equals_the_oracle(wlname, tmp_path):
+    """BASELINE.json configs[3] (GRCh38-like 3.09 Gb, nanopore2023) and configs[4] (pacbio2021, --identity 30,3) at the
+    bench's batch size: ALL 16384 reads of the first device batch, HIP path vs the CPU oracle (one oracle process per
+    usable host core on disjoint slices of the batch), FASTQ bytes and every per-read statistic.  The batch is known
+    (oracle plan probes, read indices 0..16383 under seed 42) to hold reads that overlap N runs -- whose windows carry
+    non-ACGT symbols and saturated edit bounds -- and reads clipped at the end of a linear contig
+    (simulate.py:231-246); both are asserted from the GPU's own output."""
+    import os
+    import subprocess
+    import sys
+    import bench
+    import synth_refs
+    from badread_amd.engine import HipEngine, RS_EMPTY
+    ref_dir = bench.default_ref_dir()
+    wl = bench.build_workload(io.StringIO(), wlname, ref_dir)          # FASTA -> brx_fasta_pack -> sidecar (first use on this box)
+    pref = wl[0]
+    assert pref.n_bases == 3088269832 and len(pref.names) == 24 and len(pref.exceptions) == 24 * 2 + 3
+    eng = bench.configure(HipEngine(0, scratch_bytes=34 << 30), wl)
+    out, st = eng.simulate_batch(SEED, 0, N)
+    out, st = out.copy(), st.copy()
+    eng.close()
+    assert (st['status'] & ~np.uint32(RS_EMPTY) == 0).all()
+
+    cores = max(1, min(bench.usable_cores(), 32))
+    per = -(-N // cores)
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='')
+    procs = []
+    for i in range(cores):
+        first, count = i * per, max(0, min(per, N - i * per))
+        if count == 0:
+            continue
+        path = str(tmp_path / f'slice{i}.npz')
+        procs.append((first, count, path, subprocess.Popen([sys.executable, os.path.join(here, 'oracle_slice_worker.py'), wlname, ref_dir,
+                                                            str(SEED), str(first), str(count), path], env=env,
+                                                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
+    raw = out.tobytes()
+    for first, count, path, pr in procs:
+        _, err = pr.communicate(timeout=900)
+        assert pr.returncode == 0, err.decode()[-2000:]
+        z = np.load(path)
+        so = z['stats']
+        lo = int(st['rec_off'][first])
+        hi = int(st['rec_off'][first + count - 1] + st['rec_len'][first + count - 1])
+        assert z['data'].tobytes() == raw[lo:hi], f'{wlname}: reads {first}..{first + count - 1} differ from the oracle'
+        for f in ('status', 'frag_len', 'seq_len', 'n_cols', 'n_match', 'padded_len', 'loop_count', 'change_count', 'n_alignments',
+                  'rec_len', 'target_identity', 'qerr_sum'):
+            assert (so[f] == st[f][first:first + count]).all(), (wlname, f, first)
+
+    # the batch really exercises the non-ACGT path and the clipping of linear contigs
+    lengths = dict(synth_refs.GRCH38_LENGTHS)
+    with_n = clipped = 0
+    for r in np.flatnonzero(st['rec_len'] > 0).tolist():
+        rec = raw[int(st['rec_off'][r]): int(st['rec_off'][r]) + int(st['rec_len'][r])]
+        head, seq = rec.split(b'\n', 2)[:2]
+        with_n += b'N' in seq
+        for m in re.finditer(rb'(chr\w+),[+-]strand,(\d+)-(\d+)', head):
+            clipped += int(m.group(3)) == lengths[m.group(1).decode()]
+    assert with_n >= 10 and clipped >= 1, (with_n, clipped)
+    ident = st['n_match'][st['n_cols'] > 0] / st['n_cols'][st['n_cols'] > 0]
+    if wlname == 'hifi':
+        assert float(np.mean(ident)) > 0.995                      # qscore-distributed identities around Q30
+    else:
+        assert 0.93 < float(np.mean(ident)) < 0.97

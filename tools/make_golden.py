@@ -455,10 +455,58 @@ def make_sequence_fragment():
     dump('sequence_fragment.json.gz', {'cases': cases})
 
 
+def make_random_change():
+    """Counts of the reference's own add_one_random_change (error_model.py:163-176) over 240 000 calls per k-mer, under
+    random.seed(2024): the empirical law tests/test_golden_host.py::test_random_change_law_against_the_reference holds
+    the oracle's enumerated law against (support and chi-square)."""
+    import collections
+    from badread.error_model import add_one_random_change
+    cases = []
+    random.seed(2024)
+    for kmer in ('A', 'N', 'GATTACA', 'ACGTNCA'):
+        counts = collections.Counter()
+        for _ in range(240000):
+            counts['|'.join(add_one_random_change(kmer))] += 1
+        cases.append({'kmer': kmer, 'calls': 240000, 'counts': dict(sorted(counts.items()))})
+        print(f'  random_change {kmer}: {len(counts)} outcomes')
+    dump('random_change.json', {'cases': cases})
+
+
+def make_qscore_top_rows():
+    """The 32 most frequent CIGAR rows of the reference's qscore model files (by the occurrence count the files carry)
+    with the scores / probabilities the REFERENCE's own QScoreModel parses for them: the expected laws of the per-row
+    chi-square gate (SURVEY.md section 8d gate 3)."""
+    import gzip as gz
+    out = {}
+    for name in ('nanopore2023', 'pacbio2021'):
+        path = os.path.join(REFERENCE, 'badread', 'qscore_models', name + '.gz')
+        counts = {}
+        with gz.open(path, 'rt') as f:
+            for line in f:
+                parts = line.strip().split(';')
+                if len(parts) >= 3 and parts[0] != 'overall':
+                    counts[parts[0]] = int(parts[1])
+        model = ref_qm.QScoreModel(name, NULL)
+        top = sorted((c for c in counts if c in model.scores), key=lambda c: -counts[c])[:32]
+        total = sum(counts.values())
+        out[name] = [{'cigar': c, 'count': counts[c], 'share': counts[c] / total, 'scores': list(model.scores[c]),
+                      'probs': list(model.probabilities[c])} for c in top]
+        print(f'  qscore_top_rows {name}: top row {top[0]} {counts[top[0]] / total:.3f}')
+    dump('qscore_top_rows.json', out)
+
+
 if __name__ == '__main__':
     os.makedirs(GOLDEN, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'random_change':
+        make_random_change()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'qscore_top_rows':
+        make_qscore_top_rows()
+        sys.exit(0)
     make_misc()
     make_align_kmers()
     make_fragments()
     make_build_fragment()
     make_sequence_fragment()
+    make_random_change()
+    make_qscore_top_rows()
