@@ -46,6 +46,7 @@ struct brx_ctx {
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
     int mutate_wg;               /* BRX_MUTATE_WG=1: the mutate stage is one launch of k_mutate_wg (brx_mutate_wg.h; measured slower at batch scale); default 0 = the pass pipeline */
+    uint32_t fin_head_reads;     /* BRX_FIN_HEAD_READS: the longest reads of a batch form the head set of the final stage (side streams) */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
     int wide_stream;             /* BRX_WIDE_STREAM: the head set's widest band class aligns on a third stream */
     hipStream_t side2;
@@ -157,14 +158,15 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mw = getenv("BRX_MUTATE_WG"); c->mutate_wg = mw ? atoi(mw) : 0; }
-    { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 2048u; }
+    { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 0u; }
+    { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
     { const char *pf = getenv("BRX_PROFILE"); c->profile = (pf && atoi(pf)) ? 1 : 0; }
     { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
-    { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 2048u; }
+    { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 64u; }
     { const char *sw = getenv("BRX_SEG_WAVES_PER_CU"); c->seg_waves_per_cu = sw && atoi(sw) > 0 ? (uint32_t)atoi(sw) : 8u; }
     { const char *lt = getenv("BRX_LANE_THRESHOLD"); c->lane_threshold = lt ? (uint32_t)atoi(lt) : 3000u; }
     c->err[0] = 0;
@@ -362,7 +364,9 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     const bool use_wg = c->mutate_wg && !c->mutate_inline;
     const uint32_t wg_blocks = std::min<uint32_t>((n_reads + BRX_WG_WAVES - 1) / BRX_WG_WAVES, (uint32_t)c->n_cu * 2u);
     uint2 *lane_tb = use_wg ? nullptr : (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
-    uint2 *pack_tb = use_wg ? (uint2 *)A.take((size_t)wg_blocks * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2)) : nullptr;
+    /* traceback stores of the packed window aligner: one set of 8 per workgroup of k_mutate_wg, or per wave of k_win_pack */
+    const uint32_t pack_waves = std::min<uint32_t>((std::min<uint32_t>(n_reads, c->lane_threshold) + BRX_PACK_NG - 1) / BRX_PACK_NG, (uint32_t)c->n_cu * 4u);
+    uint2 *pack_tb = (uint2 *)A.take((size_t)(use_wg ? wg_blocks : std::max<uint32_t>(pack_waves, 1u)) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
     if (!raw) { KTIMED(BRX_KERN_PLAN, st); hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces); }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_PLAN], st));
@@ -390,12 +394,18 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     std::vector<RS> h_rs(n_reads);
     c->final_launches = 0;
     c->window_misses = 0;
-    const uint32_t n_head = (c->mutate_inline || (!use_wg && n_reads <= c->tail_reads)) ? n_reads
-                            : (use_wg && n_reads <= 2 * c->head_reads) ? 0u : std::min<uint32_t>(c->head_reads, n_reads);
+    /* n_mh: reads the mutate HEAD chain takes (BRX_HEAD_READS, default 0 = every read goes through the passes: since the
+       small passes use the packed window aligner, in-place alignments -- 5x the instructions per window -- are kept for
+       the last BRX_TAIL_READS reads only); n_head: the head set of the FINAL stage (BRX_FIN_HEAD_READS, default 2048; it
+       is the mutate head set when that chain is on, because its final stage starts when its own reads are mutated) */
+    const uint32_t n_mh = (c->mutate_inline || (!use_wg && n_reads <= c->tail_reads)) ? n_reads
+                          : use_wg ? 0u : std::min<uint32_t>(c->head_reads, n_reads);
+    const uint32_t n_mb = n_reads - n_mh;
+    const uint32_t n_head = n_mh ? n_mh : (n_reads <= 2 * c->fin_head_reads ? 0u : c->fin_head_reads);
     const uint32_t n_bulk = n_reads - n_head;
     uint8_t *win_head = nullptr;
-    if (n_head && n_bulk && !use_wg) {
-        win_head = (uint8_t *)A.take((size_t)(std::min(n_head, side_waves) + BRX_SEG_WAVES) * c->win_bytes);
+    if (n_mh && n_mb && !use_wg) {
+        win_head = (uint8_t *)A.take((size_t)(std::min(n_mh, side_waves) + BRX_SEG_WAVES) * c->win_bytes);
         if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
     } else win_head = win;
     hipStream_t s_head = n_bulk ? c->side : st;            /* an all-head batch stays on the caller's stream */
@@ -416,6 +426,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     /* counters: [0],[3] join queues of head / bulk; [1] flags; [2],[4] window misses of head / bulk;
        [16 + 16 x ((set x 2 + phase) x BRX_MAX_CHUNKS + chunk)] final-stage queue heads */
     auto set_counter = [&](const FinalSet &S, int which) -> uint32_t * { return counters + (which == 0 ? (S.id ? 3 : 0) : (S.id ? 4 : 2)); };
+    bool legacy_handled = false;       /* the whole-read fallback already ran for every read (no separate mutate head chain) */
     uint64_t tail_bases = 0;           /* kernel statistics: bases of the bulk reads that finished in the in-place tail */
 
     /* launches of one phase of one set (phase 0: windowed store for every read; phase 1: full store for the misses) */
@@ -551,8 +562,8 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         }
         /* reads whose window did not fit a slot: the whole-read kernel with the inline wave aligner */
         DBG("set %d: %u reads, %u to the whole-read kernel", S.id, ns, h_ctr[0]);
-        if (h_ctr[0] > 0 && !use_wg)
-            hipLaunchKernelGGL(k_mutate, dim3(std::min(S.id ? side_waves : std::min(n_head, side_waves), h_ctr[0])), dim3(64), 0, S.st, dev, rs,
+        if (h_ctr[0] > 0 && !legacy_handled)
+            hipLaunchKernelGGL(k_mutate, dim3(std::min(S.id ? side_waves : std::min(std::max(n_mh, 1u), side_waves), h_ctr[0])), dim3(64), 0, S.st, dev, rs,
                                S.id ? req_legacy : req_legacy_head, legacy, legacy + 1, Fbuf, repl, S.id ? win : win_head,
                                (uint64_t)c->win_bytes, counters + 1, clk);
         hipLaunchKernelGGL(k_scan_mut, dim3(1), dim3(64), 0, S.st, ns, rs, order + S.b, totals + (S.id ? 3 : 8));
@@ -606,8 +617,8 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     {
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         memset(h_ctr, 0, 2 * MC_WORDS * sizeof(uint32_t));
-        h_ctr[MC_OUT] = n_bulk;                    /* block 2: "previous pass" of the first bulk pass */
-        h_ctr[MC_WORDS + MC_OUT] = n_head;         /* block 4 (copied below): the head launch's input count */
+        h_ctr[MC_OUT] = n_mb;                      /* block 2: "previous pass" of the first bulk pass */
+        h_ctr[MC_WORDS + MC_OUT] = n_mh;           /* block 4 (copied below): the head launch's input count */
         HIPCHK(c, hipMemcpyAsync(mctr + 2 * MC_WORDS, h_ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(mctr + 4 * MC_WORDS, h_ctr + MC_WORDS, MC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         HIPCHK(c, hipStreamSynchronize(st));
@@ -640,44 +651,34 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
                                    req_legacy, legacy_ctr, Fbuf, repl, winbuf, pack_tb, win, (uint64_t)c->win_bytes, counters + 1, clk, phase);
         }
         c->mutate_passes = 1;
-        HIPCHK(c, hipMemcpyAsync(h_ctr, legacy_ctr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        { int rcw = wait_stream(c, st, "k_mutate_wg"); if (rcw) return rcw; }
-        if (h_ctr[0] > 0)            /* reads whose window did not fit a slot: the whole-read kernel with the inline wave aligner */
-            hipLaunchKernelGGL(k_mutate, dim3(std::min(side_waves, h_ctr[0])), dim3(64), 0, st, dev, rs, req_legacy, legacy_ctr,
-                               legacy_ctr + 1, Fbuf, repl, win, (uint64_t)c->win_bytes, counters + 1, clk);
-        if (n_head && n_bulk) {
-            HIPCHK(c, hipEventRecord(c->ev_fork, st));
-            HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
-        }
-        tail_bases = 0;
     }
     /* ---- head chain: mutate to completion ---- */
-    if (n_head && !use_wg) {
-        if (n_bulk) {
+    if (n_mh && !use_wg) {
+        if (n_mb) {
             HIPCHK(c, hipEventRecord(c->ev_fork, st));
             HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
         }
-        launch_run(s_head, n_head, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, req_legacy_head,
+        launch_run(s_head, n_mh, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, req_legacy_head,
                    mctr + 5 * MC_WORDS, win_head);
-        if (n_bulk) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
+        if (n_mb) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
         c->mutate_passes = 1;
     }
     /* ---- bulk chain: passes ---- */
     int rc2 = BRX_OK;
-    if (n_bulk && !use_wg) {
-        const uint32_t seg_waves = std::min<uint64_t>(n_bulk, (uint64_t)c->n_cu * (uint64_t)c->seg_waves_per_cu);
+    if (n_mb && !use_wg) {
+        const uint32_t seg_waves = std::min<uint64_t>(n_mb, (uint64_t)c->n_cu * (uint64_t)c->seg_waves_per_cu);
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;                                 /* [0] count, [1] queue; not reset per pass */
         const uint32_t *n_in = mctr + 2 * MC_WORDS + MC_OUT;
-        const uint32_t *act_in = order + n_head;
-        uint32_t n_up = n_bulk, pass = 0;
+        const uint32_t *act_in = order + n_mh;
+        uint32_t n_up = n_mb, pass = 0;
         const uint32_t tail_reads = c->tail_reads;   /* this few reads left: run them to completion in place (no host round trips) */
         auto read_counts = [&](uint32_t *ctr) -> int {
             HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             return wait_stream(c, st, "mutate pass");
         };
         auto poll_head = [&]() -> int {      /* the head set's final stage starts as soon as its reads are mutated */
-            if (sets[0].launched || hipEventQuery(c->ev_head_mut) != hipSuccess) return BRX_OK;
+            if (!n_mh || sets[0].launched || hipEventQuery(c->ev_head_mut) != hipSuccess) return BRX_OK;
             return start_final(sets[0]);
         };
         for (; n_up > 0 && pass < (1u << 20); ++pass) {
@@ -714,6 +715,10 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
                 KTIMED(BRX_KERN_WIN_LANE, st);
                 hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64)), dim3(64), 0, st, msv, req_easy,
                                    ctr + MC_EASY, winbuf, lane_tb);
+            } else {                                   /* few reads left: eight windows per wave (same list, same class) */
+                KTIMED(BRX_KERN_WIN_LANE, st);
+                hipLaunchKernelGGL(k_win_pack, dim3(std::min(pack_waves, (n_up + BRX_PACK_NG - 1) / BRX_PACK_NG)), dim3(64), 0, st, msv, req_easy,
+                                   ctr + MC_EASY, ctr + 6, winbuf, pack_tb);
             }
             {
                 KTIMED(BRX_KERN_WIN_WAVE, st);
@@ -733,6 +738,22 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         }
         c->mutate_passes += pass;
         if (n_up > 0) return fail(c, BRX_E_INTERNAL, "mutate pipeline did not converge after %u passes", pass);
+    }
+    if (!n_mh) {
+        /* one mutate chain for all reads: the whole-read fallback (windows that did not fit a slot) runs here, for both
+           final sets, and the head set's side stream waits for the whole mutate stage */
+        uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
+        uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;
+        HIPCHK(c, hipMemcpyAsync(h_ctr, legacy_ctr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        { int rcw = wait_stream(c, st, "mutate stage"); if (rcw) return rcw; }
+        if (h_ctr[0] > 0)
+            hipLaunchKernelGGL(k_mutate, dim3(std::min(side_waves, h_ctr[0])), dim3(64), 0, st, dev, rs, req_legacy, legacy_ctr,
+                               legacy_ctr + 1, Fbuf, repl, win, (uint64_t)c->win_bytes, counters + 1, clk);
+        legacy_handled = true;
+        if (n_head && n_bulk) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, st));
+            HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
+        }
     }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_MUTATE], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_SCAN], st));

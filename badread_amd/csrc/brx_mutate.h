@@ -251,8 +251,10 @@ __global__ void __launch_bounds__(64 * BRX_SEG_WAVES, 4) k_mutate_seg(BrxDev d, 
                             __builtin_amdgcn_s_waitcnt(0);
                             const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
                             const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
-                            const bool easy = !INLINE && !odd && g.G == 1 && band_blocks <= BRX_LANE_W &&
-                                              tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 && n_in > lane_threshold;
+                            /* "easy" windows go to a throughput kernel: one window per LANE while the pass is large, eight
+                               windows per wave (k_win_pack) once fewer than lane_threshold reads are active */
+                            const bool easy = !INLINE && !odd && g.G == 1 && tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 &&
+                                              (n_in > lane_threshold ? band_blocks <= BRX_LANE_W : brx_pack_eligible(ql, tl, cost, odd));
                             klass = easy ? MC_EASY : MC_HARD;
                         }
                         {
@@ -535,6 +537,64 @@ __global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, c
             msv[r].res_ncols = ok ? ncols : 0u;
             msv[r].res_nmatch = ok ? nmatch : 0u;
             if (!ok) msv[r].status = ms.status | BRX_RS_BAND;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+}
+
+/* -------------------------------------------------------------------------------------------------
+ * k_win_pack: EIGHT parked windows per wave (brx_pack.h), for passes with few active reads
+ * -----------------------------------------------------------------------------------------------
+ * The lane-per-window kernel is the cheapest in instructions (1.9 k wave-instructions per window) but one launch takes
+ * 2.4-7 ms, because a lane walks 1000 columns alone; the wave-per-window aligner answers in ~0.1 ms but spends a whole
+ * wave's instruction stream on 4-6 busy lanes (61 k per window), which is what made the in-place tail of round 1 17 % of
+ * all VALU instructions of a batch -- on a path that is bound by VALU issue.  Passes with fewer than BRX_LANE_THRESHOLD
+ * active reads (the long reads: hundreds of dependent cycles) therefore use this kernel: 8 windows share a wave (12 k
+ * per window), one launch takes ~0.3 ms.  A wave pulls eight requests, turns their byte pairs (winbuf slots written by
+ * wave_park) into 2-bit planes in LDS, aligns them and writes the results to the reads' MS. */
+__global__ void __launch_bounds__(64, 4) k_win_pack(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr, uint32_t *queue,
+                                                  const uint8_t *winbuf, uint2 *tb_base) {
+    __shared__ BrxPackWin s_win[BRX_PACK_NG];
+    const int lane = lane_id();
+    const uint32_t n_req = uni(*n_req_ptr);
+    uint2 *tb = tb_base + (size_t)blockIdx.x * (size_t)BRX_PACK_NG * (size_t)BRX_PACK_TB_UNITS;
+    for (;;) {
+        const uint32_t q0 = uni(atomicAdd(queue, lane == 0 ? (uint32_t)BRX_PACK_NG : 0u));
+        if (q0 >= n_req) break;
+        const uint32_t cnt = n_req - q0 < (uint32_t)BRX_PACK_NG ? n_req - q0 : (uint32_t)BRX_PACK_NG;
+        /* ---- planes of the (up to) eight pairs: 64 symbols per step, one ballot per plane ---- */
+        for (uint32_t w = 0; w < (uint32_t)BRX_PACK_NG; ++w) {
+            BrxPackWin &W = s_win[w];
+            if (w >= cnt) { if (lane == 0) { W.Q = 0; W.T = 0; W.k = 0; } continue; }
+            const uint32_t r = req[q0 + w];
+            const MS ms = msv[r];
+            const uint32_t Q = ms.win_b - ms.win_a, T = ms.tl;
+            const uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+            for (uint32_t it = 0; 64u * it < Q; ++it) {
+                const uint32_t x = 64u * it + (uint32_t)lane;
+                const uint32_t c = x < Q ? qb[x] : 0u;
+                const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
+                if (lane < 2) { W.qlo[2 * it + lane] = (uint32_t)(lo >> (32 * lane)); W.qhi[2 * it + lane] = (uint32_t)(hi >> (32 * lane)); }
+            }
+            for (uint32_t it = 0; 64u * it < T; ++it) {
+                const uint32_t x = 64u * it + (uint32_t)lane;
+                const uint32_t c = x < T ? tbuf[x] : 0u;
+                const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
+                if (lane < 2 && 2 * it + lane < BRX_PACK_TW) { W.tlo[2 * it + lane] = (uint32_t)(lo >> (32 * lane)); W.thi[2 * it + lane] = (uint32_t)(hi >> (32 * lane)); }
+            }
+            if (lane == 0) { W.Q = Q; W.T = T; W.k = ms.cost; W.ncols = 0; W.nmatch = 0; W.ok = 0; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        brx_pack_align(s_win, tb);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        if ((uint32_t)lane < cnt) {
+            const uint32_t r = req[q0 + (uint32_t)lane];
+            const BrxPackWin &W = s_win[lane];
+            msv[r].res_ncols = W.ncols; msv[r].res_nmatch = W.nmatch;
+            if (!W.ok) msv[r].status |= BRX_RS_BAND;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);

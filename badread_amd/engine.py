@@ -171,6 +171,7 @@ class EngineBase(object):
             setattr(s, field, ptr)
             keep.append(k)
         self._keep['em'] = keep
+        self._configured = dict(getattr(self, '_configured', {}), em=t)       # which tables this engine holds now (simulate.sequence_fragment)
         return s
 
     def _fill_qscore_model(self, t):
@@ -183,6 +184,7 @@ class EngineBase(object):
             setattr(s, field, ptr)
             keep.append(k)
         self._keep['qm'] = keep
+        self._configured = dict(getattr(self, '_configured', {}), qm=t)
         return s
 
     def _fill_params(self, params):

@@ -213,7 +213,7 @@ class ErrorModel(object):
                         print(f'  done: loaded error distributions for {len(self._kmers)} '
                               f'{self.kmer_size}-mers', file=output)
                         return
-                    except (OSError, KeyError, ValueError):
+                    except Exception:          # truncated / foreign file (zipfile.BadZipFile, KeyError ...): re-parse the model
                         pass
         with get_open_func(filename)(filename, 'rt') as model_file:
             for line in model_file:
@@ -230,11 +230,16 @@ class ErrorModel(object):
         self._align_all()
         print(f'\r  done: loaded error distributions for {len(self._kmers)} {self.kmer_size}-mers',
               file=output)
-        if cache_path:
+        if cache_path and os.environ.get('RANK', '0') in ('', '0'):     # one writer per launch, and atomically:
+            tmp = f'{cache_path}.{os.getpid()}.tmp.npz'                 # a reader never sees a half-written archive
             try:
-                self.save_npz(cache_path)
+                self.save_npz(tmp)
+                os.replace(tmp, cache_path)
             except OSError:
-                pass
+                try:
+                    os.remove(tmp)
+                except OSError:
+                    pass
 
     def _align_all(self):
         """One batch of inner alignments for every alt of every row (error_model.py:129,202)."""

@@ -137,6 +137,11 @@ class QScoreModel(object):
         for cigar in self.scores:
             for run in re.findall(r'D+', cigar):
                 max_run = max(max_run, len(run))
+        # the D-run between two ops is stored in gap_bits bits, the all-ones code being reserved for "longer than any
+        # row of the table": every run of the model must stay below it, or rows would silently drop out of the table
+        if max_run > 14:
+            sys.exit(f'Error: qscore model holds a cigar with a run of {max_run} deletions; the HIP path encodes runs of up '
+                     f'to 14 (the built-in models stop at 6)')
         gap_bits = 3 if max_run <= 6 else 4
         if 2 * k + gap_bits * (k - 1) > 56:
             sys.exit(f'Error: qscore model with {k}-op windows is too wide for the HIP path')

@@ -527,7 +527,8 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
     if engine is None:
         from .engine import default_engine
         engine = default_engine()
-    error_model = ErrorModel(args.error_model, quiet)
+    # a model file that is not in the cache is aligned (align_kmers, error_model.py:179-229) on THIS engine
+    error_model = ErrorModel(args.error_model, quiet, aligner=lambda qs, ts: engine.align_batch(qs, ts)[0])
     qscore_model = QScoreModel(args.qscore_model, quiet)
     print_glitch_summary(args.glitch_rate, args.glitch_size, args.glitch_skip, quiet)
     start_rate, start_amount = adapter_parameters(args.start_adapter)
@@ -610,12 +611,14 @@ def sequence_fragment(fragment, target_identity, error_model, qscore_model, engi
     if engine is None:
         from .engine import default_engine
         engine = default_engine()
-    key = (id(engine), id(error_model), id(qscore_model))
-    if _seq_engine_state.get('key') != key:
+    # (re)configure the engine unless it holds exactly these tables already: the engine remembers what it was last
+    # given, so a simulate() or a direct set_* call in between is noticed
+    held = getattr(engine, '_configured', {})
+    if held.get('em') is not error_model.tables():
         engine.set_error_model(error_model.tables())
+    if held.get('qm') is not qscore_model.tables():
         engine.set_qscore_model(qscore_model.tables())
-        _seq_engine_state['key'] = key
-        _seq_engine_state['keep'] = (error_model, qscore_model)
+    _seq_engine_state['keep'] = (error_model, qscore_model)
     if seed is None:
         seed = random.getrandbits(64)
     if len(fragment) == 0:

@@ -76,7 +76,8 @@ ROUTES = [
     {'BRX_TB_WINDOW': -1},                                     # 8-row traceback window: most reads repeat (phase 1)
     {'BRX_TB_WINDOW': 0, 'BRX_WIDE_STREAM': 0},                # full store, no third stream for the widest class
     {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0},         # bulk passes only: every window through the lane kernel
-    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 1000000},   # bulk passes only: every window through the wave kernel
+    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 1000000},   # bulk passes only: eight windows per wave (k_win_pack), the rest through the wave kernel
+    {'BRX_TAIL_READS': 6, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_FIN_HEAD_READS': 9},   # passes with packed windows, a 6-read in-place tail, final stage in two sets
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},         # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
     # the one-launch mutate stage (BRX_MUTATE_WG=1: workgroups of 8 reads, packed window alignments)

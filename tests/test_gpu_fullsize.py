@@ -117,7 +117,8 @@ def test_configs3_and_4_every_read_of_a_full_batch_equals_the_oracle(wlname, tmp
     ref_dir = bench.default_ref_dir()
     wl = bench.build_workload(io.StringIO(), wlname, ref_dir)          # FASTA -> brx_fasta_pack -> sidecar (first use on this box)
     pref = wl[0]
-    assert pref.n_bases == 3088269832 and len(pref.names) == 24 and len(pref.exceptions) == 24 * 2 + 3
+    assert pref.n_bases == 3088269832 and len(pref.names) == 24
+    assert len(pref.exceptions) == 25 + 3        # the end run of one contig and the start run of the next are one run in packed coordinates
     eng = bench.configure(HipEngine(0, scratch_bytes=34 << 30), wl)
     out, st = eng.simulate_batch(SEED, 0, N)
     out, st = out.copy(), st.copy()

@@ -87,9 +87,10 @@ def test_sequence_fragments_matches_oracle():
 
 @pytest.mark.parametrize('env', [{'BRX_TB_WINDOW': '0'}, {'BRX_TB_WINDOW': '-1'}, {'BRX_TB_WINDOW': '1'}, {'BRX_MUTATE_INLINE': '1'},
                                  {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0'},          # bulk passes, lane kernel
-                                 {'BRX_LANE_THRESHOLD': '1000000', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0'},    # bulk passes, wave kernel
+                                 {'BRX_LANE_THRESHOLD': '1000000', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0'},    # bulk passes, packed windows (k_win_pack)
                                  {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_LANE_THRESHOLD': '0'},        # two chains + in-place tail
                                  {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1', 'BRX_WIDE_STREAM': '0'},
+                                 {'BRX_TAIL_READS': '16', 'BRX_LANE_THRESHOLD': '100', 'BRX_FIN_HEAD_READS': '64'},   # lane passes, then packed passes, then the tail
                                  {'BRX_MUTATE_WG': '1'}, {'BRX_MUTATE_WG': '1', 'BRX_HEAD_READS': '64', 'BRX_TB_WINDOW': '-1'}])
 def test_alternative_kernel_routes_give_the_same_bytes(env, monkeypatch):
     """The optional routes (full / 8-row / narrow traceback window of the final alignment -- the 8-row window
