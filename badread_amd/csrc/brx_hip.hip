@@ -22,7 +22,7 @@
 #include "brx_kernels.h"
 
 #define BRX_MAX_CHUNKS 60
-#define BRX_KEV_MAX 768
+#define BRX_KEV_MAX 2048
 
 struct brx_ctx {
     int device;
@@ -158,7 +158,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mw = getenv("BRX_MUTATE_WG"); c->mutate_wg = mw ? atoi(mw) : 0; }
-    { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 0u; }
+    { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
@@ -166,7 +166,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
     { const char *pf = getenv("BRX_PROFILE"); c->profile = (pf && atoi(pf)) ? 1 : 0; }
     { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
-    { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 64u; }
+    { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 1024u; }
     { const char *sw = getenv("BRX_SEG_WAVES_PER_CU"); c->seg_waves_per_cu = sw && atoi(sw) > 0 ? (uint32_t)atoi(sw) : 8u; }
     { const char *lt = getenv("BRX_LANE_THRESHOLD"); c->lane_threshold = lt ? (uint32_t)atoi(lt) : 3000u; }
     c->err[0] = 0;
@@ -394,10 +394,12 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     std::vector<RS> h_rs(n_reads);
     c->final_launches = 0;
     c->window_misses = 0;
-    /* n_mh: reads the mutate HEAD chain takes (BRX_HEAD_READS, default 0 = every read goes through the passes: since the
-       small passes use the packed window aligner, in-place alignments -- 5x the instructions per window -- are kept for
-       the last BRX_TAIL_READS reads only); n_head: the head set of the FINAL stage (BRX_FIN_HEAD_READS, default 2048; it
-       is the mutate head set when that chain is on, because its final stage starts when its own reads are mutated) */
+    /* n_mh: reads the mutate HEAD chain takes (BRX_HEAD_READS, default 1024; 0 = every read goes through the passes);
+       n_head: the head set of the FINAL stage (the mutate head set when that chain is on, because its final stage starts
+       when its own reads are mutated; else BRX_FIN_HEAD_READS).  Measured on configs[3], 8 batches in flight
+       (profiles/README.md r02g/r02h): head 1024 + tail 1024 2.08 Gbases/s, head 2048 + tail 2048 2.01, no head chain and a
+       64-read tail (218 passes, the small ones with the packed window aligner) 1.63, 512-read tail 1.82 -- a pass costs
+       1.5-2.6 ms beside the other batches' kernels whatever it aligns, an in-place cycle 0.3-0.6 ms. */
     const uint32_t n_mh = (c->mutate_inline || (!use_wg && n_reads <= c->tail_reads)) ? n_reads
                           : use_wg ? 0u : std::min<uint32_t>(c->head_reads, n_reads);
     const uint32_t n_mb = n_reads - n_mh;

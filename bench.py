@@ -55,7 +55,8 @@ for _p in (REPO, os.path.join(REPO, 'tools')):
 
 ALGO_BYTES_PER_BASE = 2.26          # 0.25 B packed reference read + 2 B FASTQ written + header share
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_PEAK_PER_S = 256 * 4 * 2.4e9 / 2      # 1024 SIMDs x 2.4 GHz, one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md)
+VALU_PEAK_PER_S = 6.56e11           # wave64 32-bit integer VALU instructions/s, chip-wide, MEASURED (profiles/valu_rate.json, tools/native/valu_bench.hip):
+                                    # 4 cycles per instruction per SIMD -- half of what the 2-cycle v_fma_f32 rate of MI355X_MICROARCH.md would give
 SEED = 42
 
 WORKLOADS = {
@@ -478,7 +479,7 @@ def main():
     vpb = valu_per_base(args.workload)
     if vpb:
         rate = vpb['valu_per_base'] * value / world
-        result['roofline_alu'] = {'bound': 'valu-issue', 'achieved': rate, 'peak': VALU_PEAK_PER_S, 'unit': 'wave-instructions/s',
+        result['roofline_alu'] = {'bound': 'valu-issue', 'achieved': rate, 'peak': VALU_PEAK_PER_S, 'peak_source': 'profiles/valu_rate.json (measured integer VALU issue rate)', 'unit': 'wave-instructions/s',
                                   'frac': rate / VALU_PEAK_PER_S, 'valu_per_base': vpb['valu_per_base'], 'source': vpb.get('source')}
     result['stage_ms_per_device_batch'] = stages
     result['host_ms_per_device_batch'] = sum(a['host_ms'] for a in acc) / n_batches        # wall time of one brx_simulate_batch call
