@@ -45,6 +45,7 @@ struct brx_ctx {
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
+    int run_wg;                  /* BRX_RUN_WG (default 1): head chain and tail run as k_mutate_wg (packed identity checks) instead of k_mutate_seg<true> */
     int mutate_wg;               /* BRX_MUTATE_WG=1: the mutate stage is one launch of k_mutate_wg (brx_mutate_wg.h; measured slower at batch scale); default 0 = the pass pipeline */
     uint32_t fin_head_reads;     /* BRX_FIN_HEAD_READS: the longest reads of a batch form the head set of the final stage (side streams) */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
@@ -157,6 +158,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         if ((e = hipEventCreateWithFlags(&c->ev_fork2[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    { const char *rw = getenv("BRX_RUN_WG"); c->run_wg = rw ? atoi(rw) : 1; }
     { const char *mw = getenv("BRX_MUTATE_WG"); c->mutate_wg = mw ? atoi(mw) : 0; }
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
@@ -366,7 +368,9 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     uint2 *lane_tb = use_wg ? nullptr : (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
     /* traceback stores of the packed window aligner: one set of 8 per workgroup of k_mutate_wg, or per wave of k_win_pack */
     const uint32_t pack_waves = std::min<uint32_t>((std::min<uint32_t>(n_reads, c->lane_threshold) + BRX_PACK_NG - 1) / BRX_PACK_NG, (uint32_t)c->n_cu * 4u);
-    uint2 *pack_tb = (uint2 *)A.take((size_t)(use_wg ? wg_blocks : std::max<uint32_t>(pack_waves, 1u)) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
+    const bool all_head = c->mutate_inline || (!use_wg && n_reads <= c->tail_reads);      /* the whole batch in one run-to-completion launch */
+    const uint32_t run_blocks = ((all_head ? n_reads : std::min<uint32_t>(n_reads, std::max<uint32_t>(c->tail_reads, 1u))) + BRX_WG_WAVES - 1) / BRX_WG_WAVES;   /* the tail (or everything) as k_mutate_wg */
+    uint2 *pack_tb = (uint2 *)A.take((size_t)(use_wg ? wg_blocks : std::max<uint32_t>(std::max(pack_waves, run_blocks), 1u)) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
     if (!raw) { KTIMED(BRX_KERN_PLAN, st); hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces); }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_PLAN], st));
@@ -400,13 +404,15 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
        (profiles/README.md r02g/r02h): head 1024 + tail 1024 2.08 Gbases/s, head 2048 + tail 2048 2.01, no head chain and a
        64-read tail (218 passes, the small ones with the packed window aligner) 1.63, 512-read tail 1.82 -- a pass costs
        1.5-2.6 ms beside the other batches' kernels whatever it aligns, an in-place cycle 0.3-0.6 ms. */
-    const uint32_t n_mh = (c->mutate_inline || (!use_wg && n_reads <= c->tail_reads)) ? n_reads
+    const uint32_t n_mh = all_head ? n_reads
                           : use_wg ? 0u : std::min<uint32_t>(c->head_reads, n_reads);
     const uint32_t n_mb = n_reads - n_mh;
     const uint32_t n_head = n_mh ? n_mh : (n_reads <= 2 * c->fin_head_reads ? 0u : c->fin_head_reads);
     const uint32_t n_bulk = n_reads - n_head;
     uint8_t *win_head = nullptr;
+    uint2 *pack_head = pack_tb;
     if (n_mh && n_mb && !use_wg) {
+        pack_head = (uint2 *)A.take((size_t)((n_mh + BRX_WG_WAVES - 1) / BRX_WG_WAVES) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
         win_head = (uint8_t *)A.take((size_t)(std::min(n_mh, side_waves) + BRX_SEG_WAVES) * c->win_bytes);
         if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
     } else win_head = win;
@@ -626,9 +632,23 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         HIPCHK(c, hipStreamSynchronize(st));
     }
     const uint32_t lane_threshold = c->lane_threshold;   /* fewer active reads than this: one wave per window (lower latency) */
+    /* reads taken to completion in ONE launch (the head set from the start; the last BRX_TAIL_READS of the bulk set):
+       BRX_RUN_WG=1 (default) k_mutate_wg -- workgroups of 8 reads whose identity checks are aligned eight to a wave
+       (12 k wave-instructions per window) --, 0: k_mutate_seg<true>, every read aligning its own windows with a whole
+       wave (61 k per window; 53 of the batch's 195 VALU instructions per base in profiles/r02_valu_per_base.json) */
     auto launch_run = [&](hipStream_t s, uint32_t count, const uint32_t *act_in, const uint32_t *n_in, uint32_t *act_out, uint32_t *ctr,
-                          uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr) {
+                          uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr, uint2 *packscr) {
         KTIMED(BRX_KERN_MUTATE_RUN, s);
+        if (c->run_wg) {
+            const uint32_t blocks = (count + BRX_WG_WAVES - 1) / BRX_WG_WAVES;
+            if (c->profile)
+                hipLaunchKernelGGL((k_mutate_wg<true>), dim3(blocks), dim3(64 * BRX_WG_WAVES), 0, s, dev, rs, msv, act_in, count, ctr + MC_QUEUE,
+                                   legacy_list, legacy_ctr, Fbuf, repl, winbuf, packscr, winscr, (uint64_t)c->win_bytes, counters + 1, clk, phase);
+            else
+                hipLaunchKernelGGL((k_mutate_wg<false>), dim3(blocks), dim3(64 * BRX_WG_WAVES), 0, s, dev, rs, msv, act_in, count, ctr + MC_QUEUE,
+                                   legacy_list, legacy_ctr, Fbuf, repl, winbuf, packscr, winscr, (uint64_t)c->win_bytes, counters + 1, clk, phase);
+            return;
+        }
         if (c->profile)
             hipLaunchKernelGGL((k_mutate_seg<true, true>), dim3((std::min(count, side_waves) + BRX_SEG_WAVES - 1) / BRX_SEG_WAVES), dim3(64 * BRX_SEG_WAVES), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
                                req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
@@ -646,10 +666,10 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         {
             KTIMED(BRX_KERN_MUTATE_RUN, st);
             if (c->profile)
-                hipLaunchKernelGGL((k_mutate_wg<true>), dim3(wg_blocks), dim3(64 * BRX_WG_WAVES), 0, st, dev, rs, order, n_reads, mctr + MC_QUEUE,
+                hipLaunchKernelGGL((k_mutate_wg<true>), dim3(wg_blocks), dim3(64 * BRX_WG_WAVES), 0, st, dev, rs, msv, order, n_reads, mctr + MC_QUEUE,
                                    req_legacy, legacy_ctr, Fbuf, repl, winbuf, pack_tb, win, (uint64_t)c->win_bytes, counters + 1, clk, phase);
             else
-                hipLaunchKernelGGL((k_mutate_wg<false>), dim3(wg_blocks), dim3(64 * BRX_WG_WAVES), 0, st, dev, rs, order, n_reads, mctr + MC_QUEUE,
+                hipLaunchKernelGGL((k_mutate_wg<false>), dim3(wg_blocks), dim3(64 * BRX_WG_WAVES), 0, st, dev, rs, msv, order, n_reads, mctr + MC_QUEUE,
                                    req_legacy, legacy_ctr, Fbuf, repl, winbuf, pack_tb, win, (uint64_t)c->win_bytes, counters + 1, clk, phase);
         }
         c->mutate_passes = 1;
@@ -661,7 +681,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
         }
         launch_run(s_head, n_mh, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, req_legacy_head,
-                   mctr + 5 * MC_WORDS, win_head);
+                   mctr + 5 * MC_WORDS, win_head, pack_head);
         if (n_mb) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
         c->mutate_passes = 1;
     }
@@ -695,7 +715,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
                     HIPCHK(c, hipStreamSynchronize(st));
                     for (uint32_t x : h_act) if (x < n_reads) tail_bases += h_rs[x].n;
                 }
-                launch_run(st, n_up, act_in, n_in, act_out, ctr, req_legacy, legacy_ctr, win);
+                launch_run(st, n_up, act_in, n_in, act_out, ctr, req_legacy, legacy_ctr, win, pack_tb);
                 rc2 = read_counts(ctr);
                 if (rc2) return rc2;
                 n_up = h_ctr[MC_OUT];                   /* 0 unless a window overflowed its slot (then: legacy list) */

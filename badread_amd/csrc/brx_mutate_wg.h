@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t wave_park_planes(const brx_error_model &em, 
 }
 
 template <bool PROFILE = false>
-__global__ void __launch_bounds__(64 * BRX_WG_WAVES, 4) k_mutate_wg(BrxDev d, RS *rs, const uint32_t *list, uint32_t n_list, uint32_t *queue,
+__global__ void __launch_bounds__(64 * BRX_WG_WAVES, 4) k_mutate_wg(BrxDev d, RS *rs, MS *msv, const uint32_t *list, uint32_t n_list, uint32_t *queue,
                                                                    uint32_t *legacy_list, uint32_t *legacy_ctr,
                                                                    const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf,
                                                                    uint2 *pack_tb, uint8_t *scr_base, uint64_t scr_bytes,
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(64 * BRX_WG_WAVES, 4) k_mutate_wg(BrxDev d, RS
                 r = list[qi];
                 s = rs[r];
                 if (s.n == 0) continue;
-                memset(&ms, 0, sizeof(ms));
+                ms = msv[r];                  /* zero for a fresh read; a read parked by the pass pipeline resumes (phase 1) */
                 have = true;
                 read = d.first_read + r; n = s.n;
                 F = Fbuf + s.F_off; rp = repl + s.F_off;
@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(64 * BRX_WG_WAVES, 4) k_mutate_wg(BrxDev d, RS
                 o->status = s.status | ms.status; o->m = m; o->ub = cost; o->start_trim = st; o->end_trim = et;
                 o->loops = (uint32_t)loops; o->changes = change; o->naligns = nalign;
                 o->units = 0;                                          /* sized by k_fin_join */
+                msv[r].phase = 2u;
                 uint64_t *ck = clk + (uint64_t)r * 8;
                 ck[0] += __builtin_amdgcn_s_memtime() - t_begin; ck[1] = nalign;
             }

@@ -80,6 +80,8 @@ ROUTES = [
     {'BRX_TAIL_READS': 6, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_FIN_HEAD_READS': 9},   # passes with packed windows, a 6-read in-place tail, final stage in two sets
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},         # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
+    {'BRX_RUN_WG': 0},                                                           # run-to-completion launches as k_mutate_seg<true> (every read aligns its own windows)
+    {'BRX_RUN_WG': 0, 'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},
     # the one-launch mutate stage (BRX_MUTATE_WG=1: workgroups of 8 reads, packed window alignments)
     {'BRX_MUTATE_WG': 1},
     {'BRX_MUTATE_WG': 1, 'BRX_HEAD_READS': 9, 'BRX_TB_WINDOW': -1},              # final stage split into a head and a bulk set, retry phase

@@ -351,20 +351,79 @@ def make_build_fragment():
 
 
 # ---------------------------------------------------------------------------------------------
-class ReplayErrorModel(object):
-    """add_errors_to_kmer scripted by the current iteration's Philox words (w2 picks the
-    alternative, w3 drives add_one_random_change), decided by the oracle's table walk."""
+class ScriptedErrorModelDraws(object):
+    """The REFERENCE's own ErrorModel.add_errors_to_kmer / add_one_random_change (error_model.py:135-176) run unmodified;
+    only the primitives of Python's `random` module they reach are scripted from the current iteration's Philox words:
+      random.choices(alts, weights=probs)   -> CPython's own algorithm (cumulative float weights + bisect) with its uniform
+                                               replaced by (w2 + 0.5) / 2^32
+      random.choice(['s', 'i', 'd'])        -> w3 % 3
+      random.randint(0, k - 1)              -> (w3 // 3) % k
+      random.random() in random_chance(.5)  -> below 0.5 iff bit 0 of w3 // (3k) (insertion AFTER the base)
+      random.randint(0, 3) in get_random_base (directly, or inside get_random_different_base's rejection loop)
+                                            -> insertion: bits 1-2 of w3 // (3k); substitution: the base the oracle's
+                                               rule names ((o + 1 + rest % 3) & 3, or rest & 3 for a non-ACGT original),
+                                               which the rejection loop accepts at its first draw
+    so the in-place growth of the probability lists, the `None` remainder entry, the k-mer-not-in-model
+    route and the string surgery of add_one_random_change are all executed by the reference."""
 
-    def __init__(self, engine, name, state):
-        self.engine, self.state = engine, state
-        self.type = 'random' if name == 'random' else 'model'
-        self.kmer_size = 1 if name == 'random' else 7
+    def __init__(self, state):
+        self.state = state
+        self.ctx = None
+        self.kmer = None
 
-    def add_errors_to_kmer(self, kmer):
-        codes = np.array(['ACGTN'.index(c) if c in 'ACGTN' else 5 for c in kmer], dtype=np.uint8)
-        w = self.state['w']
-        _, parts = self.engine.choose_alt(codes, w[2], w[3])
-        return [''.join('ACGTN'[c] if c < 5 else '?' for c in p) for p in parts]
+    def install(self):
+        self.saved = (random.choices, random.choice, random.random, ref_em.add_one_random_change)
+        real_rc = ref_em.add_one_random_change
+
+        def rc_wrapper(kmer):
+            self.ctx, self.kmer = 'type', kmer
+            try:
+                return real_rc(kmer)
+            finally:
+                self.ctx = None
+        random.choices, random.choice, random.random = self.choices, self.choice, self.random
+        ref_em.add_one_random_change = rc_wrapper
+
+    def remove(self):
+        random.choices, random.choice, random.random, ref_em.add_one_random_change = self.saved
+
+    def choices(self, population, weights=None, cum_weights=None, k=1):
+        import bisect
+        import itertools
+        assert k == 1 and weights is not None and self.ctx is None
+        cum = list(itertools.accumulate(weights))
+        total = cum[-1] + 0.0
+        u = (self.state['w'][2] + 0.5) / 4294967296.0
+        return [population[bisect.bisect(cum, u * total, 0, len(population) - 1)]]
+
+    def choice(self, seq):
+        assert self.ctx == 'type' and list(seq) == ['s', 'i', 'd']
+        self.kind = self.state['w'][3] % 3
+        self.ctx = 'pos'
+        return seq[self.kind]
+
+    def randint(self, a, b):
+        """The part of random.randint that belongs to the error model; returns None when the call is not ours."""
+        w3 = self.state['w'][3] if self.state['w'] else 0
+        if self.ctx == 'pos':
+            k = len(self.kmer)
+            assert (a, b) == (0, k - 1)
+            self.pos = (w3 // 3) % k
+            self.rest = w3 // (3 * k)
+            self.ctx = 'base'
+            return self.pos
+        if self.ctx == 'base':
+            assert (a, b) == (0, 3)
+            if self.kind == 0:
+                o = 'ACGT'.find(self.kmer[self.pos])
+                return ((o + 1 + self.rest % 3) & 3) if o >= 0 else (self.rest & 3)
+            assert self.kind == 1
+            return (self.rest >> 1) & 3
+        return None
+
+    def random(self):
+        assert self.ctx == 'base' and self.kind == 1
+        return 0.0 if (self.rest & 1) else 0.75
 
 
 class ReplayQScoreModel(object):
@@ -396,15 +455,29 @@ class ReplayQScoreModel(object):
             cigar = cigar[1:-1].strip('D')
 
 
+_REF_ERROR_MODELS = {}
+
+
+def reference_error_model(name):
+    """The reference's ErrorModel object (5 s per file model), loaded once per name."""
+    if name not in _REF_ERROR_MODELS:
+        _REF_ERROR_MODELS[name] = ref_em.ErrorModel(name, NULL)
+    return _REF_ERROR_MODELS[name]
+
+
 def replay_sequence_fragment(engine, em_name, qm_name, ref_qmodel, qtables, fragment, target, seed, read):
     draws = Draws(seed, read)
     state = {'w': None, 'iter': 0, 'naligns': 0, 'qpos': 0, 'pads': 0}
-    em = ReplayErrorModel(engine, em_name, state)
+    em = reference_error_model(em_name)                  # the reference's own object: add_errors_to_kmer runs unmodified
+    scripted = ScriptedErrorModelDraws(state)
     qm = ReplayQScoreModel(ref_qmodel, qtables, draws, state)
     k = em.kmer_size
     n = len(fragment) + 2 * k
 
     def fake_randint(a, b):
+        ours = scripted.randint(a, b)
+        if ours is not None:
+            return ours
         if a == 0 and b == n - 1 - k:                     # k-mer position (simulate.py:294)
             state['w'] = draws.mut(state['iter'])
             state['iter'] += 1
@@ -419,12 +492,14 @@ def replay_sequence_fragment(engine, em_name, qm_name, ref_qmodel, qtables, frag
         state['pads'] += 1
         return ''.join('ACGT'[random_base(seed, read, serial, p)] for p in range(length))
 
-    orig = (ref_sim.random.randint, ref_sim.get_random_sequence)
-    ref_sim.random.randint, ref_sim.get_random_sequence = fake_randint, fake_random_sequence
+    orig = (random.randint, ref_sim.get_random_sequence)
+    random.randint, ref_sim.get_random_sequence = fake_randint, fake_random_sequence
+    scripted.install()
     try:
         seq, qual, ident, ident_q = ref_sim.sequence_fragment(fragment, target, em, qm)
     finally:
-        ref_sim.random.randint, ref_sim.get_random_sequence = orig
+        scripted.remove()
+        random.randint, ref_sim.get_random_sequence = orig
     return {'em': em_name, 'qm': qm_name, 'fragment': fragment, 'target': target, 'seed': seed, 'read': read,
             'seq': seq, 'qual': qual, 'identity': ident, 'identity_by_qscores': ident_q,
             'iterations': state['iter'], 'alignments': state['naligns']}
@@ -499,6 +574,9 @@ if __name__ == '__main__':
     os.makedirs(GOLDEN, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == 'random_change':
         make_random_change()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'sequence_fragment':
+        make_sequence_fragment()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'qscore_top_rows':
         make_qscore_top_rows()
