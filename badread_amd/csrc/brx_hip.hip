@@ -45,7 +45,7 @@ struct brx_ctx {
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
-    int run_wg;                  /* BRX_RUN_WG (default 1): head chain and tail run as k_mutate_wg (packed identity checks) instead of k_mutate_seg<true> */
+    int run_wg;                  /* BRX_RUN_WG=1: head chain and tail run as k_mutate_wg (packed identity checks) instead of k_mutate_seg<true> (default 0: measured slower) */
     int mutate_wg;               /* BRX_MUTATE_WG=1: the mutate stage is one launch of k_mutate_wg (brx_mutate_wg.h; measured slower at batch scale); default 0 = the pass pipeline */
     uint32_t fin_head_reads;     /* BRX_FIN_HEAD_READS: the longest reads of a batch form the head set of the final stage (side streams) */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
@@ -158,7 +158,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         if ((e = hipEventCreateWithFlags(&c->ev_fork2[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
-    { const char *rw = getenv("BRX_RUN_WG"); c->run_wg = rw ? atoi(rw) : 1; }
+    { const char *rw = getenv("BRX_RUN_WG"); c->run_wg = rw ? atoi(rw) : 0; }
     { const char *mw = getenv("BRX_MUTATE_WG"); c->mutate_wg = mw ? atoi(mw) : 0; }
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
@@ -633,9 +633,12 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     }
     const uint32_t lane_threshold = c->lane_threshold;   /* fewer active reads than this: one wave per window (lower latency) */
     /* reads taken to completion in ONE launch (the head set from the start; the last BRX_TAIL_READS of the bulk set):
-       BRX_RUN_WG=1 (default) k_mutate_wg -- workgroups of 8 reads whose identity checks are aligned eight to a wave
-       (12 k wave-instructions per window) --, 0: k_mutate_seg<true>, every read aligning its own windows with a whole
-       wave (61 k per window; 53 of the batch's 195 VALU instructions per base in profiles/r02_valu_per_base.json) */
+       k_mutate_seg<true> (default), every read aligning its own windows with a whole wave (61 k wave-instructions per
+       window; 53 of the batch's 195 VALU instructions per base in profiles/r02_valu_per_base.json), or BRX_RUN_WG=1
+       k_mutate_wg -- workgroups of 8 reads whose identity checks are aligned eight to a wave (12 k per window).
+       Measured (r02i, configs[3], 8 batches in flight): seg<true> 2.04 Gbases/s, k_mutate_wg 1.71 -- a lockstep round
+       of the workgroup kernel (slowest of 8 segments + the packed alignment) takes ~1.3 M cycles against ~0.65 M for an
+       in-place cycle, and the launch is on the batch's critical path */
     auto launch_run = [&](hipStream_t s, uint32_t count, const uint32_t *act_in, const uint32_t *n_in, uint32_t *act_out, uint32_t *ctr,
                           uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr, uint2 *packscr) {
         KTIMED(BRX_KERN_MUTATE_RUN, s);

@@ -259,7 +259,7 @@ def main():
                     help='device batches in flight per GPU (one context + HIP stream + host thread each): the slowest '
                          'read of one device batch overlaps the bulk of the others')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='seconds each host core runs the cpu_baseline leg (0 = skip)')
-    ap.add_argument('--d2h', action='store_true', help='also time steps that copy the FASTQ bytes to pinned host memory')
+    ap.add_argument('--d2h', action='store_true', help='also run the same amount of work through the CLI driver (PCIe + host output stage): value_incl_d2h, value_incl_gzip')
     ap.add_argument('--ref-dir', default=default_ref_dir(), help='where the synthetic reference FASTA and its packed sidecar live')
     ap.add_argument('--ref-scale', type=float, default=1.0, help='shrink the GRCh38-like reference (tests, dry runs); 1.0 = the metric\'s 3.09 Gb')
     ap.add_argument('--cpu-engine', action='store_true',
@@ -401,18 +401,34 @@ def main():
         elapsed, bases, bad = float(tmax[0].item()), float(t[1].item()), float(t[2].item())
     value = bases / elapsed
 
+    # ---- --d2h: the SAME amount of work through the CLI's own driver (badread_amd.simulate.run_batches: stop rule,
+    # pinned ring, writer thread), FASTQ text to /dev/null and through the multi-threaded gzip stage ----
     d2h = None
     if args.d2h and rank == 0 and not dry:
-        host = torch.empty(R * 40000, dtype=torch.uint8).pin_memory()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        b2 = 0
-        for k in range(args.steps):
-            out, stats = engines[0].simulate_batch_device(SEED, ((args.warmup + k) * world + rank) * R, R, expected_bytes=R * 36000)
-            host[:out.numel()].copy_(out, non_blocking=False)
-            b2 += int(stats['seq_len'].sum())
-        torch.cuda.synchronize()
-        d2h = b2 / (time.perf_counter() - t1)
+        from badread_amd.simulate import run_batches
+        from badread_amd.output import GzipSink
+        first = engines[0]
+        for e in engines[1:]:
+            e.close()
+        del engines[1:]
+        torch.cuda.empty_cache()
+        target = int(sum(a['bases'] for a in acc))           # what this rank simulated in the timed region
+        d2h = {}
+        for name, level in (('devnull', None), ('gzip1', 1)):
+            raw = open(os.devnull, 'wb')
+            sink = raw if level is None else GzipSink(raw, level)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            count, total = run_batches(first, SEED, target, 15000.0, lambda part: sink.write(memoryview(part)), io.StringIO(),
+                                       max_batch=R, in_flight=C)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            d2h[name] = {'bases_per_s': total / dt, 'reads': count, 'bases': total, 'seconds': dt,
+                         'fastq_bytes_per_s': (getattr(sink, 'bytes_in', 0) or 2.02 * total) / dt}
+            if level is not None:
+                d2h[name]['compressed_bytes'] = sink.bytes_out
+            raw.close()
+        engines[:] = [first]
 
     if rank != 0:
         if dist is not None:
@@ -488,7 +504,11 @@ def main():
     result['mutate_passes_per_device_batch'] = sum(a['passes'] for a in acc) / n_batches
     result['traceback_window_misses_per_step'] = sum(a['misses'] for a in acc) / args.steps
     if d2h is not None:
-        result['value_incl_d2h'] = d2h
+        result['value_incl_d2h'] = d2h['devnull']['bases_per_s']
+        result['value_incl_gzip'] = d2h['gzip1']['bases_per_s']
+        result['driver_end_to_end'] = dict(d2h, note='badread_amd.simulate.run_batches (the CLI driver: stop rule, D2H through a ring of pinned '
+                                                      'buffers, writer thread) over the same number of bases, FASTQ to /dev/null and through '
+                                                      '--gzip 1 on all host cores; includes the start-up of its engine clones')
     if world == 1 and args.cpu_seconds > 0:
         result['cpu_baseline'] = cpu_baseline(10_000_000, args.cpu_seconds, args.workload, args.ref_dir)
         result['gpu_over_cpu'] = value / result['cpu_baseline']['value']

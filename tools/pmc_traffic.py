@@ -1,6 +1,6 @@
 """profiles/pmc_traffic.json (what bench.py reports as roofline.traffic) from a per-kernel PMC summary:
 
-    python tools/pmc_traffic.py <pmc_per_kernel.csv> <reads_per_step> [kernel] > profiles/pmc_traffic.json
+    python tools/pmc_traffic.py <pmc_per_kernel.csv> <reads_per_step> [rocprof kernel name] [workload] [bench.py kernel label] > profiles/pmc_traffic.json
 
 FETCH_SIZE and WRITE_SIZE (KB) come from separate rocprofv3 passes (tools/profile_round.sh).  Per
 MI355X_MICROARCH.md (HBM section) gfx950's FETCH_SIZE tallies 128-byte requests as 64 bytes, so it is doubled;
@@ -14,13 +14,15 @@ import sys
 def main():
     path, reads = sys.argv[1], int(sys.argv[2])
     kernel = sys.argv[3] if len(sys.argv) > 3 else 'k_fin_align<1, 1, 1>'
+    workload = sys.argv[4] if len(sys.argv) > 4 else 'kpn'
+    label = sys.argv[5] if len(sys.argv) > 5 else kernel.replace(' ', '')
     vals = {}
     for row in csv.DictReader(open(path)):
         if row['kernel'].replace(' ', '') == kernel.replace(' ', '') and row['counter'] in ('FETCH_SIZE', 'WRITE_SIZE'):
             vals[row['counter']] = (float(row.get('mean') or row.get('mean_value_KB')), int(row['dispatches']))
     fetch, nf = vals['FETCH_SIZE']
     write, nw = vals['WRITE_SIZE']
-    json.dump({'kernel': kernel.replace(' ', ''), 'reads_per_step': reads,
+    json.dump({'kernel': label, 'rocprof_name': kernel, 'workload': workload, 'reads_per_step': reads,
                'FETCH_SIZE_KB_per_launch': fetch, 'WRITE_SIZE_KB_per_launch': write,
                'hbm_bytes_per_launch': (2.0 * fetch + write) * 1024.0,
                'note': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 2 --warmup 1 '
