@@ -300,6 +300,7 @@ class HipEngine(EngineBase):
         if getattr(self, 'ctx', None):
             self.lib.brx_destroy(self.ctx)
             self.ctx = None
+        self._scratch = self._out = self._stats = None       # give the arena back to the allocator now, not at garbage collection
 
     def __del__(self):
         try:

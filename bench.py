@@ -411,6 +411,8 @@ def main():
         for e in engines[1:]:
             e.close()
         del engines[1:]
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
         target = int(sum(a['bases'] for a in acc))           # what this rank simulated in the timed region
         d2h = {}
