@@ -75,7 +75,7 @@ SIMULATE_OPTIONS = [
                         help='Write gzip-compressed FASTQ to stdout, compressed on all host cores (level 0-9); '
                              'default: plain text, as the reference')),
         ('--gpu-streams', dict(type=int, default=None, dest='gpu_streams',
-                               help='Device batches in flight per GPU, each on its own HIP stream (default: 4)')),
+                               help='Device batches in flight per GPU, each on its own HIP stream (default: 8)')),
     ]),
 ]
 
