@@ -435,19 +435,25 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
 
     pending = collections.deque()          # (slot, future, first_of_super_batch, n_super, first, n_mine)
     fatal = bad_read = None
+
+    def fill():
+        """Keep the pipeline full: what is outstanding is assumed to deliver its expected number of bases.  Called at
+        points that depend only on consumed totals, so every rank issues the same batches."""
+        nonlocal next_read
+        while len(pending) < len(pool) and pool.free:
+            outstanding = sum(p[3] for p in pending) * expected_mean
+            remaining = target_size - total - outstanding
+            if remaining <= 0 and pending:
+                break
+            n_super = plan_batch(max(remaining, 1), expected_mean, shard.world, max_batch)
+            first, n_mine = shard.slice_of(next_read, n_super)
+            slot, fut = pool.submit(seed, first, n_mine)
+            pending.append((slot, fut, next_read, n_super, first, n_mine))
+            next_read += n_super
+
     try:
         while total < target_size:
-            # keep the pipeline full: what is outstanding is assumed to deliver its expected number of bases
-            while len(pending) < len(pool):
-                outstanding = sum(p[3] for p in pending) * expected_mean
-                remaining = target_size - total - outstanding
-                if remaining <= 0 and pending:
-                    break
-                n_super = plan_batch(max(remaining, 1), expected_mean, shard.world, max_batch)
-                first, n_mine = shard.slice_of(next_read, n_super)
-                slot, fut = pool.submit(seed, first, n_mine)
-                pending.append((slot, fut, next_read, n_super, first, n_mine))
-                next_read += n_super
+            fill()
             slot, fut, base, n_super, first, n_mine = pending.popleft()
             out, stats = fut.result()
             # ---- the 4 B/read exchange: length (0 for skipped reads) | NOFRAG << 31 | BAD << 30 ----
@@ -476,18 +482,25 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             if shard.world > 1:
                 sizes = [int(x[0]) for x in shard.gather_words(np.array([my_bytes], dtype=np.uint32), [1] * shard.world)]
                 assert my_bytes < 2 ** 32
-            for _, part in shard.collect_bytes(out, sizes, staging):
-                ring.write(part)                    # rank 0: through pinned memory to the writer thread
+            # the engine goes back to work at once: its kept bytes are copied device-to-device first (0.5 GB at HBM speed),
+            # the slower hops (PCIe into the pinned ring, or the send to rank 0) read that copy
+            if pool.on_gpu and my_bytes:
+                out = out[:my_bytes].clone()
             pool.release(slot)                      # the engine's output buffer may be overwritten from here on
             used = lens[:last + 1]
             count += int((used > 0).sum())
             total += int(used.sum())
+            stop = fatal or bad_read is not None
+            if count and not stop:
+                expected_mean = max(total / count, 1.0)
+            if not stop and total < target_size:
+                fill()                              # the freed engine starts its next batch while this one's bytes leave
+            for _, part in shard.collect_bytes(out, sizes, staging):
+                ring.write(part)                    # rank 0: through pinned memory to the writer thread
             if shard.rank == 0:
                 print_progress(count, total, target_size, output)
-            if fatal or bad_read is not None:
+            if stop:
                 break
-            if count:
-                expected_mean = max(total / count, 1.0)
     finally:
         for slot, fut, *_ in pending:       # speculative batches past the stopping read
             try:
