@@ -3,8 +3,8 @@
 
 Flags, defaults, derived fields, validation messages and exit codes follow the reference CLI
 (/root/reference/badread/__main__.py:83-147 flags, :239-336 checks) so that existing command lines and
-scripts keep working; the offline tools of the reference (error_model, qscore_model, plot) are outside
-this build's scope and are refused with a message.  Additive options:
+scripts keep working.  `error_model` and `qscore_model` (the model builders) run their counting
+loops on the GPU (badread_amd/model_builder.py); `plot` is outside this build's scope and refused with a message.  Additive options:
 --gpu-batch (reads per device batch).  Multi-GPU: launch with
 `python -m torch.distributed.run --nproc-per-node N -m badread_amd simulate ...`; rank 0 writes stdout.
 """
@@ -24,7 +24,7 @@ from .version import __version__
 
 ERROR_MODEL_NAMES = ['random', 'nanopore2018', 'nanopore2020', 'nanopore2023', 'pacbio2016', 'pacbio2021']
 QSCORE_MODEL_NAMES = ['random', 'ideal', 'nanopore2018', 'nanopore2020', 'nanopore2023', 'pacbio2016', 'pacbio2021']
-OUT_OF_SCOPE = ('error_model', 'qscore_model', 'plot')
+OUT_OF_SCOPE = ('plot',)
 
 # (group title, group description, [(flag, kwargs), ...]) -- help texts as in the reference
 SIMULATE_OPTIONS = [
@@ -106,6 +106,30 @@ def parse_args(argv):
         for flag, kwargs in options:
             group.add_argument(flag, **kwargs)
     _add_help_group(sim)
+    # the model builders: flags and defaults of the reference (__main__.py:150-205)
+    em = subparsers.add_parser('error_model', description='Build a Badread error model', add_help=False)
+    qm = subparsers.add_parser('qscore_model', description='Build a Badread qscore model', add_help=False)
+    for sub in (em, qm):
+        req = sub.add_argument_group('Required arguments')
+        req.add_argument('--reference', type=str, required=True, help='Reference FASTA file')
+        req.add_argument('--reads', type=str, required=True, help='FASTQ of real reads')
+        req.add_argument('--alignment', type=str, required=True, help='PAF alignment of reads aligned to reference')
+    opt = em.add_argument_group('Optional arguments')
+    opt.add_argument('--k_size', type=int, default=7, help='Error model k-mer size')
+    opt.add_argument('--max_alignments', type=int, help='Only use this many alignments when generating error model '
+                                                        '(default: use all alignments)')
+    opt.add_argument('--max_alt', type=int, default=25, help='Only save up to this many alternatives to each k-mer')
+    opt = qm.add_argument_group('Optional arguments')
+    opt.add_argument('--k_size', type=int, default=9, help='Qscore model k-mer size (must be odd, default: %(default)s)')
+    opt.add_argument('--max_alignments', type=int, help='Only use this many alignments when generating qscore model '
+                                                        '(default: use all alignments)')
+    opt.add_argument('--max_del', type=int, default=6, help='Deletion runs longer than this will be collapsed to reduce '
+                                                            'the number of possible alignments')
+    opt.add_argument('--min_occur', type=int, default=100, help='CIGARs which occur less than this many times will not be '
+                                                                'included in the model')
+    opt.add_argument('--max_output', type=int, default=10000, help='The outputted model will be limited to this many lines')
+    _add_help_group(em)
+    _add_help_group(qm)
     for name in OUT_OF_SCOPE:
         sub = subparsers.add_parser(name, add_help=False, description=f'{name}: not part of the MI355X build')
         sub.add_argument('rest', nargs=argparse.REMAINDER)
@@ -213,6 +237,12 @@ def main(output=sys.stderr):
         if args.gpu_batch:
             sim.DEFAULT_MAX_BATCH = int(args.gpu_batch)
         sim.simulate(args, output=output)
+    elif args.subparser_name == 'error_model':
+        from .model_builder import make_error_model
+        make_error_model(args, output=output)
+    elif args.subparser_name == 'qscore_model':
+        from .model_builder import make_qscore_model
+        make_qscore_model(args, output=output)
     elif args.subparser_name in OUT_OF_SCOPE:
         sys.exit(f'Error: the {args.subparser_name} command is not part of the MI355X simulate build; '
                  f'use the reference Badread for it')

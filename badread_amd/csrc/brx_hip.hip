@@ -950,3 +950,26 @@ extern "C" int brx_align_batch(brx_ctx *c, uint32_t n_pairs, const uint8_t *d_qu
     DBG("align_batch: done");
     return BRX_OK;
 }
+
+/* f4: the counting loops of the model builders (brx_model.h).  The job struct of the ABI has the layout of BrxMbJob. */
+static_assert(sizeof(brx_model_job) == sizeof(BrxMbJob), "brx_model_job and BrxMbJob must have the same layout");
+extern "C" int brx_model_count(brx_ctx *c, int kind, const brx_model_job *job, void *hip_stream) {
+    if (!c || !job || (kind != 0 && kind != 1)) return BRX_E_ARG;
+    if (job->n_align == 0 || job->n_cols == 0) return BRX_OK;
+    if (kind == 0 && (job->k < 2 || 2 * job->k + 5 + 2 * BRX_MB_MAX_READ_KMER > 64)) return fail(c, BRX_E_ARG, "error model k-mer size %u not supported (2..8)", job->k);
+    if (kind == 1 && (job->n_ksizes < 1 || job->n_ksizes > 16 || job->max_del > 15)) return fail(c, BRX_E_ARG, "qscore model: k_size up to 31, max_del up to 15");
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIPCHK(c, hipSetDevice(c->device));
+    BrxMbJob j;
+    memcpy(&j, job, sizeof(j));
+    const uint64_t nb = (job->n_cols + 255) / 256;
+    hipLaunchKernelGGL(k_mb_expand, dim3((unsigned)nb), dim3(256), 0, st, j);
+    if (kind == 0) hipLaunchKernelGGL(k_mb_error, dim3((unsigned)nb), dim3(256), 0, st, j);
+    else hipLaunchKernelGGL(k_mb_qscore, dim3((unsigned)((job->n_cols * job->n_ksizes + 255) / 256)), dim3(256), 0, st, j);
+    uint32_t flags[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(flags, job->d_flags, sizeof(flags), hipMemcpyDeviceToHost, st));
+    { int rcw = wait_stream(c, st, "model builder"); if (rcw) return rcw; }
+    HIPCHK(c, hipGetLastError());
+    if (flags[0] & 1u) return fail(c, BRX_E_OUTPUT, "model builder: hash table full");
+    return BRX_OK;
+}

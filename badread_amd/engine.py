@@ -85,6 +85,20 @@ KERNEL_NAMES = ('k_plan_*', 'k_build', 'k_mutate_seg<false>', 'k_mutate_seg<true
                 'k_emit+k_recsize')
 
 
+class BrxModelJob(ctypes.Structure):
+    """brx_model_job of include/brx.h"""
+    _fields_ = [('n_align', ctypes.c_uint32), ('k', ctypes.c_uint32), ('max_del', ctypes.c_uint32), ('n_ksizes', ctypes.c_uint32),
+                ('n_cols', ctypes.c_uint64),
+                ('d_seq', ctypes.c_void_p), ('d_qual', ctypes.c_void_p), ('d_ref', ctypes.c_void_p),
+                ('d_part_type', ctypes.c_void_p), ('d_part_len', ctypes.c_void_p),
+                ('d_part_col', ctypes.c_void_p), ('d_part_read', ctypes.c_void_p), ('d_part_ref', ctypes.c_void_p),
+                ('d_align_part_off', ctypes.c_void_p), ('d_align_col_off', ctypes.c_void_p),
+                ('d_rcol', ctypes.c_void_p), ('d_qcol', ctypes.c_void_p), ('d_fcol', ctypes.c_void_p),
+                ('d_keys', ctypes.c_void_p), ('d_counts', ctypes.c_void_p), ('d_first', ctypes.c_void_p),
+                ('table_mask', ctypes.c_uint64), ('d_flags', ctypes.c_void_p),
+                ('d_spill', ctypes.c_void_p), ('spill_cap', ctypes.c_uint32)]
+
+
 class BrxKernelStat(ctypes.Structure):
     _fields_ = [('launches', ctypes.c_uint32), ('ms', ctypes.c_float), ('bases', ctypes.c_double)]
 
@@ -258,6 +272,8 @@ def bind_library(lib):
     lib.brx_set_kernel_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.brx_last_kernel_stats.restype = ctypes.c_int
     lib.brx_last_kernel_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(BrxKernelStat * len(KERNEL_NAMES))]
+    lib.brx_model_count.restype = ctypes.c_int
+    lib.brx_model_count.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(BrxModelJob), ctypes.c_void_p]
     lib.brx_last_mutate_passes.restype = ctypes.c_uint32
     lib.brx_last_mutate_passes.argtypes = [ctypes.c_void_p]
     lib.brx_last_final_launches.restype = ctypes.c_uint32
@@ -476,6 +492,46 @@ class HipEngine(EngineBase):
             raw = d_ops.cpu().numpy()
             ops_list = [raw[int(ops_off[i]):int(ops_off[i]) + int(ncols[i])].copy() for i in range(n)]
         return ops_list, dist, ncols, nmatch
+
+    def model_count(self, kind, job, k, max_del, n_ksizes, table_bits, spill_cap=1 << 16):
+        """brx_model_count over a model_builder.Job: (keys, counts, earliest ranks) of the occupied table slots and the
+        spilled windows, or None when a table of 2^table_bits slots was too small."""
+        torch = self.torch
+        keep = []
+
+        def up(arr):
+            ptr, t = self._upload(arr)
+            keep.append(t)
+            return ptr
+        size = 1 << table_bits
+        dev = self.device
+        keys = torch.full((size,), -1, dtype=torch.int64, device=dev)
+        counts = torch.zeros(size, dtype=torch.int32, device=dev)
+        first = torch.full((size,), -1, dtype=torch.int64, device=dev)
+        flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        spill = torch.zeros(spill_cap, dtype=torch.int64, device=dev)
+        cols = [torch.empty(max(job.n_cols, 1), dtype=torch.uint8, device=dev) for _ in range(3)]
+        s = BrxModelJob()
+        s.n_align, s.k, s.max_del, s.n_ksizes, s.n_cols = job.n_align, k, max_del, n_ksizes, job.n_cols
+        s.d_seq, s.d_qual, s.d_ref = up(job.seq), up(job.qual), up(job.ref)
+        s.d_part_type, s.d_part_len = up(job.part_type), up(job.part_len)
+        s.d_part_col, s.d_part_read, s.d_part_ref = up(job.part_col), up(job.part_read), up(job.part_ref)
+        s.d_align_part_off, s.d_align_col_off = up(job.align_part_off), up(job.align_col_off)
+        s.d_rcol, s.d_qcol, s.d_fcol = (c.data_ptr() for c in cols)
+        s.d_keys, s.d_counts, s.d_first = keys.data_ptr(), counts.data_ptr(), first.data_ptr()
+        s.table_mask, s.d_flags, s.d_spill, s.spill_cap = size - 1, flags.data_ptr(), spill.data_ptr(), spill_cap
+        rc = self.lib.brx_model_count(self.ctx, kind, ctypes.byref(s), self._stream())
+        if rc == E_OUTPUT:
+            return None
+        self._check(rc)
+        h_flags = flags.cpu().numpy()
+        n_spill = int(h_flags[1 + kind])
+        if n_spill > spill_cap:
+            return self.model_count(kind, job, k, max_del, n_ksizes, table_bits, spill_cap=2 * n_spill)
+        h_keys = keys.cpu().numpy().view(np.uint64)
+        used = h_keys != np.uint64(0xFFFFFFFFFFFFFFFF)
+        return (h_keys[used], counts.cpu().numpy()[used].astype(np.int64), first.cpu().numpy().view(np.uint64)[used],
+                spill[:n_spill].cpu().numpy().view(np.uint64))
 
     def stage_ms(self):
         arr = (ctypes.c_float * 8)()

@@ -99,6 +99,29 @@ def load_fasta(filename):
 RANDOM_SEQ_DICT = {0: 'A', 1: 'C', 2: 'G', 3: 'T'}
 
 
+def load_fastq(filename, output=sys.stderr, dot_interval=1000):
+    """{name: (sequence upper-cased, qualities)} like the reference's loader (misc.py:97-119): header lines are the
+    lines that start with '@', the three lines after a header are taken unseen."""
+    if get_sequence_file_type(filename) != 'FASTQ':
+        sys.exit('Error: {} is not FASTQ format'.format(filename))
+    reads = {}
+    print('Loading reads', end='', file=output, flush=True)
+    with get_open_func(filename)(filename, 'rb') as fastq:
+        for line in fastq:
+            stripped = line.strip()
+            if not stripped.startswith(b'@'):
+                continue
+            name = stripped[1:].split()[0]
+            sequence = next(fastq).strip().upper()
+            next(fastq)
+            qualities = next(fastq).strip()
+            reads[name.decode()] = (sequence.decode(), qualities.decode())
+            if len(reads) % dot_interval == 0:
+                print('.', end='', file=output, flush=True)
+    print('', file=output, flush=True)
+    return reads
+
+
 def get_random_base():
     return 'ACGT'[random.randint(0, 3)]
 

@@ -283,6 +283,40 @@ uint32_t brx_last_final_launches(const brx_ctx *ctx);
  * sqrt(edit bound) units, default 2, 0 = always the full store).  Results do not depend on it. */
 uint32_t brx_last_window_misses(const brx_ctx *ctx);
 
+/* ------------------------------------------------------------------ model builders
+ * The counting loops of make_error_model (error_model.py:31-83) and make_qscore_model (qscore_model.py:78-162) over a set
+ * of read-to-reference alignments.  The host parses FASTA / FASTQ / PAF exactly as the reference does and ships, as device
+ * arrays: the aligned slices of the reads and their qualities, the reference slices (reverse-complemented for '-' strand
+ * alignments), and the CIGAR parts ('M' 0, 'I' 1, 'D' 2; reversed for '-' strand, alignment.py:61-64) with the prefix sums
+ * of their column / read / reference offsets.  brx_model_count expands the CIGARs into the gapped column arrays
+ * (alignment.py:101-132) and counts every sliding window into the caller's hash table (keys preset to ~0, counts to 0,
+ * first to ~0):
+ *   kind 0, error model:   key = ref k-mer (2k bits, first base most significant) | read k-mer length << 2k
+ *                                | read k-mer (2 bits per base, first base least significant) << (2k + 5)
+ *   kind 1, qscore model:  key = quality of the middle base (7 bits) | window size index (k_size - 1) / 2 << 7
+ *                                | ops << 11, ops = 2 bits per read base (0 '=', 1 'X', 2 'I'), each but the first
+ *                                preceded by 4 bits holding the (collapsed) length of the deletion run before it
+ *   first[slot] = the earliest (alignment, [size index,] window start) that produced the key: Python dictionaries and its
+ *   stable sort order equal counts by first insertion.
+ * Windows a key cannot hold (error model: a read k-mer of more than 21 bases; qscore model: more than 52 key bits, a
+ * window opening with deletion columns) are appended to `spill` as (alignment << 32 | start column) for the host to count.
+ * Returns BRX_E_OUTPUT when the table is full.                                                                        */
+typedef struct {
+    uint32_t n_align, k, max_del, n_ksizes;
+    uint64_t n_cols;
+    const uint8_t *d_seq, *d_qual, *d_ref;
+    const uint8_t *d_part_type;
+    const uint32_t *d_part_len;
+    const uint64_t *d_part_col, *d_part_read, *d_part_ref;
+    const uint64_t *d_align_part_off, *d_align_col_off;
+    uint8_t *d_rcol, *d_qcol, *d_fcol;
+    uint64_t *d_keys; uint32_t *d_counts; uint64_t *d_first;
+    uint64_t table_mask;
+    uint32_t *d_flags;                 /* [4], preset to 0: [0] table full, [1] / [2] spilled windows of kind 0 / 1 */
+    uint64_t *d_spill; uint32_t spill_cap;
+} brx_model_job;
+int brx_model_count(brx_ctx *ctx, int kind, const brx_model_job *job, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -246,6 +246,8 @@ inline int readfirstlane(int v) {
 #define __builtin_amdgcn_s_memtime() (++emu::S().clock)
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(ptr, val, order, scope) (*(ptr) = (val))
+#define __HIP_MEMORY_SCOPE_AGENT 1
+#define __hip_atomic_load(ptr, order, scope) (*(ptr))
 
 /* ---- scalar helpers ------------------------------------------------------------------------------------- */
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
@@ -256,6 +258,7 @@ static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 template <class T, class U> static inline T atomicAdd(T *p, U v) { T old = *p; *p = (T)(old + (T)v); return old; }
 template <class T, class U> static inline T atomicOr(T *p, U v) { T old = *p; *p = (T)(old | (T)v); return old; }
+template <class T, class U, class V> static inline T atomicCAS(T *p, U expected, V desired) { T old = *p; if (old == (T)expected) *p = (T)desired; return old; }
 template <class T, class U> static inline T atomicMin(T *p, U v) { T old = *p; if ((T)v < old) *p = (T)v; return old; }
 template <class T, class U> static inline T atomicMax(T *p, U v) { T old = *p; if ((T)v > old) *p = (T)v; return old; }
 

@@ -570,8 +570,108 @@ def make_qscore_top_rows():
     dump('qscore_top_rows.json', out)
 
 
+MODEL_BUILDER_CASES = {
+    'error': [dict(k_size=7, max_alignments=None, max_alt=25), dict(k_size=4, max_alignments=None, max_alt=3),
+              dict(k_size=5, max_alignments=10, max_alt=25)],
+    'qscore': [dict(k_size=9, max_alignments=None, max_del=6, min_occur=1, max_output=10000),
+               dict(k_size=9, max_alignments=None, max_del=6, min_occur=100, max_output=10000),
+               dict(k_size=5, max_alignments=None, max_del=2, min_occur=2, max_output=20),
+               dict(k_size=3, max_alignments=7, max_del=6, min_occur=1, max_output=10000)],
+}
+
+
+def make_model_builders():
+    """Inputs for the model builders (row f4) made HERE -- a random two-contig reference, 48 reads cut from it and
+    mutated (substitutions, insertions and deletions of 1-30 bases, both strands, clipped ends, random qualities), their
+    alignments from the oracle aligner written as PAF with cg:Z: CIGARs, plus decoy lines the loader must drop -- and the
+    output of the REFERENCE's own make_error_model / make_qscore_model on them for several argument sets."""
+    import contextlib
+    import types
+    rng = np.random.default_rng(404)
+    folder = os.path.join(GOLDEN, 'model_builder')
+    os.makedirs(folder, exist_ok=True)
+    dna = lambda n: ''.join(np.array(list('ACGT'))[rng.integers(0, 4, n)])
+    refs = collections.OrderedDict([('ctg_one', dna(12000)), ('ctg_two', dna(6000))])
+    refs['ctg_two'] = refs['ctg_two'][:3000] + 'NNNNRY' + refs['ctg_two'][3006:]
+    with open(os.path.join(folder, 'ref.fasta'), 'w') as f:
+        for name, seq in refs.items():
+            f.write(f'>{name} some description\n')
+            for i in range(0, len(seq), 70):
+                f.write(seq[i:i + 70] + '\n')
+    reads, paf = [], []
+    for r in range(48):
+        name = f'read_{r}'
+        ctg = 'ctg_one' if r % 3 else 'ctg_two'
+        L = int(rng.integers(150, 2600))
+        start = int(rng.integers(0, len(refs[ctg]) - L))
+        piece = refs[ctg][start:start + L]
+        rate = float(rng.choice([0.02, 0.05, 0.10, 0.17]))
+        out = []
+        for ch in piece:
+            u = rng.random()
+            if u < rate / 3:
+                out.append('ACGT'[rng.integers(0, 4)])
+            elif u < 2 * rate / 3:
+                out.append(ch + dna(int(rng.choice([1, 1, 1, 2, 3, 30]))))
+            elif u < rate:
+                continue
+            else:
+                out.append(ch)
+        mutated = ''.join(out)
+        if r % 7 == 0:                                   # one long deletion, longer than any --max_del
+            cut = len(mutated) // 2
+            mutated = mutated[:cut] + mutated[cut + int(rng.integers(7, 20)):]
+        strand = '+' if rng.random() < 0.5 else '-'
+        d, ops = pyoracle.align(mutated.encode(), piece.encode())
+        runs, cigar = [], []
+        for op in ops.tolist():
+            letter = 'M' if op in (0, 1) else 'I' if op == 2 else 'D'
+            if runs and runs[-1][1] == letter:
+                runs[-1][0] += 1
+            else:
+                runs.append([1, letter])
+        cigar = ''.join(f'{n}{t}' for n, t in runs)
+        clip5, clip3 = (int(rng.integers(0, 30)), int(rng.integers(0, 30))) if r % 4 == 0 else (0, 0)
+        read_fwd = dna(clip5) + mutated + dna(clip3)
+        read_seq = read_fwd if strand == '+' else ref_misc.reverse_complement(read_fwd)
+        rs, re_ = (clip5, clip5 + len(mutated)) if strand == '+' else (clip3, clip3 + len(mutated))
+        qual = ''.join(chr(33 + int(q)) for q in rng.integers(1, 51, len(read_seq)))
+        if r % 11 == 0:
+            read_seq = read_seq.lower()                  # the loader upper-cases
+        reads.append((name, read_seq, qual))
+        matches = int((ops == 0).sum())
+        line = [name, str(len(read_seq)), str(rs), str(re_), strand, ctg, str(len(refs[ctg])), str(start), str(start + L),
+                str(matches), str(len(ops)), '60', f'NM:i:{d}', f'AS:i:{2 * matches - 4 * d}', f'cg:Z:{cigar}']
+        paf.append('\t'.join(line))
+        if r % 5 == 0:                                   # a second, worse alignment of the same read: dropped
+            paf.append('\t'.join(line[:13] + [f'AS:i:{2 * matches - 4 * d - 50}', 'cg:Z:' + f'{re_ - rs}M']))
+    paf.append('\t'.join(['read_short', '90', '0', '90', '+', 'ctg_one', '12000', '10', '100', '90', '90', '60', 'AS:i:180', 'cg:Z:90M']))
+    paf.append('\t'.join(['read_bad', '400', '0', '400', '+', 'ctg_one', '12000', '500', '900', '250', '400', '60', 'AS:i:100', 'cg:Z:400M']))
+    reads.append(('read_short', dna(90), 'I' * 90))
+    reads.append(('read_bad', dna(400), 'I' * 400))
+    with open(os.path.join(folder, 'reads.fastq'), 'w') as f:
+        for name, seq, qual in reads:
+            f.write(f'@{name} extra words\n{seq}\n+\n{qual}\n')
+    with open(os.path.join(folder, 'aln.paf'), 'w') as f:
+        f.write('\n'.join(paf) + '\n')
+    out = {'error': [], 'qscore': []}
+    for kind, fn in (('error', ref_em.make_error_model), ('qscore', ref_qm.make_qscore_model)):
+        for case in MODEL_BUILDER_CASES[kind]:
+            args = types.SimpleNamespace(reference=os.path.join(folder, 'ref.fasta'), reads=os.path.join(folder, 'reads.fastq'),
+                                         alignment=os.path.join(folder, 'aln.paf'), **case)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                fn(args, output=io.StringIO())
+            out[kind].append({'args': case, 'text': buf.getvalue()})
+            print(f'  model builder {kind} {case}: {len(buf.getvalue())} characters, {buf.getvalue().count(chr(10))} lines')
+    dump('model_builder.json.gz', out)
+
+
 if __name__ == '__main__':
     os.makedirs(GOLDEN, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'model_builders':
+        make_model_builders()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'random_change':
         make_random_change()
         sys.exit(0)
@@ -588,3 +688,4 @@ if __name__ == '__main__':
     make_sequence_fragment()
     make_random_change()
     make_qscore_top_rows()
+    make_model_builders()
