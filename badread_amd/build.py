@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.realpath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(CSRC, 'libbrx_hip.so')
 SOURCES = ['brx_hip.hip']
-DEPS = ['brx_hip.hip', 'brx_kernels.h', 'brx_align.h', 'brx_mutate.h', os.path.join('..', '..', 'include', 'brx.h'),
-        os.path.join('..', '..', 'include', 'brx_spec.h')]
+DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))) + \
+    [os.path.join('..', '..', 'include', 'brx.h'), os.path.join('..', '..', 'include', 'brx_spec.h')]
 
 
 def hipcc():

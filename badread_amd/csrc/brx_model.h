@@ -56,7 +56,9 @@ __global__ void __launch_bounds__(256) k_mb_expand(BrxMbJob j) {
     j.fcol[c] = t != 1u ? j.ref[j.part_ref[lo] + o] : (uint8_t)BRX_MB_GAP;
 }
 
-__device__ __forceinline__ int mb_code(uint32_t ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1; }
+/* 'A' 'C' 'G' 'T' -> 0..3 and the test for them, as arithmetic (a chain of comparisons becomes a jump tree per column) */
+__device__ __forceinline__ uint32_t mb_code(uint32_t ch) { return ((ch >> 1) ^ (ch >> 2)) & 3u; }
+__device__ __forceinline__ bool mb_acgt(uint32_t ch) { return (ch >> 5) == 2u && ((0x0010008Au >> (ch & 31u)) & 1u) != 0u; }
 
 __device__ inline void mb_count(const BrxMbJob &j, uint64_t key, uint64_t rank) {
     uint64_t slot = ((key * 0x9E3779B97F4A7C15ull) >> 20) & j.table_mask;
@@ -90,20 +92,18 @@ __global__ void __launch_bounds__(256) k_mb_error(BrxMbJob j) {
     uint64_t e = s;
     for (; e < c1 && nref < j.k; ++e) {
         const uint32_t f = j.fcol[e], r = j.rcol[e];
-        if (f != BRX_MB_GAP) {
-            const int c = mb_code(f);
-            ok &= c >= 0;
-            refk = (refk << 2) | (uint32_t)(c & 3);
-            if (nref == 0) first_ref = f;
-            last_ref = f; nref += 1;
-        }
-        if (r != BRX_MB_GAP) {
-            const int c = mb_code(r);
-            ok &= c >= 0;
-            if (nread < BRX_MB_MAX_READ_KMER) readk |= (uint64_t)(c & 3) << (2 * nread); else too_long = true;
-            if (nread == 0) first_read = r;
-            last_read = r; nread += 1;
-        }
+        const bool hf = f != BRX_MB_GAP, hr = r != BRX_MB_GAP;
+        ok = ok && (!hf || mb_acgt(f)) && (!hr || mb_acgt(r));
+        refk = hf ? ((refk << 2) | mb_code(f)) : refk;
+        first_ref = (hf && nref == 0) ? f : first_ref;
+        last_ref = hf ? f : last_ref;
+        nref += hf ? 1u : 0u;
+        const bool fits = nread < BRX_MB_MAX_READ_KMER;
+        readk |= (hr && fits) ? ((uint64_t)mb_code(r) << (2 * (nread & 31u))) : 0ull;
+        too_long = too_long || (hr && !fits);
+        first_read = (hr && nread == 0) ? r : first_read;
+        last_read = hr ? r : last_read;
+        nread += hr ? 1u : 0u;
     }
     if (nref < j.k) return;                                     /* `end > len(aligned_ref_seq)`: no window left */
     if (!(nread > 1 && first_ref == first_read && last_ref == last_read && ok)) return;
