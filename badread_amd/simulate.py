@@ -22,6 +22,7 @@ Randomness: every draw on the device is Philox4x32-10 keyed by (seed, read index
 import os
 import random
 import sys
+import time
 
 import numpy as np
 
@@ -301,6 +302,7 @@ class _HostRing(object):
         self.todo = queue.Queue()
         self.error = None
         self.sink = None
+        self.sink_seconds = self.alloc_seconds = 0.0
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
@@ -312,7 +314,9 @@ class _HostRing(object):
             buf, n = item
             try:
                 if self.error is None and n:
+                    t0 = time.perf_counter()
                     self.sink(memoryview(buf.numpy())[:n])
+                    self.sink_seconds += time.perf_counter() - t0
             except BaseException as ex:             # surfaced by flush()
                 self.error = ex
             self.free.put(buf)
@@ -322,7 +326,9 @@ class _HostRing(object):
         buf = self.free.get()
         if buf is None or buf.numel() < nbytes:
             cap = max(int(nbytes * 1.25), 1 << 20)
+            t0 = time.perf_counter()
             buf = self.torch.empty(cap, dtype=self.torch.uint8, pin_memory=self.pinned)
+            self.alloc_seconds += time.perf_counter() - t0
         return buf
 
     def write(self, tensor):
@@ -354,7 +360,9 @@ class _BatchPool(object):
         self.on_gpu = torch is not None and getattr(engine, 'device', None) is not None and engine.device.type == 'cuda'
         if in_flight > 1 and hasattr(engine, 'clone'):
             self.streams = [torch.cuda.Stream(device=engine.device) if self.on_gpu else None for _ in range(in_flight)]
-            self.engines += [engine.clone() for _ in range(in_flight - 1)]
+            # a clone is made by the worker thread that first needs it: its tens of GB of scratch are mapped (seconds,
+            # measured: 6.8 s for 7 x 34 GB up front) while the engines that already exist are computing
+            self.engines += [None] * (in_flight - 1)
         elif self.on_gpu:
             self.streams = [torch.cuda.Stream(device=engine.device)]
         self.free = list(range(len(self.engines)))
@@ -364,11 +372,16 @@ class _BatchPool(object):
         return len(self.engines)
 
     def submit(self, seed, first, n_mine):
-        i = self.free.pop()
-        eng, stream = self.engines[i], self.streams[i]
+        i = self.free.pop(0)                             # engine 0 exists already: it takes the first batch
+        stream = self.streams[i]
 
         def job():
             import torch
+            if self.engines[i] is None:
+                if self.on_gpu:
+                    torch.cuda.set_device(self.engines[0].device)
+                self.engines[i] = self.engines[0].clone()
+            eng = self.engines[i]
             if n_mine == 0:
                 return torch.zeros(0, dtype=torch.uint8), np.zeros(0, dtype=eng.stats_dtype)
             if not self.on_gpu:
@@ -393,7 +406,8 @@ class _BatchPool(object):
         if self.pool is not None:
             self.pool.shutdown(wait=True)
         for eng in self.engines[1:]:
-            eng.close()
+            if eng is not None:
+                eng.close()
 
 
 def run_batches(engine, seed, target_size, mean_length, write, output, shard=None, max_batch=None, in_flight=1):
@@ -419,7 +433,10 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     expected_mean = float(mean_length)
     if shard.rank == 0:
         print_progress(count, total, target_size, output)
+    timing = run_batches.last_timing = collections.Counter()     # seconds of the consumer thread per activity (bench.py --d2h)
+    t0 = time.perf_counter()
     pool = _BatchPool(engine, max(1, int(in_flight)))
+    timing['create_engines'] = time.perf_counter() - t0
     ring = None
     if shard.rank == 0:
         ring = _HostRing(torch, pinned=pool.on_gpu)
@@ -455,7 +472,10 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         while total < target_size:
             fill()
             slot, fut, base, n_super, first, n_mine = pending.popleft()
+            t0 = time.perf_counter()
             out, stats = fut.result()
+            timing['wait_for_batch'] += time.perf_counter() - t0
+            timing['batches'] += 1
             # ---- the 4 B/read exchange: length (0 for skipped reads) | NOFRAG << 31 | BAD << 30 ----
             words = (stats['seq_len'].astype(np.uint32) * (stats['rec_len'] > 0)).astype(np.uint32)
             assert not len(words) or int(words.max()) < FLAG_BAD
@@ -484,8 +504,10 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
                 assert my_bytes < 2 ** 32
             # the engine goes back to work at once: its kept bytes are copied device-to-device first (0.5 GB at HBM speed),
             # the slower hops (PCIe into the pinned ring, or the send to rank 0) read that copy
+            t0 = time.perf_counter()
             if pool.on_gpu and my_bytes:
                 out = out[:my_bytes].clone()
+            timing['clone'] += time.perf_counter() - t0
             pool.release(slot)                      # the engine's output buffer may be overwritten from here on
             used = lens[:last + 1]
             count += int((used > 0).sum())
@@ -495,8 +517,10 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
                 expected_mean = max(total / count, 1.0)
             if not stop and total < target_size:
                 fill()                              # the freed engine starts its next batch while this one's bytes leave
+            t0 = time.perf_counter()
             for _, part in shard.collect_bytes(out, sizes, staging):
                 ring.write(part)                    # rank 0: through pinned memory to the writer thread
+            timing['copy_out'] += time.perf_counter() - t0
             if shard.rank == 0:
                 print_progress(count, total, target_size, output)
             if stop:
@@ -507,9 +531,16 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
                 fut.result()
             except Exception:
                 pass
+        t0 = time.perf_counter()
         pool.close()
+        timing['close_engines'] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         if ring is not None:
             ring.flush()
+            timing['sink'] = ring.sink_seconds
+            timing['ring_alloc'] = ring.alloc_seconds
+        timing['flush'] = time.perf_counter() - t0
+        timing['retries'] = sum(getattr(e, 'retries', 0) for e in pool.engines if e is not None)
     if shard.rank == 0:
         print('\n', file=output)
     if fatal:

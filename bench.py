@@ -429,6 +429,7 @@ def main():
                          'fastq_bytes_per_s': (getattr(sink, 'bytes_in', 0) or 2.02 * total) / dt}
             if level is not None:
                 d2h[name]['compressed_bytes'] = sink.bytes_out
+            d2h[name]['consumer_thread_seconds'] = {k: round(float(v), 3) for k, v in run_batches.last_timing.items()}
             raw.close()
         engines[:] = [first]
 
