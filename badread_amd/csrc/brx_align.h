@@ -34,6 +34,11 @@
 #include <stdint.h>
 #include <type_traits>
 
+/* pointer to global memory, for the stores whose address the compiler would otherwise treat as generic (flat) */
+#ifndef BRX_GLOBAL
+#define BRX_GLOBAL __attribute__((address_space(1)))
+#endif
+
 #define BRX_OP_EQ 0
 #define BRX_OP_X 1
 #define BRX_OP_I 2
@@ -212,6 +217,38 @@ __device__ __forceinline__ int brx_wave_min(int v) {
 }
 __device__ __forceinline__ uint32_t brx_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   /* v_bfi_b32 */
 
+/* sign-extended bit b of v: all ones or zero (v_bfe_i32) */
+__device__ __forceinline__ uint32_t brx_bit_mask(uint32_t v, int b) { return (uint32_t)((int32_t)(v << (31 - b)) >> 31); }
+
+/* The query word of a lane as bit planes instead of one equality mask per symbol: code bit 0, code bit 1, "row holds
+   A/C/G/T" and "row holds N" (rows past the end of the query are in neither).  The equality mask of a column whose
+   target symbol is A/C/G/T is then two three-input bit operations on the symbol's two code bits -- the five-way select
+   over per-symbol masks cost 12 instructions per column, a quarter of the whole column update. */
+struct BrxQPlanes { uint32_t lo, hi, acgt, n; };
+__device__ inline BrxQPlanes brx_query_planes(const uint8_t *__restrict__ Qs, int w, int Q) {
+    BrxQPlanes p = {0u, 0u, 0u, 0u};
+    const uint32_t *q4 = reinterpret_cast<const uint32_t *>(Qs + 32 * w);
+#pragma unroll 1
+    for (int d = 0; d < 8; ++d) {
+        const uint32_t v = q4[d];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t code = (v >> (8 * b)) & 0xFFu;
+            const int r = 4 * d + b;
+            const bool ok = (32 * w + r) < Q;
+            p.lo |= (code & 1u) << r;
+            p.hi |= ((code >> 1) & 1u) << r;
+            p.acgt |= (uint32_t)(ok && code < 4u) << r;
+            p.n |= (uint32_t)(ok && code == 4u) << r;
+        }
+    }
+    return p;
+}
+/* k0 / k1: bit 0 / bit 1 of the target symbol, as masks */
+__device__ __forceinline__ uint32_t brx_eq_acgt(const BrxQPlanes &p, uint32_t k0, uint32_t k1) {
+    return ~(p.lo ^ k0) & ~(p.hi ^ k1) & p.acgt;
+}
+
 template <int G, bool MW = false>
 __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                   const BrxGeom g, uint2 *__restrict__ tb, uint32_t *prog = nullptr) {
@@ -226,14 +263,14 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
     int tf = NEVER, tl = NEVER, slot = 0;
     if (s < g.NS) { tf = brx_jfirst(g, s) + s; tl = brx_jlast(g, s) + s; slot = s % g.WSp; }
     uint32_t Pv[G], Mv[G];
-    uint32_t pe[G][5];
+    BrxQPlanes qp[G];
 #pragma unroll
-    for (int x = 0; x < G; ++x) {
-        Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;
-#pragma unroll
-        for (int c = 0; c < 5; ++c) pe[x][c] = 0;
-    }
+    for (int x = 0; x < G; ++x) { Pv[x] = 0xFFFFFFFFu; Mv[x] = 0; qp[x] = BrxQPlanes{0u, 0u, 0u, 0u}; }
     uint32_t carry = 0;
+    /* windowed traceback store (brx_stored), incrementally: acc = slope * column, exact in 64 bits */
+    const uint32_t keep_lim = (uint32_t)(2 * g.H + g.R - 1);
+    int keep_base = g.R * s + g.H + g.R - 1;
+    int64_t acc = (int64_t)(1 - s) * (int64_t)g.slope;
 
     /* target window: chunk c = target bytes [256c, 256c+256) lives in half c & 1 of the first 512 ring bytes; `odd` remembers
        which halves hold a symbol outside A,C,G,T,N (IUPAC codes: slow equality path) */
@@ -262,7 +299,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
 
     const size_t step_units = (size_t)g.WSp * (size_t)G;
     uint2 *dst = tb + ((size_t)1 * (size_t)g.WSp + (size_t)slot) * (size_t)G;
-    for (int t = 1; t <= g.t_end; ++t, dst += step_units) {
+    for (int t = 1; t <= g.t_end; ++t, dst += step_units, acc += (int64_t)g.slope) {
         /* ---- refill of the target window, keyed on the newest column in use (scalar code) ---- */
         while (__builtin_expect(s_top < g.NS - 1 && t >= t_top, 0)) { s_top += 1; t_top = brx_jlast(g, s_top) + s_top + 1; }
         const int front = t - s_top - 1;             /* 0-based target index of the newest column */
@@ -282,26 +319,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
                 for (int x = 0; x < G; ++x) {
                     Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;          /* cells below the band grow by +1 per row */
                     const int w = s * G + x;
-                    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
-                    if (w < g.NW) {
-                        const uint32_t *q4 = reinterpret_cast<const uint32_t *>(Qs + 32 * w);
-#pragma unroll 1
-                        for (int d = 0; d < 8; ++d) {
-                            const uint32_t v = q4[d];
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const uint32_t code = (v >> (8 * b)) & 0xFFu;
-                                const int r = 4 * d + b;
-                                const bool ok = (32 * w + r) < g.Q;
-                                m0 |= (uint32_t)(ok && code == 0) << r;
-                                m1 |= (uint32_t)(ok && code == 1) << r;
-                                m2 |= (uint32_t)(ok && code == 2) << r;
-                                m3 |= (uint32_t)(ok && code == 3) << r;
-                                m4 |= (uint32_t)(ok && code == 4) << r;
-                            }
-                        }
-                    }
-                    pe[x][0] = m0; pe[x][1] = m1; pe[x][2] = m2; pe[x][3] = m3; pe[x][4] = m4;
+                    qp[x] = w < g.NW ? brx_query_planes(Qs, w, g.Q) : BrxQPlanes{0u, 0u, 0u, 0u};
                 }
             }
             next_entry = brx_wave_min(tf > t ? tf : NEVER);
@@ -314,14 +332,13 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
         uint32_t hp = (0x9u >> nb) & 1u, hm = (0x2u >> nb) & 1u;
         const uint32_t k0 = 0u - (c & 1u), k1 = 0u - ((c >> 1) & 1u), k4 = 0u - ((c >> 2) & 1u);
         const bool rare = __builtin_expect(odd != 0u, 0) && __ballot(actm != 0u && c > 4u) != 0ull;
-        const bool keep = brx_stored(g, s, t - s);                             /* windowed traceback store */
+        const bool keep = (uint32_t)(keep_base - (int)(uint32_t)((uint64_t)acc >> 20)) <= keep_lim;   /* windowed traceback store */
 #pragma unroll
         for (int x = 0; x < G; ++x) {
             /* symbol select by mask arithmetic (v_bfi), NOT by ?: over the array -- hipcc folds a select
                chain over the elements of a private array into one dynamically indexed load, which pins
                the array in scratch memory (a vmcnt-ordered load per column) */
-            uint32_t Eq = brx_bfi(k1, brx_bfi(k0, pe[x][3], pe[x][2]), brx_bfi(k0, pe[x][1], pe[x][0]));
-            Eq = brx_bfi(k4, pe[x][4], Eq);
+            uint32_t Eq = brx_bfi(k4, qp[x].n, brx_eq_acgt(qp[x], k0, k1));
             if (rare) { if (actm != 0u && c > 4u && s * G + x < g.NW) Eq = brx_eq_rare(Qs, g.Q, s * G + x, c); }
             uint32_t pv = Pv[x], mv = Mv[x];
             const uint32_t Xv = Eq | mv;
@@ -353,6 +370,8 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
                     dst += ((ptrdiff_t)nslot - (ptrdiff_t)slot) * (ptrdiff_t)G;
                     slot = nslot;
                 } else { tf = NEVER; tl = NEVER; }
+                keep_base = g.R * s + g.H + g.R - 1;
+                acc = (int64_t)(t - s) * (int64_t)g.slope;     /* the loop header adds one step before the next trip */
             }
             next_hop = brx_wave_min(tl);
             next_entry = brx_wave_min(tf > t ? tf : NEVER);
@@ -545,30 +564,50 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
                                             const BrxGeom g, uint2 *__restrict__ tb) {
     const int lane = threadIdx.x & 63;
     uint32_t *const ring32 = brx_ring<MW>();
+    /* the store base is the same in every lane: say so (and that it is global memory), and the traceback stores take the
+       scalar-base form -- row address in SGPRs + a 32-bit lane offset -- instead of a 64-bit vector add per column */
+    const uint64_t tb_addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)tb >> 32)) << 32) |
+                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)tb);
     constexpr int NEVER = 0x7FFFFFFF;
-    constexpr int JNEVER = 0x3FFFFFFF;              /* `j - jf` must not overflow for the (negative) j of an idle lane */
+    constexpr int JNEVER = 0x3FFFFFFF;              /* `j - af` of an idle lane (negative j included) stays far above any span */
     constexpr int K = 4;
     int s = lane;
-    int jf = JNEVER, jl = -1, slot = 0;              /* column window of the lane's current superblock */
+    int jf = JNEVER, jl = -1;                        /* column window of the lane's current superblock */
+    uint32_t slot8 = 0;                              /* byte offset of the lane's slot in a traceback row */
     int tf = NEVER, tl = NEVER;                     /* first / last loop trip of that window          */
-    if (s < g.NS) {
-        jf = brx_jfirst(g, s); jl = brx_jlast(g, s); slot = s % g.WSp;
-        tf = s + (jf - 1) / K; tl = s + (jl - 1) / K;
-        if (jl < jf) { tf = NEVER; }                /* empty window: never active, but it still hops at tl */
-    }
+    /* column j is computed iff (uint32_t)(j - af) <= ad: one add and one unsigned compare per column */
+    int af = JNEVER; uint32_t ad = 0;
+    /* windowed traceback store (brx_stored), incrementally: acc = slope * (third column of the trip), exact in 64 bits;
+       superblock s is written iff (uint32_t)(keep_base - (acc >> 20)) <= keep_lim */
+    const uint32_t keep_lim = (uint32_t)(2 * g.H + g.R - 1);
+    int keep_base = 0;
+    int64_t acc = 0;
+    const int64_t acc_step = (int64_t)K * (int64_t)g.slope;
+    auto window = [&](int tau_now) {                 /* everything that depends on s; tau_now: the next trip to run */
+        if (s < g.NS) {
+            jf = brx_jfirst(g, s); jl = brx_jlast(g, s); slot8 = 8u * (uint32_t)(s % g.WSp);
+            tf = s + (jf - 1) / K; tl = s + (jl - 1) / K;
+            af = jf; ad = (uint32_t)(jl - jf);
+            if (jl < jf) { tf = NEVER; af = JNEVER; ad = 0; }      /* empty window: never active, but it still hops at tl */
+        } else { jf = JNEVER; jl = -1; tf = NEVER; tl = NEVER; af = JNEVER; ad = 0; }
+        keep_base = g.R * s + g.H + g.R - 1;
+        acc = (int64_t)(K * (tau_now - s) + 2) * (int64_t)g.slope;
+    };
+    window(0);
     uint32_t Pv = 0xFFFFFFFFu, Mv = 0;
-    uint32_t pe0 = 0, pe1 = 0, pe2 = 0, pe3 = 0, pe4 = 0;
-    uint32_t carry = 0;                             /* 4 x 2 bits: 0 idle, 1/2/3 = hout -1/0/+1       */
+    BrxQPlanes qp = {0u, 0u, 0u, 0u};
+    uint32_t carry = 0xAAu;                         /* 4 x 2 bits, column 0 on top: bit 1 = hout is +1, bit 0 = hout is -1;
+                                                       an idle lane hands on +1 (the cells above the band grow by one per column) */
 
     auto fetch_chunk = [&](int c) -> uint32_t {
         const int idx = 256 * c + 4 * lane;
         return (idx + 4 <= g.T + 16) ? *reinterpret_cast<const uint32_t *>(Ts + idx) : 0xFEFEFEFEu;
     };
-    auto chunk_odd = [&](int c, uint32_t v) -> uint32_t {
+    auto chunk_odd = [&](int c, uint32_t v) -> uint32_t {       /* any symbol other than A/C/G/T in the chunk (N and IUPAC codes) */
         const int idx = 256 * c + 4 * lane;
         bool o = false;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) o |= idx + b < g.T && ((v >> (8 * b)) & 0xFFu) > 4u;
+        for (int b = 0; b < 4; ++b) o |= idx + b < g.T && ((v >> (8 * b)) & 0xFFu) > 3u;
         return __ballot(o) != 0ull ? 1u : 0u;
     };
     uint32_t odd = 0, pending = 0;
@@ -582,10 +621,10 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
     int tl_top = (brx_jlast(g, 0) - 1) / K;         /* its last trip                                     */
     int next_entry = brx_wave_min(tf), next_hop = brx_wave_min(tl);
     const int tau_end = (g.NS - 1) + (g.T - 1) / K;
-    const size_t trip_units = (size_t)K * (size_t)g.WSp;
-    uint2 *dst = tb + (size_t)1 * (size_t)g.WSp + (size_t)slot;          /* row 4 tau + 1, this lane's slot */
+    const size_t wsp = (size_t)g.WSp;
+    BRX_GLOBAL uint64_t *row = (BRX_GLOBAL uint64_t *)tb_addr + wsp;     /* traceback row 4 tau + 1 (uniform); a lane writes row[c * WSp + slot] */
     uint32_t wnext = ring32[((uint32_t)(K * (0 - s)) >> 2) & (BRX_RING_BYTES / 4 - 1)];
-    for (int tau = 0; tau <= tau_end; ++tau, dst += trip_units) {
+    for (int tau = 0; tau <= tau_end; ++tau, row += (size_t)K * wsp, acc += acc_step) {
         /* ---- refill of the target window, keyed on the newest byte in use (scalar code) ---- */
         while (__builtin_expect(s_top < g.NS - 1 && tau > tl_top, 0)) { s_top += 1; tl_top = s_top + (brx_jlast(g, s_top) - 1) / K; }
         const int fq = (tau - s_top);               /* newest column group in use: bytes 4 fq .. 4 fq + 3 */
@@ -602,28 +641,11 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
             }
         }
 
-        /* ---- a superblock enters the band: build its equality masks ---- */
+        /* ---- a superblock enters the band: read its query rows ---- */
         if (__builtin_expect(tau == next_entry, 0)) {
             if (tau == tf) {
                 Pv = 0xFFFFFFFFu; Mv = 0;                         /* cells below the band grow by +1 per row */
-                uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
-                const uint32_t *q4 = reinterpret_cast<const uint32_t *>(Qs + 32 * s);
-#pragma unroll 1
-                for (int d = 0; d < 8; ++d) {
-                    const uint32_t v = q4[d];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const uint32_t code = (v >> (8 * b)) & 0xFFu;
-                        const int r = 4 * d + b;
-                        const bool ok = (32 * s + r) < g.Q;
-                        m0 |= (uint32_t)(ok && code == 0) << r;
-                        m1 |= (uint32_t)(ok && code == 1) << r;
-                        m2 |= (uint32_t)(ok && code == 2) << r;
-                        m3 |= (uint32_t)(ok && code == 3) << r;
-                        m4 |= (uint32_t)(ok && code == 4) << r;
-                    }
-                }
-                pe0 = m0; pe1 = m1; pe2 = m2; pe3 = m3; pe4 = m4;
+                qp = brx_query_planes(Qs, s, g.Q);
             }
             next_entry = brx_wave_min(tf > tau ? tf : NEVER);
         }
@@ -632,32 +654,33 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
         const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
         const uint32_t w = wnext;
         const int jb = K * (tau - s);                              /* columns jb + 1 .. jb + 4 */
-        const uint32_t keepm = brx_stored(g, s, jb + 2) ? ~0u : 0u;   /* windowed traceback store: one test per trip */
+        const uint32_t a0 = (uint32_t)(jb + 1 - af);
+        const bool keep = (uint32_t)(keep_base - (int)(uint32_t)((uint64_t)acc >> 20)) <= keep_lim;   /* one test per trip */
         uint32_t out = 0;
         bool rare = false;
         if (__builtin_expect(odd != 0u, 0)) {
             bool lr = false;
 #pragma unroll
-            for (int c = 0; c < K; ++c) lr |= (jb + 1 + c >= jf) && (jb + 1 + c <= jl) && ((w >> (8 * c)) & 0xFFu) > 4u;
+            for (int c = 0; c < K; ++c) lr |= (a0 + (uint32_t)c <= ad) && ((w >> (8 * c)) & 0xFFu) > 3u;
             rare = __ballot(lr) != 0ull;
         }
-        /* one column; RARE = the trip contains an IUPAC symbol other than N (out-of-line equality mask) */
-        auto column = [&](const int c, auto rare_tag) {
-            const int j = jb + 1 + c;
-            const uint32_t actm = ~(uint32_t)(((j - jf) | (jl - j)) >> 31);     /* all ones iff jf <= j <= jl */
-            const uint32_t ch = (w >> (8 * c)) & 0xFFu;
-            const uint32_t hin = (nb >> (2 * c)) & 3u;
-            const uint32_t hp = (0x9u >> hin) & 1u, hm = (0x2u >> hin) & 1u;
-            const uint32_t k0 = 0u - (ch & 1u), k1 = 0u - ((ch >> 1) & 1u), k4 = 0u - ((ch >> 2) & 1u);
-            uint32_t Eq = brx_bfi(k1, brx_bfi(k0, pe3, pe2), brx_bfi(k0, pe1, pe0));
-            Eq = brx_bfi(k4, pe4, Eq);
-            if constexpr (decltype(rare_tag)::value) {
-                if (actm != 0u && ch > 4u) {                   /* inline, rolled: a call would impose the callee's registers */
+        /* one column.  ANY = the trip holds an N or an IUPAC symbol in some lane's active column (out-of-line masks) */
+        auto column = [&](const int c, auto any_tag) {
+            const bool act = a0 + (uint32_t)c <= ad;               /* jf <= jb + 1 + c <= jl */
+            const uint32_t hm = (nb >> (6 - 2 * c)) & 1u, hp = (nb >> (7 - 2 * c)) & 1u;
+            uint32_t Eq;
+            if constexpr (decltype(any_tag)::value) {
+                const uint32_t ch = (w >> (8 * c)) & 0xFFu;
+                Eq = brx_eq_acgt(qp, 0u - (ch & 1u), 0u - ((ch >> 1) & 1u));
+                if (ch == 4u) Eq = qp.n;
+                if (act && ch > 4u) {                              /* inline, rolled: a call would impose the callee's registers */
                     uint32_t mq = 0;
 #pragma unroll 1
                     for (int rr = 0; rr < 32; ++rr) { const int qi = 32 * s + rr; if (qi < g.Q && Qs[qi] == ch) mq |= 1u << rr; }
                     Eq = mq;
                 }
+            } else {
+                Eq = brx_eq_acgt(qp, brx_bit_mask(w, 8 * c), brx_bit_mask(w, 8 * c + 1));
             }
             const uint32_t Xv = Eq | Mv;
             const uint32_t Eq2 = Eq | hm;
@@ -668,10 +691,12 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
             const uint32_t MhS = (Mh << 1) | hm;
             const uint32_t pv = MhS | ~(Xv | PhS);
             const uint32_t mv = PhS & Xv;
-            if (actm & keepm) dst[(size_t)c * (size_t)g.WSp] = make_uint2(pv, Ph);
-            Pv = brx_bfi(actm, pv, Pv);
-            Mv = brx_bfi(actm, mv, Mv);
-            out |= (((Ph >> 31) + 2u - (Mh >> 31)) & actm) << (2 * c);
+            const uint32_t Ph_out = Ph;
+            Pv = act ? pv : Pv;
+            Mv = act ? mv : Mv;
+            if (act && keep) *(BRX_GLOBAL uint64_t *)((BRX_GLOBAL char *)(row + (size_t)c * wsp) + slot8) = ((uint64_t)Ph_out << 32) | (uint64_t)pv;   /* uint2 {pv, Ph} */
+            const uint32_t ho = (uint32_t)((((uint64_t)(Ph >> 31) << 32) | (uint64_t)Mh) >> 31);   /* (Ph>>31) << 1 | Mh >> 31: v_alignbit */
+            out = (out << 2) | (act ? ho : 2u);
         };
         if (__builtin_expect(rare, 0)) {
 #pragma unroll 1
@@ -683,17 +708,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
 
         /* ---- a superblock leaves the band: its lane takes superblock s + 64 ---- */
         if (__builtin_expect(tau == next_hop, 0)) {
-            if (tau >= tl) {
-                s += 64;
-                if (s < g.NS) {
-                    jf = brx_jfirst(g, s); jl = brx_jlast(g, s);
-                    tf = s + (jf - 1) / K; tl = s + (jl - 1) / K;
-                    if (jl < jf) tf = NEVER;
-                    const int nslot = s % g.WSp;
-                    dst += (ptrdiff_t)nslot - (ptrdiff_t)slot;
-                    slot = nslot;
-                } else { jf = JNEVER; jl = -1; tf = NEVER; tl = NEVER; }
-            }
+            if (tau >= tl) { s += 64; window(tau); }             /* acc: the loop header adds one step before the next trip */
             next_hop = brx_wave_min(tl);
             next_entry = brx_wave_min(tf > tau ? tf : NEVER);
         }

@@ -40,6 +40,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
+#define BRX_GLOBAL                 /* address-space qualifier of the product's explicit global-memory stores: one flat memory here */
 #define __shared__ static thread_local   /* one workgroup runs at a time per host thread: a static IS its LDS */
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
