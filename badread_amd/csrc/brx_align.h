@@ -58,7 +58,7 @@ struct BrxGeom {
     int WSp;           /* band slots per time step in the traceback store         */
     int K;             /* time skew between neighbouring superblocks: superblock s handles column j at
                           time j + K*s.  K = 4 for G = 1 (four columns per loop trip), else 1            */
-    int t_end;         /* last traceback row = T + K*(NS - 1)                      */
+    int t_end;         /* last traceback row = T (K = 4: rounded up to a multiple of 4) + K*(NS - 1) */
     int H;             /* windowed traceback store: only superblocks within H rows of the straight line
                           row = column * Q / T are written (BRX_H_ALL: every superblock of the band)    */
     uint32_t slope;    /* Q / T with 20 fractional bits (0 when the store is not windowed)               */
@@ -105,7 +105,7 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul =
     if (g.WSp > g.NS) g.WSp = g.NS;
     if (g.WSp < 1) g.WSp = 1;
     g.K = G == 1 ? 4 : 1;
-    g.t_end = T + g.K * (g.NS - 1);
+    g.t_end = (G == 1 ? (T + 3) / 4 * 4 : T) + g.K * (g.NS - 1);   /* K = 4: whole trips, the last one may run past column T */
     g.H = BRX_H_ALL; g.slope = 0;
     if (hmul != 0 && G <= 16 && T > 0 && (uint64_t)Q < ((uint64_t)T << 11)) {
         const int H = hmul > 0 ? hmul * (int)brx_isqrt((uint32_t)k) + 24 : 8;
@@ -569,35 +569,39 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
     const uint64_t tb_addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)tb >> 32)) << 32) |
                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)tb);
     constexpr int NEVER = 0x7FFFFFFF;
-    constexpr int JNEVER = 0x3FFFFFFF;              /* `j - af` of an idle lane (negative j included) stays far above any span */
     constexpr int K = 4;
+    /* A superblock works in WHOLE trips: trips tf .. tl, i.e. columns 4 (tf - s) + 1 .. 4 (tl - s) + 4 -- its band window
+       [jf, jl] widened to trip boundaries (up to three columns on either side, the last trip possibly past column T: those
+       bytes are padding and nothing reads their cells).  Computing more than the Ukkonen band is harmless (cells outside it
+       are upper bounds either way, cells inside are exact), and one activity test, one store predicate and one select of
+       the running Pv / Mv per trip replace four of each. */
     int s = lane;
-    int jf = JNEVER, jl = -1;                        /* column window of the lane's current superblock */
     uint32_t slot8 = 0;                              /* byte offset of the lane's slot in a traceback row */
-    int tf = NEVER, tl = NEVER;                     /* first / last loop trip of that window          */
-    /* column j is computed iff (uint32_t)(j - af) <= ad: one add and one unsigned compare per column */
-    int af = JNEVER; uint32_t ad = 0;
+    int tf = NEVER, tl = NEVER;                     /* first / last loop trip of the lane's superblock: trip tau is computed
+                                                       iff (uint32_t)(tau - tf) <= tspan                                  */
+    uint32_t tspan = 0;
     /* windowed traceback store (brx_stored), incrementally: acc = slope * (third column of the trip), exact in 64 bits;
        superblock s is written iff (uint32_t)(keep_base - (acc >> 20)) <= keep_lim */
     const uint32_t keep_lim = (uint32_t)(2 * g.H + g.R - 1);
     int keep_base = 0;
     int64_t acc = 0;
     const int64_t acc_step = (int64_t)K * (int64_t)g.slope;
-    auto window = [&](int tau_now) {                 /* everything that depends on s; tau_now: the next trip to run */
+    auto window = [&](int tau_now) {                 /* everything that depends on s; tau_now: the trip the loop is in */
+        tf = NEVER; tl = NEVER; tspan = 0;
         if (s < g.NS) {
-            jf = brx_jfirst(g, s); jl = brx_jlast(g, s); slot8 = 8u * (uint32_t)(s % g.WSp);
-            tf = s + (jf - 1) / K; tl = s + (jl - 1) / K;
-            af = jf; ad = (uint32_t)(jl - jf);
-            if (jl < jf) { tf = NEVER; af = JNEVER; ad = 0; }      /* empty window: never active, but it still hops at tl */
-        } else { jf = JNEVER; jl = -1; tf = NEVER; tl = NEVER; af = JNEVER; ad = 0; }
+            const int jf = brx_jfirst(g, s), jl = brx_jlast(g, s);
+            slot8 = 8u * (uint32_t)(s % g.WSp);
+            tl = s + (jl - 1) / K;
+            if (jl >= jf) { tf = s + (jf - 1) / K; tspan = (uint32_t)(tl - tf); }   /* empty window: never active, but it still hops at tl */
+        }
         keep_base = g.R * s + g.H + g.R - 1;
         acc = (int64_t)(K * (tau_now - s) + 2) * (int64_t)g.slope;
     };
     window(0);
     uint32_t Pv = 0xFFFFFFFFu, Mv = 0;
     BrxQPlanes qp = {0u, 0u, 0u, 0u};
-    uint32_t carry = 0xAAu;                         /* 4 x 2 bits, column 0 on top: bit 1 = hout is +1, bit 0 = hout is -1;
-                                                       an idle lane hands on +1 (the cells above the band grow by one per column) */
+    uint32_t carry = 0xF0u;                         /* bits 7..4: hout of columns 0..3 is +1; bits 3..0: it is -1.  An idle lane
+                                                       hands on +1 (the cells above the band grow by one per column) */
 
     auto fetch_chunk = [&](int c) -> uint32_t {
         const int idx = 256 * c + 4 * lane;
@@ -622,9 +626,12 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
     int next_entry = brx_wave_min(tf), next_hop = brx_wave_min(tl);
     const int tau_end = (g.NS - 1) + (g.T - 1) / K;
     const size_t wsp = (size_t)g.WSp;
-    BRX_GLOBAL uint64_t *row = (BRX_GLOBAL uint64_t *)tb_addr + wsp;     /* traceback row 4 tau + 1 (uniform); a lane writes row[c * WSp + slot] */
+    /* traceback rows 4 tau + 1 .. 4 tau + 4 (uniform addresses); a lane writes at byte slot8 of each */
+    BRX_GLOBAL char *row0 = (BRX_GLOBAL char *)((BRX_GLOBAL uint64_t *)tb_addr + wsp);
+    BRX_GLOBAL char *row1 = row0 + 8 * wsp, *row2 = row0 + 16 * wsp, *row3 = row0 + 24 * wsp;
+    const size_t trip_bytes = 8 * (size_t)K * wsp;
     uint32_t wnext = ring32[((uint32_t)(K * (0 - s)) >> 2) & (BRX_RING_BYTES / 4 - 1)];
-    for (int tau = 0; tau <= tau_end; ++tau, row += (size_t)K * wsp, acc += acc_step) {
+    for (int tau = 0; tau <= tau_end; ++tau, row0 += trip_bytes, row1 += trip_bytes, row2 += trip_bytes, row3 += trip_bytes, acc += acc_step) {
         /* ---- refill of the target window, keyed on the newest byte in use (scalar code) ---- */
         while (__builtin_expect(s_top < g.NS - 1 && tau > tl_top, 0)) { s_top += 1; tl_top = s_top + (brx_jlast(g, s_top) - 1) / K; }
         const int fq = (tau - s_top);               /* newest column group in use: bytes 4 fq .. 4 fq + 3 */
@@ -653,21 +660,20 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
         /* ---- four column updates, straight-line ---- */
         const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
         const uint32_t w = wnext;
-        const int jb = K * (tau - s);                              /* columns jb + 1 .. jb + 4 */
-        const uint32_t a0 = (uint32_t)(jb + 1 - af);
+        const bool act = (uint32_t)(tau - tf) <= tspan;
         const bool keep = (uint32_t)(keep_base - (int)(uint32_t)((uint64_t)acc >> 20)) <= keep_lim;   /* one test per trip */
-        uint32_t out = 0;
         bool rare = false;
         if (__builtin_expect(odd != 0u, 0)) {
             bool lr = false;
 #pragma unroll
-            for (int c = 0; c < K; ++c) lr |= (a0 + (uint32_t)c <= ad) && ((w >> (8 * c)) & 0xFFu) > 3u;
-            rare = __ballot(lr) != 0ull;
+            for (int c = 0; c < K; ++c) lr |= ((w >> (8 * c)) & 0xFFu) > 3u;
+            rare = __ballot(lr && act) != 0ull;
         }
-        /* one column.  ANY = the trip holds an N or an IUPAC symbol in some lane's active column (out-of-line masks) */
+        uint32_t P = Pv, M = Mv, accP = 0, accM = 0;
+        uint32_t pvs[K], phs[K];
+        /* one column.  ANY = the trip holds an N or an IUPAC symbol in some active lane (out-of-line masks) */
         auto column = [&](const int c, auto any_tag) {
-            const bool act = a0 + (uint32_t)c <= ad;               /* jf <= jb + 1 + c <= jl */
-            const uint32_t hm = (nb >> (6 - 2 * c)) & 1u, hp = (nb >> (7 - 2 * c)) & 1u;
+            const uint32_t hm = (nb >> (3 - c)) & 1u, hp = (nb >> (7 - c)) & 1u;
             uint32_t Eq;
             if constexpr (decltype(any_tag)::value) {
                 const uint32_t ch = (w >> (8 * c)) & 0xFFu;
@@ -682,29 +688,58 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
             } else {
                 Eq = brx_eq_acgt(qp, brx_bit_mask(w, 8 * c), brx_bit_mask(w, 8 * c + 1));
             }
-            const uint32_t Xv = Eq | Mv;
+            const uint32_t Xv = Eq | M;
             const uint32_t Eq2 = Eq | hm;
-            const uint32_t Xh = (((Eq2 & Pv) + Pv) ^ Pv) | Eq2;
-            const uint32_t Ph = Mv | ~(Xh | Pv);
-            const uint32_t Mh = Pv & Xh;
+            const uint32_t Xh = (((Eq2 & P) + P) ^ P) | Eq2;
+            const uint32_t Ph = M | ~(Xh | P);
+            const uint32_t Mh = P & Xh;
             const uint32_t PhS = (Ph << 1) | hp;
             const uint32_t MhS = (Mh << 1) | hm;
-            const uint32_t pv = MhS | ~(Xv | PhS);
-            const uint32_t mv = PhS & Xv;
-            const uint32_t Ph_out = Ph;
-            Pv = act ? pv : Pv;
-            Mv = act ? mv : Mv;
-            if (act && keep) *(BRX_GLOBAL uint64_t *)((BRX_GLOBAL char *)(row + (size_t)c * wsp) + slot8) = ((uint64_t)Ph_out << 32) | (uint64_t)pv;   /* uint2 {pv, Ph} */
-            const uint32_t ho = (uint32_t)((((uint64_t)(Ph >> 31) << 32) | (uint64_t)Mh) >> 31);   /* (Ph>>31) << 1 | Mh >> 31: v_alignbit */
-            out = (out << 2) | (act ? ho : 2u);
+            P = MhS | ~(Xv | PhS);
+            M = PhS & Xv;
+            pvs[c] = P; phs[c] = Ph;
+            accP = __builtin_amdgcn_alignbit(accP, Ph, 31);        /* accP << 1 | Ph >> 31 */
+            accM = __builtin_amdgcn_alignbit(accM, Mh, 31);
         };
         if (__builtin_expect(rare, 0)) {
+            /* rolled: the loop index is a run-time value, so the bit positions are computed */
 #pragma unroll 1
-            for (int c = 0; c < K; ++c) column(c, std::true_type{});
+            for (int c = 0; c < K; ++c) {
+                const uint32_t hm = (nb >> (3 - c)) & 1u, hp = (nb >> (7 - c)) & 1u;
+                const uint32_t ch = (w >> (8 * c)) & 0xFFu;
+                uint32_t Eq = brx_eq_acgt(qp, 0u - (ch & 1u), 0u - ((ch >> 1) & 1u));
+                if (ch == 4u) Eq = qp.n;
+                if (act && ch > 4u) {
+                    uint32_t mq = 0;
+#pragma unroll 1
+                    for (int rr = 0; rr < 32; ++rr) { const int qi = 32 * s + rr; if (qi < g.Q && Qs[qi] == ch) mq |= 1u << rr; }
+                    Eq = mq;
+                }
+                const uint32_t Xv = Eq | M;
+                const uint32_t Eq2 = Eq | hm;
+                const uint32_t Xh = (((Eq2 & P) + P) ^ P) | Eq2;
+                const uint32_t Ph = M | ~(Xh | P);
+                const uint32_t Mh = P & Xh;
+                const uint32_t PhS = (Ph << 1) | hp;
+                const uint32_t MhS = (Mh << 1) | hm;
+                P = MhS | ~(Xv | PhS);
+                M = PhS & Xv;
+                if (act && keep) *(BRX_GLOBAL uint64_t *)(row0 + 8 * (size_t)c * wsp + slot8) = ((uint64_t)Ph << 32) | (uint64_t)P;
+                accP = (accP << 1) | (Ph >> 31);
+                accM = (accM << 1) | (Mh >> 31);
+            }
         } else {
             column(0, std::false_type{}); column(1, std::false_type{}); column(2, std::false_type{}); column(3, std::false_type{});
+            if (act && keep) {                                     /* uint2 {pv, Ph} per column */
+                *(BRX_GLOBAL uint64_t *)(row0 + slot8) = ((uint64_t)phs[0] << 32) | (uint64_t)pvs[0];
+                *(BRX_GLOBAL uint64_t *)(row1 + slot8) = ((uint64_t)phs[1] << 32) | (uint64_t)pvs[1];
+                *(BRX_GLOBAL uint64_t *)(row2 + slot8) = ((uint64_t)phs[2] << 32) | (uint64_t)pvs[2];
+                *(BRX_GLOBAL uint64_t *)(row3 + slot8) = ((uint64_t)phs[3] << 32) | (uint64_t)pvs[3];
+            }
         }
-        carry = out;
+        Pv = act ? P : Pv;
+        Mv = act ? M : Mv;
+        carry = act ? ((accP << 4) | accM) : 0xF0u;
 
         /* ---- a superblock leaves the band: its lane takes superblock s + 64 ---- */
         if (__builtin_expect(tau == next_hop, 0)) {

@@ -41,7 +41,8 @@ struct brx_ctx {
     uint32_t final_launches, mutate_passes;
     int mutate_inline;
     uint32_t seg_waves_per_cu;   /* BRX_SEG_WAVES_PER_CU: persistent waves of k_mutate_seg per CU */
-    uint32_t tail_reads;         /* BRX_TAIL_READS: this few reads left in the mutate stage -> one in-place launch */
+    uint32_t tail_reads;         /* BRX_TAIL_READS: this few reads left in the mutate stage -> one in-place launch (0xFFFFFFFF = not set: n_reads / 12, at least 1024;
+                                    measured on configs[3]: 1024 of 16384, 4096 of 49152) */
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
@@ -168,7 +169,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
     { const char *pf = getenv("BRX_PROFILE"); c->profile = (pf && atoi(pf)) ? 1 : 0; }
     { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
-    { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 1024u; }
+    { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 0xFFFFFFFFu; }   /* unset: a twelfth of the batch, at least 1024 */
     { const char *sw = getenv("BRX_SEG_WAVES_PER_CU"); c->seg_waves_per_cu = sw && atoi(sw) > 0 ? (uint32_t)atoi(sw) : 8u; }
     { const char *lt = getenv("BRX_LANE_THRESHOLD"); c->lane_threshold = lt ? (uint32_t)atoi(lt) : 3000u; }
     c->err[0] = 0;
@@ -368,8 +369,9 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     uint2 *lane_tb = use_wg ? nullptr : (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
     /* traceback stores of the packed window aligner: one set of 8 per workgroup of k_mutate_wg, or per wave of k_win_pack */
     const uint32_t pack_waves = std::min<uint32_t>((std::min<uint32_t>(n_reads, c->lane_threshold) + BRX_PACK_NG - 1) / BRX_PACK_NG, (uint32_t)c->n_cu * 4u);
-    const bool all_head = c->mutate_inline || (!use_wg && n_reads <= c->tail_reads);      /* the whole batch in one run-to-completion launch */
-    const uint32_t run_blocks = ((all_head ? n_reads : std::min<uint32_t>(n_reads, std::max<uint32_t>(c->tail_reads, 1u))) + BRX_WG_WAVES - 1) / BRX_WG_WAVES;   /* the tail (or everything) as k_mutate_wg */
+    const uint32_t tail_eff = c->tail_reads != 0xFFFFFFFFu ? c->tail_reads : std::max<uint32_t>(1024u, n_reads / 12u);
+    const bool all_head = c->mutate_inline || (!use_wg && n_reads <= tail_eff);      /* the whole batch in one run-to-completion launch */
+    const uint32_t run_blocks = ((all_head ? n_reads : std::min<uint32_t>(n_reads, std::max<uint32_t>(tail_eff, 1u))) + BRX_WG_WAVES - 1) / BRX_WG_WAVES;   /* the tail (or everything) as k_mutate_wg */
     uint2 *pack_tb = (uint2 *)A.take((size_t)(use_wg ? wg_blocks : std::max<uint32_t>(std::max(pack_waves, run_blocks), 1u)) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
     if (!raw) { KTIMED(BRX_KERN_PLAN, st); hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces); }
@@ -697,7 +699,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         const uint32_t *n_in = mctr + 2 * MC_WORDS + MC_OUT;
         const uint32_t *act_in = order + n_mh;
         uint32_t n_up = n_mb, pass = 0;
-        const uint32_t tail_reads = c->tail_reads;   /* this few reads left: run them to completion in place (no host round trips) */
+        const uint32_t tail_reads = tail_eff;   /* this few reads left: run them to completion in place (no host round trips) */
         auto read_counts = [&](uint32_t *ctr) -> int {
             HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             return wait_stream(c, st, "mutate pass");

@@ -39,8 +39,8 @@ from .version import __version__
 NOFRAG_MESSAGE = ('Error: failed to generate any sequence fragments - are your read lengths '
                   'incompatible with your reference contig lengths?')
 ADJUST_SAMPLES = 100000
-DEFAULT_MAX_BATCH = 16384
-DEFAULT_IN_FLIGHT = 8          # super-batches in flight per GPU (--gpu-streams): what bench.py measures
+DEFAULT_MAX_BATCH = 49152
+DEFAULT_IN_FLIGHT = 6          # super-batches in flight per GPU (--gpu-streams): what bench.py measures
 
 
 # ---------------------------------------------------------------------------------------------

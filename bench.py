@@ -19,9 +19,10 @@ are loaded through the native packer brx_fasta_pack + its sidecar, like a user's
   kpn    configs[1]: 5.5 Mb K. pneumoniae-like reference (3 circular contigs, numpy default_rng(1)), defaults (round 1's line)
 
 A "step" is ONE pass of the whole hot path (plan -> fragments -> mutate -> align -> qscores -> FASTQ bytes) over
-one batch of `--reads-per-step` read indices per GPU (default 131072 reads x 15 kb ~ 2 Gbases; the 30x job is 47 such
-steps per GPU on 8 GPUs).  The batch goes through the C-ABI as `--streams` device batches (brx_simulate_batch, 16384
-reads each by default) that are in flight together, one context + HIP stream + host thread each; device batches of
+one batch of `--reads-per-step` read indices per GPU (default 294912 reads x 15 kb ~ 4.4 Gbases; the 30x job is 21 such
+steps on one GPU).  The batch goes through the C-ABI as `--streams` device batches (brx_simulate_batch, 6 x 49152
+reads by default: measured best on the MI355X among 4..16 batches of 16384..65536 reads -- bigger launches, and
+6 x 42 GB of scratch still fit the 288 GB) that are in flight together, one context + HIP stream + host thread each; device batches of
 consecutive steps follow each other without a barrier, exactly as the CLI driver runs them
 (badread_amd.simulate.run_batches).  Inputs (packed reference, model tables) are resident in HBM before the timed
 region; the FASTQ bytes stay in HBM (`--d2h` adds the PCIe-inclusive rate as `value_incl_d2h`).  Weak scaling: every
@@ -252,10 +253,10 @@ def main():
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='human', choices=sorted(WORKLOADS))
-    ap.add_argument('--reads-per-step', type=int, default=131072,
+    ap.add_argument('--reads-per-step', type=int, default=294912,
                     help='read indices per GPU per step; split into --streams device batches')
-    ap.add_argument('--scratch-gb', type=float, default=30.0, help='scratch arena per in-flight batch')
-    ap.add_argument('--streams', type=int, default=8,
+    ap.add_argument('--scratch-gb', type=float, default=42.0, help='scratch arena per in-flight batch')
+    ap.add_argument('--streams', type=int, default=6,
                     help='device batches in flight per GPU (one context + HIP stream + host thread each): the slowest '
                          'read of one device batch overlaps the bulk of the others')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='seconds each host core runs the cpu_baseline leg (0 = skip)')
