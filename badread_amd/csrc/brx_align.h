@@ -261,12 +261,13 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
      * needs no tag.  carry: 0 = lane above idle (top of the band: +1), 1/2/3 = hout -1/0/+1. */
     int s = lane;
     int tf = NEVER, tl = NEVER, slot = 0;
-    if (s < g.NS) { tf = brx_jfirst(g, s) + s; tl = brx_jlast(g, s) + s; slot = s % g.WSp; }
+    uint32_t tspan = 0;                              /* step t is computed iff (uint32_t)(t - tf) <= tspan */
+    if (s < g.NS) { tf = brx_jfirst(g, s) + s; tl = brx_jlast(g, s) + s; slot = s % g.WSp; tspan = tl >= tf ? (uint32_t)(tl - tf) : 0u; if (tl < tf) tf = NEVER; }
     uint32_t Pv[G], Mv[G];
     BrxQPlanes qp[G];
 #pragma unroll
     for (int x = 0; x < G; ++x) { Pv[x] = 0xFFFFFFFFu; Mv[x] = 0; qp[x] = BrxQPlanes{0u, 0u, 0u, 0u}; }
-    uint32_t carry = 0;
+    uint32_t carry = 2u;                             /* an idle lane hands on +1 */
     /* windowed traceback store (brx_stored), incrementally: acc = slope * column, exact in 64 bits */
     const uint32_t keep_lim = (uint32_t)(2 * g.H + g.R - 1);
     int keep_base = g.R * s + g.H + g.R - 1;
@@ -328,44 +329,44 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
         /* ---- the column update: straight-line VALU code, lanes outside the band discard the result ---- */
         const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
         const uint32_t c = cnext;
-        const uint32_t actm = ~(uint32_t)(((t - tf) | (tl - t)) >> 31);        /* all ones iff tf <= t <= tl */
-        uint32_t hp = (0x9u >> nb) & 1u, hm = (0x2u >> nb) & 1u;
+        const bool act = (uint32_t)(t - tf) <= tspan;                          /* tf <= t <= tl */
+        uint32_t hp = nb >> 1, hm = nb & 1u;                                   /* carry: bit 1 = hout +1, bit 0 = hout -1 */
         const uint32_t k0 = 0u - (c & 1u), k1 = 0u - ((c >> 1) & 1u), k4 = 0u - ((c >> 2) & 1u);
-        const bool rare = __builtin_expect(odd != 0u, 0) && __ballot(actm != 0u && c > 4u) != 0ull;
+        const bool rare = __builtin_expect(odd != 0u, 0) && __ballot(act && c > 4u) != 0ull;
         const bool keep = (uint32_t)(keep_base - (int)(uint32_t)((uint64_t)acc >> 20)) <= keep_lim;   /* windowed traceback store */
+        const bool put = act && keep;
 #pragma unroll
         for (int x = 0; x < G; ++x) {
-            /* symbol select by mask arithmetic (v_bfi), NOT by ?: over the array -- hipcc folds a select
-               chain over the elements of a private array into one dynamically indexed load, which pins
-               the array in scratch memory (a vmcnt-ordered load per column) */
+            /* Words past the last query row (only the last superblock has them) are computed like the others: their planes
+               are empty, their stores land in slots nothing reads, and the carry they hand on leaves the matrix. */
             uint32_t Eq = brx_bfi(k4, qp[x].n, brx_eq_acgt(qp[x], k0, k1));
-            if (rare) { if (actm != 0u && c > 4u && s * G + x < g.NW) Eq = brx_eq_rare(Qs, g.Q, s * G + x, c); }
-            uint32_t pv = Pv[x], mv = Mv[x];
-            const uint32_t Xv = Eq | mv;
+            if (rare) { if (act && c > 4u && s * G + x < g.NW) Eq = brx_eq_rare(Qs, g.Q, s * G + x, c); }
+            const uint32_t pv0 = Pv[x], mv0 = Mv[x];
+            const uint32_t Xv = Eq | mv0;
             const uint32_t Eq2 = Eq | hm;
-            const uint32_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
-            const uint32_t Ph = mv | ~(Xh | pv);
-            const uint32_t Mh = pv & Xh;
+            const uint32_t Xh = (((Eq2 & pv0) + pv0) ^ pv0) | Eq2;
+            const uint32_t Ph = mv0 | ~(Xh | pv0);
+            const uint32_t Mh = pv0 & Xh;
             const uint32_t PhS = (Ph << 1) | hp;
             const uint32_t MhS = (Mh << 1) | hm;
-            pv = MhS | ~(Xv | PhS);
-            mv = PhS & Xv;
-            uint32_t livem = actm;
-            if (G > 1) livem &= 0u - (uint32_t)(s * G + x < g.NW);            /* words past the last query row do not exist */
-            Pv[x] = brx_bfi(livem, pv, Pv[x]);
-            Mv[x] = brx_bfi(livem, mv, Mv[x]);
-            if (livem && keep) dst[x] = make_uint2(pv, Ph);
-            hp = brx_bfi(livem, Ph >> 31, hp);
-            hm = brx_bfi(livem, Mh >> 31, hm);
+            const uint32_t pv = MhS | ~(Xv | PhS);
+            const uint32_t mv = PhS & Xv;
+            Pv[x] = act ? pv : pv0;
+            Mv[x] = act ? mv : mv0;
+            if (put) dst[x] = make_uint2(pv, Ph);
+            hp = Ph >> 31;
+            hm = Mh >> 31;
         }
-        carry = (hp + 2u - hm) & actm;
+        carry = act ? ((hp << 1) | hm) : 2u;
 
         /* ---- a superblock leaves the band: its lane takes superblock s + 64 ---- */
         if (__builtin_expect(t == next_hop, 0)) {
             if (t >= tl) {
                 s += 64;
+                tspan = 0;
                 if (s < g.NS) {
                     tf = brx_jfirst(g, s) + s; tl = brx_jlast(g, s) + s;
+                    if (tl >= tf) tspan = (uint32_t)(tl - tf); else tf = NEVER;
                     const int nslot = s % g.WSp;
                     dst += ((ptrdiff_t)nslot - (ptrdiff_t)slot) * (ptrdiff_t)G;
                     slot = nslot;

@@ -26,7 +26,7 @@ def main():
                'FETCH_SIZE_KB_per_launch': fetch, 'WRITE_SIZE_KB_per_launch': write,
                'hbm_bytes_per_launch': (2.0 * fetch + write) * 1024.0,
                'note': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh: bench.py --steps 1 '
-                       f'--warmup 1 --streams 1 --reads-per-step 16384; the dispatches include the 64-read priming call), mean over {nf} / {nw} dispatches; FETCH_SIZE doubled per MI355X_MICROARCH.md '
+                       f'--warmup 1 --streams 1 --reads-per-step 49152; the dispatches include the 64-read priming call), mean over {nf} / {nw} dispatches; FETCH_SIZE doubled per MI355X_MICROARCH.md '
                        f'(gfx950 counts 128-B requests as 64 B; calibrated for wide streaming reads only: upper estimate '
                        f'here); WRITE_SIZE as reported (KB)'}, sys.stdout, indent=1)
     print()

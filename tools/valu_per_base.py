@@ -1,7 +1,7 @@
 """SQ_INSTS_VALU per simulated base from a PMC pass (tools/profile_round.sh): what bench.py's `roofline_alu` multiplies by
 the measured bases/s.    python tools/valu_per_base.py <pmc_per_kernel.csv> <bench json of the same run> <workload> <tag>
 
-The PMC run is `bench.py --steps 1 --warmup 1 --streams 1 --reads-per-step 16384`: two device batches of 16384 reads run one
+The PMC run is `bench.py --steps 1 --warmup 1 --streams 1 --reads-per-step 49152`: two device batches of 49152 reads run one
 after the other (warm-up + timed) plus the 64-read priming call, all counted; bases = both batches (the priming call's
 64 reads are < 0.3 % and ignored)."""
 import csv
@@ -23,7 +23,7 @@ def main():
     out = {workload: {'valu_per_base': total / bases, 'bases_counted': bases, 'device_batches': batches,
                       'per_kernel_valu_per_base': {k: v / bases for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])[:12]},
                       'source': f'profiles/{tag}_pmc_per_kernel.csv: rocprofv3 --pmc SQ_INSTS_VALU ... --kernel-trace, bench.py --workload {workload} '
-                                f'--steps 1 --warmup 1 --streams 1 --reads-per-step 16384'}}
+                                f'--steps 1 --warmup 1 --streams 1 --reads-per-step 49152'}}
     json.dump(out, sys.stdout, indent=1)
     print()
 
