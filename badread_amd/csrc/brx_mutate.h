@@ -27,10 +27,17 @@
 #define BRX_MUTATE_H
 
 #define BRX_WIN_Q 1024                                   /* slot bytes reserved for the window of F           */
-#define BRX_WIN_STRIDE 5120                              /* slot bytes per read: [0,1024) query, then target  */
-#define BRX_WIN_TMAX (BRX_WIN_STRIDE - BRX_WIN_Q - 16)   /* longer joined windows go to the legacy kernel     */
+#define BRX_WIN_BYTES 5120                               /* byte part of a slot: [0,1024) query, then target  */
+#define BRX_WIN_TMAX (BRX_WIN_BYTES - BRX_WIN_Q - 16)    /* longer joined windows go to the legacy kernel     */
 #define BRX_LANE_TMAX 1536                               /* lane kernel: target columns held in LDS planes    */
+/* behind the bytes: the same pair as 2-bit planes (32-bit words: query lo[32] hi[32], target lo[48] hi[48]), written by
+   the parking wave for windows bound for the lane kernel -- 64 symbols per ballot in the wave that has just written
+   them, instead of 64 windows x 32 dependent loads in front of every lane-kernel wave (measured: 0.59 of its 2.1 ms) */
+#define BRX_WIN_PLANES BRX_WIN_BYTES
+#define BRX_WIN_PLANE_WORDS (2 * 32 + 2 * (BRX_LANE_TMAX / 32))
+#define BRX_WIN_STRIDE (BRX_WIN_BYTES + 4 * BRX_WIN_PLANE_WORDS)   /* slot bytes per read */
 #define BRX_LANE_W 8                                     /* lane kernel: band blocks alive in one column      */
+#define BRX_LANE_TBC 16                                  /* lane kernel: traceback columns fetched per round  */
 #define BRX_LANE_TB_UNITS ((uint64_t)(BRX_LANE_TMAX + 1) * BRX_LANE_W * 64)   /* uint2 units per wave       */
 
 struct MS {                       /* loop state of a parked read */
@@ -256,6 +263,21 @@ __global__ void __launch_bounds__(64 * BRX_SEG_WAVES, 4) k_mutate_seg(BrxDev d, 
                             const bool easy = !INLINE && !odd && g.G == 1 && tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 &&
                                               (n_in > lane_threshold ? band_blocks <= BRX_LANE_W : brx_pack_eligible(ql, tl, cost, odd));
                             klass = easy ? MC_EASY : MC_HARD;
+                            if (easy) {         /* may go to k_win_lane (the host picks by its own, older count): the pair as bit planes */
+                                uint32_t *pl = reinterpret_cast<uint32_t *>(qb + BRX_WIN_PLANES);
+                                for (uint32_t it = 0; 64u * it < ql; ++it) {
+                                    const uint32_t x = 64u * it + (uint32_t)lane;
+                                    const uint32_t c = x < ql ? qb[x] : 0u;
+                                    const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
+                                    if (lane < 2) { pl[2 * it + lane] = (uint32_t)(lo >> (32 * lane)); pl[32 + 2 * it + lane] = (uint32_t)(hi >> (32 * lane)); }
+                                }
+                                for (uint32_t it = 0; 64u * it < tl; ++it) {
+                                    const uint32_t x = 64u * it + (uint32_t)lane;
+                                    const uint32_t c = x < tl ? tbuf[x] : 0u;
+                                    const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
+                                    if (lane < 2) { pl[64 + 2 * it + lane] = (uint32_t)(lo >> (32 * lane)); pl[64 + BRX_LANE_TMAX / 32 + 2 * it + lane] = (uint32_t)(hi >> (32 * lane)); }
+                                }
+                            }
                         }
                         {
                             MS o = ms;
@@ -385,29 +407,18 @@ __global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, c
         if (valid) ms = msv[r];
         const int Q = valid ? (int)(ms.win_b - ms.win_a) : 0, T = valid ? (int)ms.tl : 0, kb = valid ? (int)ms.cost : 0;
 
-        /* ---- pack the 64 window pairs into bit planes, one request at a time, all lanes helping ---- */
-        for (int i = 0; i < 64; ++i) {
-            const uint32_t ri = wave_bcast_u32(r, i);
-            const int Qi = (int)wave_bcast_u32((uint32_t)Q, i), Ti = (int)wave_bcast_u32((uint32_t)T, i);
-            if (Qi == 0) continue;
-            const uint8_t *qb = winbuf + (uint64_t)ri * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
-            for (int p = 0; 64 * p < Qi; ++p) {
-                const int x = 64 * p + lane;
-                const uint32_t c = x < Qi ? qb[x] : 0u;
-                const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
-                if (lane < 2) {
-                    q_lo[2 * p + lane][i] = (uint32_t)(lo >> (32 * lane));
-                    q_hi[2 * p + lane][i] = (uint32_t)(hi >> (32 * lane));
-                }
+        /* ---- the window pair of every lane as bit planes: written by the parking wave behind the bytes of its slot ---- */
+        {
+            const uint32_t *pl = reinterpret_cast<const uint32_t *>(winbuf + (uint64_t)r * BRX_WIN_STRIDE + BRX_WIN_PLANES);
+            const int nq = (Q + 31) >> 5, nt = (T + 31) >> 5;
+            const int nq_max = (int)wave_max_u32((uint32_t)nq), nt_max = (int)wave_max_u32((uint32_t)nt);
+            for (int w = 0; w < nq_max; ++w) {
+                const bool in = w < nq;
+                q_lo[w][lane] = in ? pl[w] : 0u; q_hi[w][lane] = in ? pl[32 + w] : 0u;
             }
-            for (int p = 0; 64 * p < Ti; ++p) {
-                const int x = 64 * p + lane;
-                const uint32_t c = x < Ti ? tbuf[x] : 0u;
-                const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
-                if (lane < 2) {
-                    t_lo[2 * p + lane][i] = (uint32_t)(lo >> (32 * lane));
-                    t_hi[2 * p + lane][i] = (uint32_t)(hi >> (32 * lane));
-                }
+            for (int w = 0; w < nt_max; ++w) {
+                const bool in = w < nt;
+                t_lo[w][lane] = in ? pl[64 + w] : 0u; t_hi[w][lane] = in ? pl[64 + BRX_LANE_TMAX / 32 + w] : 0u;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -442,8 +453,9 @@ __global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, c
             uint32_t P[BRX_LANE_W], M[BRX_LANE_W], QL[BRX_LANE_W], QH[BRX_LANE_W];
 #pragma unroll
             for (int x = 0; x < BRX_LANE_W; ++x) {
+                if (x >= Wb) break;                                /* Wb: widest band of the wave's windows, in blocks */
                 const int sb = s_lo + x;
-                const bool on = act && x < Wb && sb <= s_hi;
+                const bool on = act && sb <= s_hi;
                 const int sbc = on ? sb : 0;
                 const int slot = sbc & (BRX_LANE_W - 1);
                 P[x] = st_pv[slot][lane]; M[x] = st_mv[slot][lane];
@@ -479,7 +491,11 @@ __global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
 
-        /* ---- traceback, canonical (up, left, diagonal), 8 columns fetched per round trip ---- */
+        /* ---- traceback, canonical (up, left, diagonal), BRX_LANE_TBC columns fetched per round trip ----
+           A lane owns its window, so the walk is bit arithmetic on the two words it holds per column (block s0 of the row
+           it starts the round in, and s0 - 1): the run of up moves in a column is the run of set Pv bits below the current
+           row (one count-leading-zeros), then the Ph bit of the row it stops in says left or diagonal.  No per-move loop, no
+           ballots inside a round; a climb that leaves the two fetched blocks ends the lane's round early. */
         int i = Q, j = T;
         uint32_t ncols = 0, nmatch = 0;
         bool ok = valid;
@@ -487,9 +503,9 @@ __global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, c
         while (__ballot(go) != 0ull) {
             const int s0 = go ? ((i - 1) >> 5) : 0;           /* block of the current row; rows may cross into s0 - 1 */
             const int jst = j;
-            uint2 A[8], Bv[8];
+            uint2 A[BRX_LANE_TBC], Bv[BRX_LANE_TBC];
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
+            for (int x = 0; x < BRX_LANE_TBC; ++x) {
                 const int col = jst - x;
                 A[x] = make_uint2(0u, 0u); Bv[x] = make_uint2(0u, 0u);
                 if (go && col >= 1) {
@@ -499,35 +515,44 @@ __global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, c
             }
             bool walk = go;
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                /* column jst - x: climb while the vertical delta is +1, then leave leftwards or diagonally */
-                for (int guard = 0; guard < 72; ++guard) {
-                    const bool here = walk && i > 0 && j == jst - x && j > 0;
-                    if (__ballot(here) == 0ull) break;
-                    if (here) {
+            for (int x = 0; x < BRX_LANE_TBC; ++x) {
+                /* column jst - x (every completed column moves the lane exactly one column left) */
+                bool done = !(walk && i > 0 && j > 0);
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {             /* at most two blocks per column per round */
+                    if (!done) {
                         const int sb = (i - 1) >> 5;
-                        if (sb != s0 && sb != s0 - 1) walk = false;                 /* left the two fetched blocks: refetch */
+                        if (sb != s0 && sb != s0 - 1) { walk = false; done = true; }     /* left the two fetched blocks: refetch */
                         else {
                             const int jf = 32 * sb - g.dhi + 1 < 1 ? 1 : 32 * sb - g.dhi + 1;
                             long long jl = 32ll * (sb + 1) - g.dlo; if (jl > T) jl = T;
-                            if (j < jf || j > jl) { ok = false; walk = false; go = false; }
+                            if (j < jf || j > jl) { ok = false; walk = false; go = false; done = true; }
                             else {
-                                const uint32_t sel = 0u - (uint32_t)(sb == s0);
-                                const uint32_t vx = (A[x].x & sel) | (Bv[x].x & ~sel), vy = (A[x].y & sel) | (Bv[x].y & ~sel);
+                                const bool top = sb == s0;
+                                const uint32_t vx = top ? A[x].x : Bv[x].x, vy = top ? A[x].y : Bv[x].y;
                                 const int bit = (i - 1) & 31;
-                                if ((vx >> bit) & 1u) { i -= 1; ncols += 1; }
-                                else if ((vy >> bit) & 1u) { j -= 1; ncols += 1; }
-                                else {
-                                    const int qi_ = i - 1, tj = j - 1;
-                                    const uint32_t qc = ((q_lo[qi_ >> 5][lane] >> (qi_ & 31)) & 1u) | (((q_hi[qi_ >> 5][lane] >> (qi_ & 31)) & 1u) << 1);
-                                    const uint32_t tc = ((t_lo[tj >> 5][lane] >> (tj & 31)) & 1u) | (((t_hi[tj >> 5][lane] >> (tj & 31)) & 1u) << 1);
-                                    nmatch += (uint32_t)(qc == tc);
-                                    i -= 1; j -= 1; ncols += 1;
+                                const uint32_t stay = ~vx & (0xFFFFFFFFu >> (31 - bit));   /* rows of the block, at or above this one, that do not move up */
+                                if (stay == 0u) {                  /* up all the way out of the block */
+                                    i -= bit + 1; ncols += (uint32_t)(bit + 1);
+                                    if (i == 0) done = true;
+                                } else {
+                                    const int row = 31 - __clz((int)stay);
+                                    i -= bit - row; ncols += (uint32_t)(bit - row);
+                                    if ((vy >> row) & 1u) { j -= 1; ncols += 1; }
+                                    else {
+                                        const int qi_ = i - 1, tj = j - 1;
+                                        const uint32_t qc = ((q_lo[qi_ >> 5][lane] >> (qi_ & 31)) & 1u) | (((q_hi[qi_ >> 5][lane] >> (qi_ & 31)) & 1u) << 1);
+                                        const uint32_t tc = ((t_lo[tj >> 5][lane] >> (tj & 31)) & 1u) | (((t_hi[tj >> 5][lane] >> (tj & 31)) & 1u) << 1);
+                                        nmatch += (uint32_t)(qc == tc);
+                                        i -= 1; j -= 1; ncols += 1;
+                                    }
+                                    done = true;
                                 }
                             }
                         }
                     }
                 }
+                if (!done) walk = false;                           /* a third block in one column: next round */
             }
             go = go && ok && i > 0 && j > 0;
         }
