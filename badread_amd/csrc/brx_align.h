@@ -82,7 +82,7 @@ __host__ __device__ inline uint32_t brx_isqrt(uint32_t v) {
  * Pv/Ph bit, are unchanged), but only the superblocks that intersect rows [c(j) - H, c(j) + H] of column j,
  * c(j) = j*Q/T, are written to the traceback store.  The canonical path of an alignment with k edits strays
  * from that straight line like a random walk of ~k steps (measured: at most 1.5 sqrt(distance) rows on
- * nanopore2023 reads of 2-60 kb), so with H = hmul sqrt(k) + 24, hmul = 4, the traceback practically never asks
+ * nanopore2023 reads of 2-60 kb), so with H = hmul sqrt(k) + 24, hmul = 2 (BRX_TB_WINDOW; measured on configs[3]: 4 -> 2.84, 3 -> 2.92, 2 -> 2.98 Gbases/s with no miss, 1 -> 2.9 with 110 misses per 295 k reads), the traceback practically never asks
  * for a cell that was not stored (hmul < 0: H = 8, a test setting that makes most reads miss); when it does, the alignment reports failure and the caller repeats it with the full
  * store.  A traceback that succeeds read exactly the bits the full store would have held: same result. */
 __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul = 0) {
