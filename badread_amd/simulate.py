@@ -347,17 +347,13 @@ class _HostRing(object):
 
 
 class _BatchPool(object):
-    """`in_flight` engines (the given one + clones sharing its device tables), each driven by a host thread on its own HIP
-    stream, so that several batches overlap on the GPU.  Jobs start in submission order on whichever engine is idle; a job
-    returns a COPY of the batch's FASTQ bytes (a device tensor on the GPU engines: 1.5 GB at HBM speed) and its per-read
-    statistics and hands its engine straight back, so an engine never waits for the consumer, which takes the batches in
-    index order (measured through the driver, configs[3], /dev/null: engines released by the consumer 1.5 Gbases/s -- a
-    finished batch behind a slower, earlier one kept its engine idle).  `depth` bounds the jobs outstanding (computing +
-    finished but not yet consumed) and with them the device memory of the copies."""
+    """`in_flight` engines (the given one + clones sharing its device tables), each driven by its own host thread on
+    its own HIP stream, so that several batches overlap on the GPU.  A job returns the batch's FASTQ bytes WHERE THEY
+    ARE (a device tensor on the GPU engines) and its per-read statistics; the consumer copies out only the bytes it
+    keeps and then releases the engine."""
 
     def __init__(self, engine, in_flight):
         import concurrent.futures
-        import queue
         self.engines = [engine]
         self.streams = [None]
         torch = getattr(engine, 'torch', None)           # absent on the tests' CPU checker engines
@@ -369,51 +365,42 @@ class _BatchPool(object):
             self.engines += [None] * (in_flight - 1)
         elif self.on_gpu:
             self.streams = [torch.cuda.Stream(device=engine.device)]
-        n = len(self.engines)
-        self.idle = queue.Queue()
-        for i in range(n):
-            self.idle.put(i)                             # engine 0 exists already: it takes the first batch
-        self.depth = n + max(1, n // 2) if n > 1 else 1
-        self.clone_seconds = 0.0
-        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=n) if n > 1 else None
+        self.free = list(range(len(self.engines)))
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=len(self.engines)) if len(self.engines) > 1 else None
 
     def __len__(self):
         return len(self.engines)
 
     def submit(self, seed, first, n_mine):
+        i = self.free.pop(0)                             # engine 0 exists already: it takes the first batch
+        stream = self.streams[i]
+
         def job():
             import torch
-            i = self.idle.get()
-            try:
-                stream = self.streams[i]
-                if self.engines[i] is None:
-                    if self.on_gpu:
-                        torch.cuda.set_device(self.engines[0].device)
-                    self.engines[i] = self.engines[0].clone()
-                eng = self.engines[i]
-                if n_mine == 0:
-                    return torch.zeros(0, dtype=torch.uint8), np.zeros(0, dtype=eng.stats_dtype)
-                if not self.on_gpu:
-                    out, stats = eng.simulate_batch(seed, first, n_mine, allow_nofrag=True)
-                    return torch.from_numpy(np.ascontiguousarray(out).copy()), stats.copy()
-                torch.cuda.set_device(eng.device)
-                with torch.cuda.stream(stream):
-                    out, stats = eng.simulate_batch_device(seed, first, n_mine, allow_nofrag=True)
-                    stats = stats.copy()
-                    t0 = time.perf_counter()
-                    nbytes = int(stats['rec_off'][-1] + stats['rec_len'][-1]) if len(stats) else 0
-                    out = out[:nbytes].clone()           # the engine's buffer is overwritten by its next batch
-                    stream.synchronize()
-                    self.clone_seconds += time.perf_counter() - t0
-                    return out, stats
-            finally:
-                self.idle.put(i)
+            if self.engines[i] is None:
+                if self.on_gpu:
+                    torch.cuda.set_device(self.engines[0].device)
+                self.engines[i] = self.engines[0].clone()
+            eng = self.engines[i]
+            if n_mine == 0:
+                return torch.zeros(0, dtype=torch.uint8), np.zeros(0, dtype=eng.stats_dtype)
+            if not self.on_gpu:
+                out, stats = eng.simulate_batch(seed, first, n_mine, allow_nofrag=True)
+                return torch.from_numpy(np.ascontiguousarray(out).copy()), stats.copy()
+            torch.cuda.set_device(eng.device)
+            with torch.cuda.stream(stream):
+                out, stats = eng.simulate_batch_device(seed, first, n_mine, allow_nofrag=True)
+                stream.synchronize()
+                return out, stats.copy()                 # `out` is the engine's buffer: valid until release(i)
         if self.pool is None:
             class _Done(object):
                 def __init__(self, v): self.v = v
                 def result(self): return self.v
-            return _Done(job())
-        return self.pool.submit(job)
+            return i, _Done(job())
+        return i, self.pool.submit(job)
+
+    def release(self, i):
+        self.free.append(i)
 
     def close(self):
         if self.pool is not None:
@@ -463,28 +450,28 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             buf = dev_staging['buf'] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
         return buf[:nbytes]
 
-    pending = collections.deque()          # (future, first_of_super_batch, n_super, first, n_mine)
+    pending = collections.deque()          # (slot, future, first_of_super_batch, n_super, first, n_mine)
     fatal = bad_read = None
 
     def fill():
         """Keep the pipeline full: what is outstanding is assumed to deliver its expected number of bases.  Called at
         points that depend only on consumed totals, so every rank issues the same batches."""
         nonlocal next_read
-        while len(pending) < pool.depth:
-            outstanding = sum(p[2] for p in pending) * expected_mean
+        while len(pending) < len(pool) and pool.free:
+            outstanding = sum(p[3] for p in pending) * expected_mean
             remaining = target_size - total - outstanding
             if remaining <= 0 and pending:
                 break
             n_super = plan_batch(max(remaining, 1), expected_mean, shard.world, max_batch)
             first, n_mine = shard.slice_of(next_read, n_super)
-            fut = pool.submit(seed, first, n_mine)
-            pending.append((fut, next_read, n_super, first, n_mine))
+            slot, fut = pool.submit(seed, first, n_mine)
+            pending.append((slot, fut, next_read, n_super, first, n_mine))
             next_read += n_super
 
     try:
         while total < target_size:
             fill()
-            fut, base, n_super, first, n_mine = pending.popleft()
+            slot, fut, base, n_super, first, n_mine = pending.popleft()
             t0 = time.perf_counter()
             out, stats = fut.result()
             timing['wait_for_batch'] += time.perf_counter() - t0
@@ -515,7 +502,13 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             if shard.world > 1:
                 sizes = [int(x[0]) for x in shard.gather_words(np.array([my_bytes], dtype=np.uint32), [1] * shard.world)]
                 assert my_bytes < 2 ** 32
-            out = out[:my_bytes]
+            # the engine goes back to work at once: its kept bytes are copied device-to-device first (0.5 GB at HBM speed),
+            # the slower hops (PCIe into the pinned ring, or the send to rank 0) read that copy
+            t0 = time.perf_counter()
+            if pool.on_gpu and my_bytes:
+                out = out[:my_bytes].clone()
+            timing['clone'] += time.perf_counter() - t0
+            pool.release(slot)                      # the engine's output buffer may be overwritten from here on
             used = lens[:last + 1]
             count += int((used > 0).sum())
             total += int(used.sum())
@@ -523,7 +516,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             if count and not stop:
                 expected_mean = max(total / count, 1.0)
             if not stop and total < target_size:
-                fill()                              # the next batches are queued while this one's bytes leave
+                fill()                              # the freed engine starts its next batch while this one's bytes leave
             t0 = time.perf_counter()
             for _, part in shard.collect_bytes(out, sizes, staging):
                 ring.write(part)                    # rank 0: through pinned memory to the writer thread
@@ -533,7 +526,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             if stop:
                 break
     finally:
-        for fut, *_ in pending:             # speculative batches past the stopping read
+        for slot, fut, *_ in pending:       # speculative batches past the stopping read
             try:
                 fut.result()
             except Exception:
@@ -541,7 +534,6 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         t0 = time.perf_counter()
         pool.close()
         timing['close_engines'] = time.perf_counter() - t0
-        timing['clone'] = pool.clone_seconds
         t0 = time.perf_counter()
         if ring is not None:
             ring.flush()
