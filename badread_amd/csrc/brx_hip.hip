@@ -52,6 +52,9 @@ struct brx_ctx {
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
     int wide_stream;             /* BRX_WIDE_STREAM: the head set's widest band class aligns on a third stream */
     hipStream_t side2;
+    hipStream_t side3, aux;      /* the bulk set's wide band classes; the wave-per-window kernel of a pass (beside the lane kernel) */
+    hipEvent_t ev_pf, ev_pj;     /* fork / join of that kernel */
+    int fin4_wide, wave_stream, bulk_wide;   /* BRX_FIN4_WIDE, BRX_WAVE_STREAM, BRX_BULK_WIDE (see run_pipeline) */
     hipEvent_t ev_fork2[2], ev_join2[2], ev_head_mut;
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
                                     three wide classes: a stream per class measured 30 % slower, r01d) */
@@ -112,6 +115,10 @@ static void release(brx_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->side2) (void)hipStreamDestroy(c->side2);
+    if (c->side3) (void)hipStreamDestroy(c->side3);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->ev_pf) (void)hipEventDestroy(c->ev_pf);
+    if (c->ev_pj) (void)hipEventDestroy(c->ev_pj);
     for (int i = 0; i < 2; ++i) { if (c->ev_fork2[i]) (void)hipEventDestroy(c->ev_fork2[i]); if (c->ev_join2[i]) (void)hipEventDestroy(c->ev_join2[i]); }
     if (c->ev_head_mut) (void)hipEventDestroy(c->ev_head_mut);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -155,6 +162,8 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     }
     if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_pf, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_pj, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     for (int i = 0; i < 2; ++i)
         if ((e = hipEventCreateWithFlags(&c->ev_fork2[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
@@ -164,6 +173,13 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
+    { const char *v = getenv("BRX_FIN4_WIDE"); c->fin4_wide = v ? atoi(v) : 0; }
+    { const char *v = getenv("BRX_WAVE_STREAM"); c->wave_stream = v ? atoi(v) : 0; }
+    { const char *v = getenv("BRX_BULK_WIDE"); c->bulk_wide = v ? atoi(v) : 0; }
+    /* the streams of these experiments exist only when asked for: every stream of a context takes a hardware queue, and two idle
+       extra streams per context (6 contexts) cost 24 % of the rate (measured, A/B on one box: 2.97 -> 2.27 Gbases/s) */
+    if (c->bulk_wide && (e = hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
+    if (c->wave_stream && (e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
@@ -430,7 +446,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     };
     FinalSet sets[2];
     sets[0] = FinalSet{0, n_head, s_head, (c->wide_stream && n_bulk) ? c->side2 : s_head, 0, false, false, 0, 0, {0, 0, 0, 0, 0}};
-    sets[1] = FinalSet{n_head, n_reads, st, st, 1, false, false, 0, 0, {0, 0, 0, 0, 0}};
+    sets[1] = FinalSet{n_head, n_reads, st, (c->bulk_wide && c->wide_stream) ? c->side3 : st, 1, false, false, 0, 0, {0, 0, 0, 0, 0}};
     uint64_t *set_units = units_sorted, *set_tboff = tboff_sorted;      /* staging arrays, indexed by order position */
     std::vector<uint64_t> h_tboff(n_reads), h_units(n_reads);
     /* counters: [0],[3] join queues of head / bulk; [1] flags; [2],[4] window misses of head / bulk;
@@ -520,12 +536,16 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
                 hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
                                    dev, rs, order, b, e, cq + 0, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
             }
-            if (fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
+            /* BRX_FIN4_WIDE: the four-word class follows the widest one on the wide stream instead of leading the set's own stream */
+            const bool four_wide = fork && c->fin4_wide;
+            hipStream_t s4 = four_wide ? S.wide : S.st;
+            if (!four_wide && fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
             if (S.bases_by_class[2] || phase == 1) {
-                KTIMED(BRX_KERN_FIN_ALIGN4, S.st);
-                hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st,
+                KTIMED(BRX_KERN_FIN_ALIGN4, s4);
+                hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, s4,
                                    dev, rs, order, b, e, cq + 4, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
             }
+            if (four_wide) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
             if (S.bases_by_class[1] || phase == 1) {
                 KTIMED(BRX_KERN_FIN_ALIGN2, S.st);
                 hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, S.st,
@@ -538,14 +558,14 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             }
             {
                 KTIMED(BRX_KERN_FIN_QSCORE, S.st);
-                hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 3, phase, 1, 4,
+                hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 3, phase, 1, four_wide ? 2 : 4,
                                    c->scratch, c->scratch, tb_base, clk);
             }
             if (fork) HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join2[S.id], 0));
-            if (S.bases_by_class[3] || phase == 1) {
+            if (S.bases_by_class[3] || (four_wide && S.bases_by_class[2]) || phase == 1) {
                 KTIMED(BRX_KERN_FIN_QSCORE, S.st);
                 hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
-                                   cq + 5, phase, 5, 0xFFFF, c->scratch, c->scratch, tb_base, clk);
+                                   cq + 5, phase, four_wide ? 3 : 5, 0xFFFF, c->scratch, c->scratch, tb_base, clk);
             }
         }
         if (phase == 0) c->final_launches += (uint32_t)chunks.size();
@@ -711,7 +731,8 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         for (; n_up > 0 && pass < (1u << 20); ++pass) {
             uint32_t *ctr = mctr + (pass & 1u) * MC_WORDS;
             uint32_t *act_out = (pass & 1u) ? active_b : active_a;
-            HIPCHK(c, hipMemsetAsync(ctr, 0, MC_WORDS * sizeof(uint32_t), st));
+            /* ctr (this pass's counter block) was zeroed by the previous pass's k_win_wave -- by the memset before the loop for
+               passes 0 and 1 -- instead of a fill kernel per pass on the batch's critical path */
             if (n_up <= tail_reads) {
                 if (c->ktiming) {
                     std::vector<uint32_t> h_act(n_up);
@@ -738,6 +759,19 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
                                        ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                        win, (uint64_t)c->win_bytes, counters + 1, phase);
             }
+            {   /* the windows the lane / pack kernel does not take: one per wave -- beside that kernel on a second stream
+                   (BRX_WAVE_STREAM=1) or after it; it also zeroes the counter block of the NEXT pass */
+                const bool ws_ = c->wave_stream != 0;
+                hipStream_t sw = ws_ ? c->aux : st;
+                if (ws_) { HIPCHK(c, hipEventRecord(c->ev_pf, st)); HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_pf, 0)); }
+                if (ws_) {
+                    KTIMED(BRX_KERN_WIN_WAVE, sw);
+                    hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, sw, msv, req_hard, ctr + MC_HARD,
+                                       ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1, mctr + ((pass + 1) & 1u) * MC_WORDS);
+                    HIPCHK(c, hipEventRecord(c->ev_pj, c->aux));
+                }
+            }
+            const bool ws = c->wave_stream != 0;
             if (n_up > lane_threshold) {
                 KTIMED(BRX_KERN_WIN_LANE, st);
                 hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64)), dim3(64), 0, st, msv, req_easy,
@@ -747,10 +781,11 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
                 hipLaunchKernelGGL(k_win_pack, dim3(std::min(pack_waves, (n_up + BRX_PACK_NG - 1) / BRX_PACK_NG)), dim3(64), 0, st, msv, req_easy,
                                    ctr + MC_EASY, ctr + 6, winbuf, pack_tb);
             }
-            {
+            if (ws) HIPCHK(c, hipStreamWaitEvent(st, c->ev_pj, 0));
+            else {
                 KTIMED(BRX_KERN_WIN_WAVE, st);
                 hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
-                                   ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1);
+                                   ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1, mctr + ((pass + 1) & 1u) * MC_WORDS);
             }
             /* the active count only shrinks: look at it every 4th pass while it is large, every pass near the end */
             if (n_up <= 4 * std::min<uint32_t>(tail_reads, 48u) || n_up <= tail_reads + 64 || (pass & 3u) == 3u) {
@@ -828,6 +863,8 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     if (c->ktiming) {
         if (n_head && n_bulk) HIPCHK(c, hipStreamSynchronize(c->side));
         if (sets[0].wide_forked) HIPCHK(c, hipStreamSynchronize(c->side2));
+        if (sets[1].wide_forked && sets[1].wide != st) HIPCHK(c, hipStreamSynchronize(c->side3));
+        if (c->wave_stream) HIPCHK(c, hipStreamSynchronize(c->aux));
         for (int i = 0; i < c->kev_n; ++i) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, c->kev_b[i], c->kev_e[i]) != hipSuccess) continue;

@@ -361,9 +361,12 @@ __global__ void __launch_bounds__(64 * BRX_SEG_WAVES, 4) k_mutate_seg(BrxDev d, 
  * k_win_wave: one parked window per wave (the windows k_win_lane does not take)
  * ----------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(64, 5) k_win_wave(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr, uint32_t *queue,
-                                                  const uint8_t *winbuf, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags) {
+                                                  const uint8_t *winbuf, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags,
+                                                  uint32_t *next_ctr) {
     const int lane = lane_id();
     const uint32_t n_req = uni(*n_req_ptr);
+    /* the counter block of the NEXT pass: last read (as the input count) by this pass's k_mutate_seg, which is done */
+    if (next_ctr && blockIdx.x == 0 && lane < (int)MC_WORDS) next_ctr[lane] = 0u;
     uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)blockIdx.x * scr_bytes);
     for (;;) {
         const uint32_t qi = wave_pop(queue);
