@@ -70,12 +70,16 @@ SIMULATE_OPTIONS = [
     ]),
     ('MI355X', 'Device options (additive; no effect on the simulated reads)', [
         ('--gpu-batch', dict(type=int, default=None, dest='gpu_batch',
-                             help='Maximum reads per device batch and GPU (default: 16384)')),
+                             help='Maximum reads per device batch and GPU (default: 49152)')),
         ('--gzip', dict(type=int, default=None, dest='gzip_level', metavar='LEVEL',
                         help='Write gzip-compressed FASTQ to stdout, compressed on all host cores (level 0-9); '
                              'default: plain text, as the reference')),
+        ('--gzip-device', dict(action='store_true', dest='gzip_device',
+                               help='Write gzip-compressed FASTQ to stdout, compressed on the GPU before the bytes cross PCIe '
+                                    '(a Huffman code per sequence line and per quality line, no match search: smaller than '
+                                    'gzip -6 on simulated reads, and the host only copies)')),
         ('--gpu-streams', dict(type=int, default=None, dest='gpu_streams',
-                               help='Device batches in flight per GPU, each on its own HIP stream (default: 8)')),
+                               help='Device batches in flight per GPU, each on its own HIP stream (default: 6)')),
     ]),
 ]
 

@@ -1012,3 +1012,51 @@ extern "C" int brx_model_count(brx_ctx *c, int kind, const brx_model_job *job, v
     if (flags[0] & 1u) return fail(c, BRX_E_OUTPUT, "model builder: hash table full");
     return BRX_OK;
 }
+
+/* f2: gzip members on the device (brx_gzip_dev.h) */
+static BrxGzConst gz_const() {
+    BrxGzConst K;
+    K.x2n[0] = 0x40000000u;
+    for (int i = 1; i < 32; ++i) K.x2n[i] = brx_gz_mulmod(K.x2n[i - 1], K.x2n[i - 1]);
+    return K;
+}
+extern "C" size_t brx_gzip_device_bound(size_t n_bytes, uint32_t n_blocks) {
+    if (!n_bytes) return 8;
+    const size_t nb = n_blocks ? n_blocks : (n_bytes + BRX_GZ_BLOCK - 1) / BRX_GZ_BLOCK;
+    return nb * (size_t)brx_gz_member_bound(0) + (15 * n_bytes + 7) / 8 + nb + 16;      /* sum over the blocks of brx_gz_member_bound(len) */
+}
+extern "C" size_t brx_gzip_device_scratch(size_t n_bytes, uint32_t n_blocks) {
+    const size_t nb = n_blocks ? n_blocks : (n_bytes + BRX_GZ_BLOCK - 1) / BRX_GZ_BLOCK;
+    return nb * (size_t)(4 * BRX_GZ_TAB + 4 * BRX_GZ_OFFS + 8) + (nb + 1) * 8 + 1024;
+}
+extern "C" int brx_gzip_device(brx_ctx *c, const void *d_in, size_t n_bytes, const uint64_t *d_block_off, uint32_t n_blocks, void *d_out, size_t out_cap,
+                               void *d_scratch, size_t scratch_bytes, size_t *out_bytes, void *hip_stream) {
+    if (!c || !out_bytes || (n_bytes && (!d_in || !d_out || !d_scratch)) || (d_block_off && !n_blocks)) return BRX_E_ARG;
+    *out_bytes = 0;
+    if (!n_bytes) return BRX_OK;
+    if ((uintptr_t)d_out & 3u) return fail(c, BRX_E_ARG, "brx_gzip_device: the output buffer must be 4-byte aligned");
+    const uint32_t nb = d_block_off ? n_blocks : (uint32_t)((n_bytes + BRX_GZ_BLOCK - 1) / BRX_GZ_BLOCK);
+    if (scratch_bytes < brx_gzip_device_scratch(n_bytes, nb)) return fail(c, BRX_E_SCRATCH, "brx_gzip_device: scratch too small (%zu < %zu)", scratch_bytes, brx_gzip_device_scratch(n_bytes, nb));
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIPCHK(c, hipSetDevice(c->device));
+    static const BrxGzConst K = gz_const();
+    uint8_t *p = (uint8_t *)d_scratch;
+    uint64_t *member_off = (uint64_t *)p; p += ((size_t)nb + 1) * 8;
+    uint32_t *tabs = (uint32_t *)p; p += (size_t)nb * 4 * BRX_GZ_TAB;
+    uint32_t *offs = (uint32_t *)p; p += (size_t)nb * 4 * BRX_GZ_OFFS;
+    uint32_t *crcs = (uint32_t *)p; p += (size_t)nb * 4;
+    uint32_t *sizes = (uint32_t *)p;
+    const uint32_t grid = std::min<uint32_t>(nb, (uint32_t)c->n_cu * 8u);
+    hipLaunchKernelGGL(k_gz_plan, dim3(grid), dim3(64), 0, st, (const uint8_t *)d_in, (uint64_t)n_bytes, d_block_off, nb, K, tabs, offs, crcs, sizes);
+    hipLaunchKernelGGL(k_gz_scan, dim3(1), dim3(64), 0, st, nb, sizes, member_off);
+    uint64_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, member_off + nb, 8, hipMemcpyDeviceToHost, st));
+    { int rcw = wait_stream(c, st, "brx_gzip_device (plan)"); if (rcw) return rcw; }
+    if (total + 8 > out_cap) { c->output_needed = (size_t)total + 8; return fail(c, BRX_E_OUTPUT, "brx_gzip_device: output buffer too small: need %llu bytes", (unsigned long long)total + 8); }
+    HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)((total + 7) & ~(uint64_t)3), st));
+    hipLaunchKernelGGL(k_gz_pack, dim3(grid), dim3(64), 0, st, (const uint8_t *)d_in, (uint64_t)n_bytes, d_block_off, nb, (uint8_t *)d_out, member_off, tabs, offs, crcs);
+    { int rcw = wait_stream(c, st, "brx_gzip_device (pack)"); if (rcw) return rcw; }
+    HIPCHK(c, hipGetLastError());
+    *out_bytes = (size_t)total;
+    return BRX_OK;
+}

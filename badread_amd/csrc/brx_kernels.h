@@ -719,6 +719,7 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
 #include "brx_mutate.h"
 #include "brx_mutate_wg.h"
 #include "brx_model.h"
+#include "brx_gzip_dev.h"
 
 /* offsets for the final stage of one SET of reads (list[0..n): a range of the processing order), relative to the
    set's seq / ops buffers.  totals: [0]=seq bytes [1]=ops bytes */

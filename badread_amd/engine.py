@@ -272,6 +272,13 @@ def bind_library(lib):
     lib.brx_set_kernel_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.brx_last_kernel_stats.restype = ctypes.c_int
     lib.brx_last_kernel_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(BrxKernelStat * len(KERNEL_NAMES))]
+    lib.brx_gzip_device_bound.restype = ctypes.c_size_t
+    lib.brx_gzip_device_bound.argtypes = [ctypes.c_size_t, ctypes.c_uint32]
+    lib.brx_gzip_device_scratch.restype = ctypes.c_size_t
+    lib.brx_gzip_device_scratch.argtypes = [ctypes.c_size_t, ctypes.c_uint32]
+    lib.brx_gzip_device.restype = ctypes.c_int
+    lib.brx_gzip_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                    ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
     lib.brx_model_count.restype = ctypes.c_int
     lib.brx_model_count.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(BrxModelJob), ctypes.c_void_p]
     lib.brx_last_mutate_passes.restype = ctypes.c_uint32
@@ -532,6 +539,37 @@ class HipEngine(EngineBase):
         used = h_keys != np.uint64(0xFFFFFFFFFFFFFFFF)
         return (h_keys[used], counts.cpu().numpy()[used].astype(np.int64), first.cpu().numpy().view(np.uint64)[used],
                 spill[:n_spill].cpu().numpy().view(np.uint64))
+
+    def gzip_device(self, data, block_off=None):
+        """brx_gzip_device: a uint8 tensor of FASTQ text on this engine's device -> a uint8 tensor (same device) holding
+        gzip members of it, one per block.  block_off: ascending byte offsets (numpy, first 0, last len(data)) of the
+        blocks, or None for 64 KB blocks."""
+        torch = self.torch
+        n = int(data.numel())
+        if n == 0:
+            return torch.zeros(0, dtype=torch.uint8, device=self.device)
+        nb, d_off, keep = 0, None, None
+        if block_off is not None:
+            block_off = np.ascontiguousarray(block_off, dtype=np.uint64)
+            assert len(block_off) >= 2 and int(block_off[0]) == 0 and int(block_off[-1]) == n
+            nb = len(block_off) - 1
+            keep = torch.from_numpy(block_off.view(np.int64).copy()).to(self.device)
+            d_off = ctypes.c_void_p(keep.data_ptr())
+        scratch = torch.empty(int(self.lib.brx_gzip_device_scratch(n, nb)) + 8, dtype=torch.uint8, device=self.device)
+        blocks = nb or -(-n // 65536)
+        # FASTQ packs to about half; the worst case (brx_gzip_device_bound: 15 bits per byte) is only allocated when the
+        # library asks for it
+        cap = min(int(0.7 * n) + 200 * blocks + 4096, int(self.lib.brx_gzip_device_bound(n, nb)) + 8)
+        got = ctypes.c_size_t(0)
+        for _ in range(2):
+            out = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            rc = self.lib.brx_gzip_device(self.ctx, ctypes.c_void_p(data.data_ptr()), n, d_off, nb, ctypes.c_void_p(out.data_ptr()), out.numel(),
+                                          ctypes.c_void_p(scratch.data_ptr()), scratch.numel(), ctypes.byref(got), self._stream())
+            if rc != E_OUTPUT:
+                break
+            cap = int(self.lib.brx_output_needed(self.ctx)) + 8
+        self._check(rc)
+        return out[:got.value]
 
     def stage_ms(self):
         arr = (ctypes.c_float * 8)()

@@ -410,7 +410,7 @@ class _BatchPool(object):
                 eng.close()
 
 
-def run_batches(engine, seed, target_size, mean_length, write, output, shard=None, max_batch=None, in_flight=1):
+def run_batches(engine, seed, target_size, mean_length, write, output, shard=None, max_batch=None, in_flight=1, device_gzip=False):
     """
     The `while total_size < target_size` loop (simulate.py:63-86) over super-batches of read indices.
     `write(bytes_like)` receives the FASTQ bytes in read order on rank 0 only.  Returns (read count, total bases).
@@ -423,6 +423,9 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     Between ranks: one all_gather of 4 bytes per read (length + two status bits) and one word per rank (bytes kept)
     per super-batch, then the kept record bytes travel point to point to rank 0 only.  On every rank the bytes leave the
     GPU through a ring of pinned host buffers drained by a writer thread (_HostRing).
+
+    device_gzip: every rank turns the bytes it keeps into gzip members ON ITS GPU (brx_gzip_device, blocks cut at the
+    lines of the records: badread_amd.output.fastq_blocks) before they go anywhere; `write` then receives gzip data.
     """
     import collections
     import torch
@@ -450,6 +453,12 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             buf = dev_staging['buf'] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
         return buf[:nbytes]
 
+    gz_engine = None
+    if device_gzip:
+        if not hasattr(engine, 'gzip_device'):
+            sys.exit('Error: --gzip-device needs the GPU engine')
+        from .output import fastq_blocks
+        gz_engine = engine.clone(1 << 20) if hasattr(engine, 'clone') else engine      # its own context: the others are busy on their threads
     pending = collections.deque()          # (slot, future, first_of_super_batch, n_super, first, n_mine)
     fatal = bad_read = None
 
@@ -498,6 +507,14 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             my_lo = first - base
             keep = int(np.clip(last - my_lo + 1, 0, n_mine))
             my_bytes = int(stats['rec_off'][keep - 1] + stats['rec_len'][keep - 1]) if keep else 0
+            packed = False
+            if gz_engine is not None and my_bytes:
+                t0 = time.perf_counter()
+                blocks = fastq_blocks(stats['rec_off'][:keep], stats['rec_len'][:keep], stats['seq_len'][:keep], my_bytes)
+                out = gz_engine.gzip_device(out[:my_bytes], blocks)       # a new tensor: the engine's buffer is free again
+                my_bytes = int(out.numel())
+                packed = True
+                timing['device_gzip'] += time.perf_counter() - t0
             sizes = [my_bytes]
             if shard.world > 1:
                 sizes = [int(x[0]) for x in shard.gather_words(np.array([my_bytes], dtype=np.uint32), [1] * shard.world)]
@@ -505,7 +522,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             # the engine goes back to work at once: its kept bytes are copied device-to-device first (0.5 GB at HBM speed),
             # the slower hops (PCIe into the pinned ring, or the send to rank 0) read that copy
             t0 = time.perf_counter()
-            if pool.on_gpu and my_bytes:
+            if pool.on_gpu and my_bytes and not packed:
                 out = out[:my_bytes].clone()
             timing['clone'] += time.perf_counter() - t0
             pool.release(slot)                      # the engine's output buffer may be overwritten from here on
@@ -533,6 +550,8 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
                 pass
         t0 = time.perf_counter()
         pool.close()
+        if gz_engine is not None and gz_engine is not engine:
+            gz_engine.close()
         timing['close_engines'] = time.perf_counter() - t0
         t0 = time.perf_counter()
         if ring is not None:
@@ -592,6 +611,9 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
                                            end_rate, end_amount))
     sink = stdout if stdout is not None else getattr(sys.stdout, 'buffer', None)
     gzip_level = getattr(args, 'gzip_level', None)
+    device_gzip = bool(getattr(args, 'gzip_device', False))
+    if device_gzip and gzip_level is not None:
+        sys.exit('Error: --gzip and --gzip-device exclude each other')
     if gzip_level is not None and sink is not None and shard.rank == 0:
         from .output import GzipSink
         sink = GzipSink(sink, gzip_level)          # multi-threaded gzip members (libbrx_host.so)
@@ -602,7 +624,7 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
         def write(part):
             sys.stdout.write(bytes(part).decode('latin-1'))
     result = run_batches(engine, seed, target_size, float(args.mean_frag_length), write, quiet, shard,
-                         in_flight=getattr(args, 'gpu_streams', None) or DEFAULT_IN_FLIGHT)
+                         in_flight=getattr(args, 'gpu_streams', None) or DEFAULT_IN_FLIGHT, device_gzip=device_gzip)
     if sink is not None and hasattr(sink, 'flush'):
         sink.flush()
     return result

@@ -417,18 +417,24 @@ def main():
         torch.cuda.empty_cache()
         target = int(sum(a['bases'] for a in acc))           # what this rank simulated in the timed region
         d2h = {}
-        for name, level in (('devnull_cold', None), ('devnull', None), ('gzip1', 1)):   # cold: includes mapping the clones' scratch
+        for name, level in (('devnull_cold', None), ('devnull', None), ('gzip_device', 'device'), ('gzip1', 1)):   # cold: includes mapping the clones' scratch
             raw = open(os.devnull, 'wb')
-            sink = raw if level is None else GzipSink(raw, level)
+            sink = raw if level in (None, 'device') else GzipSink(raw, level)
+            counter = {'bytes': 0}
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            count, total = run_batches(first, SEED, target, 15000.0, lambda part: sink.write(memoryview(part)), io.StringIO(),
-                                       max_batch=R, in_flight=C)
+            def write_part(part, sink=sink, counter=counter):
+                counter['bytes'] += len(part)
+                sink.write(memoryview(part))
+            count, total = run_batches(first, SEED, target, 15000.0, write_part, io.StringIO(),
+                                       max_batch=R, in_flight=C, device_gzip=(level == 'device'))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             d2h[name] = {'bases_per_s': total / dt, 'reads': count, 'bases': total, 'seconds': dt,
                          'fastq_bytes_per_s': (getattr(sink, 'bytes_in', 0) or 2.02 * total) / dt}
-            if level is not None:
+            if level == 'device':
+                d2h[name]['compressed_bytes'] = counter['bytes']
+            elif level is not None:
                 d2h[name]['compressed_bytes'] = sink.bytes_out
             d2h[name]['consumer_thread_seconds'] = {k: round(float(v), 3) for k, v in run_batches.last_timing.items()}
             raw.close()
@@ -510,6 +516,7 @@ def main():
     if d2h is not None:
         result['value_incl_d2h'] = d2h['devnull']['bases_per_s']
         result['value_incl_gzip'] = d2h['gzip1']['bases_per_s']
+        result['value_incl_gzip_device'] = d2h['gzip_device']['bases_per_s']
         result['driver_end_to_end'] = dict(d2h, note='badread_amd.simulate.run_batches (the CLI driver: stop rule, D2H through a ring of pinned '
                                                       'buffers, writer thread) over the same number of bases, FASTQ to /dev/null and through '
                                                       '--gzip 1 on all host cores; includes the start-up of its engine clones')

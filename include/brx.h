@@ -317,6 +317,20 @@ typedef struct {
 } brx_model_job;
 int brx_model_count(brx_ctx *ctx, int kind, const brx_model_job *job, void *hip_stream);
 
+/* ---- output stage: the FASTQ bytes of a batch as gzip members, made on the device ----
+ * Replaces the `| gzip` the reference's users put behind /root/reference/badread/simulate.py:73-82 (print of the
+ * record text).  d_in: n_bytes of text in device memory.  d_block_off: n_blocks + 1 ascending byte offsets (device
+ * memory; first 0, last n_bytes, no block longer than 128 MB) -- every block becomes one gzip member with its own
+ * Huffman code -- or NULL (n_blocks 0): 64 KB blocks.  d_out: device buffer of at least brx_gzip_device_bound(n_bytes,
+ * n_blocks) bytes (4-byte aligned); d_scratch: brx_gzip_device_scratch(n_bytes, n_blocks) bytes of device memory.
+ * Writes the members back to back (dynamic Huffman coding of the bytes, no match search: gzip readers take them as one
+ * stream); *out_bytes = their total size.  Synchronous on `hip_stream`.  BRX_E_OUTPUT / BRX_E_SCRATCH when a buffer is
+ * too small. */
+size_t brx_gzip_device_bound(size_t n_bytes, uint32_t n_blocks);
+size_t brx_gzip_device_scratch(size_t n_bytes, uint32_t n_blocks);
+int brx_gzip_device(brx_ctx *ctx, const void *d_in, size_t n_bytes, const uint64_t *d_block_off, uint32_t n_blocks, void *d_out,
+                    size_t out_cap, void *d_scratch, size_t scratch_bytes, size_t *out_bytes, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
