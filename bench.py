@@ -418,6 +418,9 @@ def main():
         target = int(sum(a['bases'] for a in acc))           # what this rank simulated in the timed region
         d2h = {}
         for name, level in (('devnull_cold', None), ('devnull', None), ('gzip_device', 'device'), ('gzip1', 1)):   # cold: includes mapping the clones' scratch
+            print(f'[bench --d2h] {name} ...', file=sys.stderr, flush=True)
+            gc.collect()
+            torch.cuda.empty_cache()                 # the legs run at the edge of the 288 GB (6 x 42 GB of scratch): give back what the last one cached
             raw = open(os.devnull, 'wb')
             sink = raw if level in (None, 'device') else GzipSink(raw, level)
             counter = {'bytes': 0}
