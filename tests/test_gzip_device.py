@@ -206,3 +206,46 @@ def test_a_full_batch_of_simulated_reads_round_trips():
     assert gzip.decompress(packed) == text
     assert len(packed) < 0.53 * n and len(packed) < len(zlib.compress(text[:4000000], 6)) * (n / 4000000.0)
     eng.close()
+
+
+GZ_WORKER = '''
+import io, os, sys
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, 'tests')); sys.path.insert(0, os.path.join({repo!r}, 'oracle'))
+import emu_engine as EE
+from badread_amd import simulate as S
+from test_host_simulate import Args
+S.DEFAULT_MAX_BATCH = 24
+shard = S.Shard.from_env()
+out = io.BytesIO()
+S.simulate(Args(gzip_device=True), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=out, shard=shard)
+if shard.rank == 0:
+    open({outfile!r}, 'wb').write(out.getvalue())
+else:
+    assert out.getvalue() == b''
+'''
+
+
+def test_two_ranks_compress_their_own_bytes_and_rank_0_writes_one_stream(tmp_path, monkeypatch):
+    """--gzip-device over two ranks (gloo, interpreted kernels): every rank packs the records it keeps, the members travel
+    to rank 0 in read order, and the stream decompresses to the single-process text."""
+    import io
+    import os
+    import subprocess
+    import sys
+    import emu_engine as EE
+    from badread_amd import simulate as S
+    from test_host_simulate import Args, _free_port
+    here = os.path.dirname(os.path.abspath(__file__))
+    monkeypatch.setattr(S, 'DEFAULT_MAX_BATCH', 24)
+    plain = io.BytesIO()
+    S.simulate(Args(), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=plain, shard=S.Shard())
+    port = _free_port()
+    outfile = str(tmp_path / 'ranks.fastq.gz')
+    script = tmp_path / 'worker.py'
+    script.write_text(GZ_WORKER.format(repo=os.path.dirname(here), outfile=outfile))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert gzip.decompress(open(outfile, 'rb').read()) == plain.getvalue()
