@@ -817,7 +817,8 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
 template <int MAXG, int GLO, int GHI>
 __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                    uint32_t *queue, uint32_t *retries, int phase, const uint8_t *Fbuf,
-                                                   uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
+                                                   uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk,
+                                                   uint8_t *slab_base, uint64_t slab_units) {
     const int lane = lane_id();
     for (;;) {
         const uint32_t qi = q_begin + wave_pop(queue);
@@ -834,10 +835,14 @@ __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d,
         const uint8_t *F = Fbuf + s.F_off;
         uint8_t *seq = seqbuf + s.seq_off;                                 /* joined and padded by k_fin_join */
         uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
-        uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
         const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
+        /* the traceback store is dead once the read's path is written: with slabs (BRX_TB_SLABS) every persistent wave owns
+           one store sized for the largest read of its class and reuses it, instead of every read of the set owning a region */
+        uint2 *tb = slab_units ? reinterpret_cast<uint2 *>(slab_base) + (uint64_t)blockIdx.x * slab_units
+                               : reinterpret_cast<uint2 *>(tb_base + s.tb_off);
+        const uint64_t tb_cap = slab_units ? slab_units : s.units - col_units;
         int ncols = 0, nmatch = 0; bool nospace = false;
-        const bool ok = brx_wave_align<MAXG, (GLO < MAXG ? GLO : MAXG)>(seq, (int)m, F, (int)n, (int)s.ub, tb, s.units - col_units, ops_end, &ncols, &nmatch,
+        const bool ok = brx_wave_align<MAXG, (GLO < MAXG ? GLO : MAXG)>(seq, (int)m, F, (int)n, (int)s.ub, tb, tb_cap, ops_end, &ncols, &nmatch,
                                              &nospace, nullptr, aclk, (phase == 0 && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0);
         if (lane == 0) {
             RS *o = &rs[r];
@@ -859,7 +864,7 @@ __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d,
 #define BRX_QS_HOT_MAX 128
 __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                     uint32_t *queue, int phase, int klo, int khi, uint8_t *seqbuf, const uint8_t *opsbuf,
-                                                    uint8_t *tb_base, uint64_t *clk) {
+                                                    uint8_t *tb_base, uint64_t *clk, int slabs) {
     __shared__ uint32_t qhist[256];
     __shared__ uint32_t hot_thr[BRX_QS_HOT_MAX], hot_score[BRX_QS_HOT_MAX];
     const int lane = lane_id();
@@ -894,7 +899,7 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
         const uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
         uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
         const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
-        uint32_t *col_of = reinterpret_cast<uint32_t *>(tb + (s.units - col_units));
+        uint32_t *col_of = reinterpret_cast<uint32_t *>(slabs ? tb : tb + (s.units - col_units));      /* slabs: tb_off is the read's col_of[] */
         const bool ok = !(s.status & BRX_RS_BAND);
         const uint32_t ncols = s.n_cols;
         const uint8_t *ops = ops_end - ncols;

@@ -85,6 +85,10 @@ ROUTES = [
     # the one-launch mutate stage (BRX_MUTATE_WG=1: workgroups of 8 reads, packed window alignments)
     {'BRX_MUTATE_WG': 1},
     {'BRX_MUTATE_WG': 1, 'BRX_HEAD_READS': 9, 'BRX_TB_WINDOW': -1},              # final stage split into a head and a bulk set, retry phase
+    # one traceback store per persistent wave instead of one per read (BRX_TB_SLABS)
+    {'BRX_TB_SLABS': 1},
+    {'BRX_TB_SLABS': 1, 'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_TB_WINDOW': -1},   # two sets, retry phase with full stores
+    {'BRX_TB_SLABS': 1, 'BRX_TB_WINDOW': 0, 'BRX_WIDE_STREAM': 0, 'BRX_WAVES_PER_CU': 1},
 ]
 
 
