@@ -54,6 +54,7 @@ struct brx_ctx {
     hipStream_t side2;
     hipStream_t side3, aux;      /* the bulk set's wide band classes; the wave-per-window kernel of a pass (beside the lane kernel) */
     hipEvent_t ev_pf, ev_pj;     /* fork / join of that kernel */
+    int fin_pair;                /* BRX_FIN_PAIR: one-word band class with two reads per wave (brx_pair.h) */
     int tb_slabs;                /* BRX_TB_SLABS: one traceback store per persistent wave of the final aligners instead of one per read */
     int fin4_wide, wave_stream, bulk_wide;   /* BRX_FIN4_WIDE, BRX_WAVE_STREAM, BRX_BULK_WIDE (see run_pipeline) */
     hipEvent_t ev_fork2[2], ev_join2[2], ev_head_mut;
@@ -176,6 +177,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
     { const char *v = getenv("BRX_FIN4_WIDE"); c->fin4_wide = v ? atoi(v) : 0; }
     { const char *v = getenv("BRX_TB_SLABS"); c->tb_slabs = v ? atoi(v) : 0; }
+    { const char *v = getenv("BRX_FIN_PAIR"); c->fin_pair = v ? atoi(v) : 0; }
     { const char *v = getenv("BRX_WAVE_STREAM"); c->wave_stream = v ? atoi(v) : 0; }
     { const char *v = getenv("BRX_BULK_WIDE"); c->bulk_wide = v ? atoi(v) : 0; }
     /* the streams of these experiments exist only when asked for: every stream of a context takes a hardware queue, and two idle
@@ -646,8 +648,12 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             }
             {
                 KTIMED(BRX_KERN_FIN_ALIGN1, S.st);
-                hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 2, misses, phase,
-                                   Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
+                if (c->fin_pair)
+                    hipLaunchKernelGGL(k_fin_align_pair, dim3(std::max(1u, (waves + 1) / 2)), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 2, misses, phase,
+                                       Fbuf, c->scratch, c->scratch, tb_base, clk);
+                else
+                    hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 2, misses, phase,
+                                       Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
             }
             {
                 KTIMED(BRX_KERN_FIN_QSCORE, S.st);

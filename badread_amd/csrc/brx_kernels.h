@@ -861,6 +861,89 @@ __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d,
     }
 }
 
+#include "brx_pair.h"
+/* BRX_FIN_PAIR=1: the one-word band class with two reads per wave where both bands fit half a wave (brx_pair.h); reads that
+   do not pair -- wider bands, an odd one out, empty sequences -- go through brx_wave_align as in k_fin_align<1, 1, 1>. */
+__global__ void __launch_bounds__(64, 4) k_fin_align_pair(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
+                                                         uint32_t *queue, uint32_t *retries, int phase, const uint8_t *Fbuf,
+                                                         uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
+    const int lane = lane_id();
+    bool drained = false;
+    while (!drained) {
+        /* ---- up to two reads of this class and phase ---- */
+        uint32_t rr[2] = {0u, 0u};
+        int nc = 0;
+        while (nc < 2) {
+            const uint32_t qi = q_begin + wave_pop(queue);
+            if (qi >= q_end) { drained = true; break; }
+            const uint32_t r = order[qi];
+            const RS s = rs[r];
+            if (s.n == 0) continue;
+            if ((int)(s.klass & 0xFFFFu) != 1) continue;
+            if (((s.klass & BRX_KL_RETRY) != 0u) != (phase != 0)) continue;
+            rr[nc++] = r;
+        }
+        if (nc == 0) break;
+        RS s2[2];
+        BrxGeom g2[2];
+        bool pair_ok = nc == 2;
+        uint64_t col_units[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i >= nc) { g2[i] = brx_make_geom(1, 1, 0); g2[i].NS = 0; continue; }
+            s2[i] = rs[rr[i]];
+            col_units[i] = ((uint64_t)s2[i].m * 4 + 7) / 8 + 2;
+            const int hmul = (phase == 0 && !(s2[i].klass & BRX_KL_FULL)) ? d.tb_hmul : 0;
+            g2[i] = brx_make_geom((int)s2[i].m > 0 ? (int)s2[i].m : 1, (int)s2[i].n > 0 ? (int)s2[i].n : 1, (int)s2[i].ub, hmul);
+            pair_ok = pair_ok && s2[i].m > 0 && brx_pair_eligible(g2[i]) && brx_align_units(g2[i]) <= s2[i].units - col_units[i];
+        }
+        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        bool okv[2] = {false, false};
+        int ncolsv[2] = {0, 0}, nmatchv[2] = {0, 0};
+        if (pair_ok) {
+            brx_align_forward_k4_pair(seqbuf + s2[0].seq_off, Fbuf + s2[0].F_off, g2[0], reinterpret_cast<uint2 *>(tb_base + s2[0].tb_off),
+                                      seqbuf + s2[1].seq_off, Fbuf + s2[1].F_off, g2[1], reinterpret_cast<uint2 *>(tb_base + s2[1].tb_off));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {
+                const RS &s = s2[i];
+                uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)s.n + (uint64_t)s.m;
+                bool ok = brx_align_traceback(seqbuf + s.seq_off, Fbuf + s.F_off, g2[i], reinterpret_cast<uint2 *>(tb_base + s.tb_off), ops_end,
+                                              &ncolsv[i], &nmatchv[i]);
+                if (ok && (ncolsv[i] - nmatchv[i]) > (int)s.ub) ok = false;
+                okv[i] = ok;
+            }
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < nc; ++i) {
+                const RS &s = s2[i];
+                uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)s.n + (uint64_t)s.m;
+                bool nospace = false;
+                okv[i] = brx_wave_align<1, 1>(seqbuf + s.seq_off, (int)s.m, Fbuf + s.F_off, (int)s.n, (int)s.ub, reinterpret_cast<uint2 *>(tb_base + s.tb_off),
+                                              s.units - col_units[i], ops_end, &ncolsv[i], &nmatchv[i], &nospace, nullptr, nullptr,
+                                              (phase == 0 && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0);
+            }
+        }
+        if (lane == 0) {
+            for (int i = 0; i < nc; ++i) {
+                const RS &s = s2[i];
+                RS *o = &rs[rr[i]];
+                if (!okv[i] && phase == 0) {
+                    o->klass = s.klass | BRX_KL_RETRY;
+                    atomicAdd(retries, 1u);
+                    clk[(uint64_t)rr[i] * 8 + 2] = 1;
+                } else {
+                    o->status = s.status | (okv[i] ? 0u : BRX_RS_BAND);
+                    o->n_cols = (uint32_t)ncolsv[i]; o->n_match = (uint32_t)nmatchv[i];
+                }
+                uint64_t *ck = clk + (uint64_t)rr[i] * 8;
+                ck[3] = (__builtin_amdgcn_s_memtime() - t_begin) / (uint64_t)nc; ck[7] = 1u | (pair_ok ? 0x100u : 0u);       /* brx_last_read_cycles[7]: band class, + 0x100 = aligned as one of a pair */
+            }
+        }
+    }
+}
+
 #define BRX_QS_HOT_MAX 128
 __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                     uint32_t *queue, int phase, int klo, int khi, uint8_t *seqbuf, const uint8_t *opsbuf,

@@ -89,6 +89,10 @@ ROUTES = [
     {'BRX_TB_SLABS': 1},
     {'BRX_TB_SLABS': 1, 'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_TB_WINDOW': -1},   # two sets, retry phase with full stores
     {'BRX_TB_SLABS': 1, 'BRX_TB_WINDOW': 0, 'BRX_WIDE_STREAM': 0, 'BRX_WAVES_PER_CU': 1},
+    # two final alignments per wave for narrow one-word bands (BRX_FIN_PAIR, brx_pair.h)
+    {'BRX_FIN_PAIR': 1},
+    {'BRX_FIN_PAIR': 1, 'BRX_TB_WINDOW': -1, 'BRX_HEAD_READS': 9, 'BRX_TAIL_READS': 6},      # two sets, most reads repeat with the full store
+    {'BRX_FIN_PAIR': 1, 'BRX_TB_WINDOW': 0, 'BRX_WAVES_PER_CU': 1},
 ]
 
 
@@ -110,6 +114,9 @@ def test_pipeline_routes_equal_the_oracle(env, monkeypatch):
         assert eng.mutate_passes() > 3
     if env.get('BRX_MUTATE_WG') == 1:
         assert eng.mutate_passes() == 1
+    if env.get('BRX_FIN_PAIR') == 1 and env.get('BRX_TB_WINDOW') != -1:
+        paired = (eng.read_cycles(n)[:, 7] & 0x100) != 0
+        assert paired.sum() >= n // 2 and paired.sum() % 2 == 0      # most reads were aligned two to a wave
 
 
 def test_lds_threshold_build_variant(monkeypatch):
