@@ -54,6 +54,7 @@ struct brx_ctx {
     hipStream_t side2;
     hipStream_t side3, aux;      /* the bulk set's wide band classes; the wave-per-window kernel of a pass (beside the lane kernel) */
     hipEvent_t ev_pf, ev_pj;     /* fork / join of that kernel */
+    int fin_wg;                  /* BRX_FIN_WG: wide band classes with one read per workgroup of 4 / 16 waves (brx_wg_align.h) */
     int fin_pair;                /* BRX_FIN_PAIR: one-word band class with two reads per wave (brx_pair.h) */
     int tb_slabs;                /* BRX_TB_SLABS: one traceback store per persistent wave of the final aligners instead of one per read */
     int fin4_wide, wave_stream, bulk_wide;   /* BRX_FIN4_WIDE, BRX_WAVE_STREAM, BRX_BULK_WIDE (see run_pipeline) */
@@ -178,6 +179,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *v = getenv("BRX_FIN4_WIDE"); c->fin4_wide = v ? atoi(v) : 0; }
     { const char *v = getenv("BRX_TB_SLABS"); c->tb_slabs = v ? atoi(v) : 0; }
     { const char *v = getenv("BRX_FIN_PAIR"); c->fin_pair = v ? atoi(v) : 0; }
+    { const char *v = getenv("BRX_FIN_WG"); c->fin_wg = v ? atoi(v) : 0; }
     { const char *v = getenv("BRX_WAVE_STREAM"); c->wave_stream = v ? atoi(v) : 0; }
     { const char *v = getenv("BRX_BULK_WIDE"); c->bulk_wide = v ? atoi(v) : 0; }
     /* the streams of these experiments exist only when asked for: every stream of a context takes a hardware queue, and two idle
@@ -628,8 +630,15 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             }
             if (S.bases_by_class[3] || phase == 1) {
                 KTIMED(BRX_KERN_FIN_ALIGN16, S.wide);
-                hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
-                                   dev, rs, order, b, e, cq + 0, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
+                if (c->fin_wg)          /* first the reads a 1024-lane workgroup can take with one word per lane, then the rest as before */
+                    hipLaunchKernelGGL((k_fin_align_wg<16, 8, 0xFFFF>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu)), dim3(1024), 0, S.wide,
+                                       dev, rs, order, b, e, cq + 6, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
+                if (c->fin_wg)
+                    hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF, 1024>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
+                                       dev, rs, order, b, e, cq + 0, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
+                else
+                    hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
+                                       dev, rs, order, b, e, cq + 0, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
             }
             /* BRX_FIN4_WIDE: the four-word class follows the widest one on the wide stream instead of leading the set's own stream */
             const bool four_wide = fork && c->fin4_wide;
@@ -637,8 +646,15 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             if (!four_wide && fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
             if (S.bases_by_class[2] || phase == 1) {
                 KTIMED(BRX_KERN_FIN_ALIGN4, s4);
-                hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, s4,
-                                   dev, rs, order, b, e, cq + 4, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
+                if (c->fin_wg)
+                    hipLaunchKernelGGL((k_fin_align_wg<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 2u)), dim3(256), 0, s4,
+                                       dev, rs, order, b, e, cq + 7, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
+                if (c->fin_wg)
+                    hipLaunchKernelGGL((k_fin_align<4, 4, 4, 256>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, s4,
+                                       dev, rs, order, b, e, cq + 4, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
+                else
+                    hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, s4,
+                                       dev, rs, order, b, e, cq + 4, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
             }
             if (four_wide) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
             if (S.bases_by_class[1] || phase == 1) {

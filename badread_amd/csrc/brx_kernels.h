@@ -24,6 +24,7 @@
 #include "../../include/brx.h"
 #include "../../include/brx_spec.h"
 #include "brx_align.h"
+#include "brx_wg_align.h"
 
 #define BRX_ALIGN_INTERVAL 25     /* settings.ALIGNMENT_INTERVAL */
 #define BRX_ALIGN_SIZE 1000       /* settings.ALIGNMENT_SIZE     */
@@ -814,7 +815,7 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
     }
 }
 
-template <int MAXG, int GLO, int GHI>
+template <int MAXG, int GLO, int GHI, int WG_LANES = 0>
 __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                    uint32_t *queue, uint32_t *retries, int phase, const uint8_t *Fbuf,
                                                    uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk,
@@ -836,6 +837,10 @@ __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d,
         uint8_t *seq = seqbuf + s.seq_off;                                 /* joined and padded by k_fin_join */
         uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
         const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
+        /* BRX_FIN_WG: reads whose band fits the workgroup aligner were aligned by k_fin_align_wg (same test there) */
+        if constexpr (WG_LANES != 0) {
+            if (brx_wg_eligible(m, n, s.ub, (phase == 0 && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0, WG_LANES, s.units - col_units, nullptr)) continue;
+        }
         /* the traceback store is dead once the read's path is written: with slabs (BRX_TB_SLABS) every persistent wave owns
            one store sized for the largest read of its class and reuses it, instead of every read of the set owning a region */
         uint2 *tb = slab_units ? reinterpret_cast<uint2 *>(slab_base) + (uint64_t)blockIdx.x * slab_units
@@ -861,10 +866,65 @@ __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d,
     }
 }
 
+/* BRX_FIN_WG=1: the wide band classes with one read per WORKGROUP of W waves (brx_wg_align.h).  Reads whose band does not fit
+   64 W lanes with one word each (or whose store was sized too small for that geometry) are left to k_fin_align, which is
+   launched behind this kernel with the same eligibility test. */
+template <int W, int GLO, int GHI>
+__global__ void __launch_bounds__(64 * W) k_fin_align_wg(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
+                                                        uint32_t *queue, uint32_t *retries, int phase, const uint8_t *Fbuf,
+                                                        uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
+    __shared__ uint32_t s_next;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (;;) {
+        if (wave == 0) { const uint32_t q = q_begin + wave_pop(queue); if (lane == 0) s_next = q; }
+        __syncthreads();
+        const uint32_t qi = s_next;
+        __syncthreads();
+        if (qi >= q_end) break;
+        const uint32_t r = order[qi];
+        const RS s = rs[r];
+        if (s.n == 0) continue;
+        const int klass = (int)(s.klass & 0xFFFFu);
+        if (klass < GLO || klass > GHI) continue;
+        if (((s.klass & BRX_KL_RETRY) != 0u) != (phase != 0)) continue;
+        const uint32_t n = s.n, m = s.m;
+        const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
+        BrxGeom g;
+        if (!brx_wg_eligible(m, n, s.ub, (phase == 0 && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0, 64 * W, s.units - col_units, &g)) continue;
+        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        const uint8_t *F = Fbuf + s.F_off;
+        uint8_t *seq = seqbuf + s.seq_off;
+        uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
+        brx_align_forward_wg<W>(seq, F, g, tb);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();                                                    /* every wave's stores are visible to wave 0 */
+        if (wave == 0) {
+            uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
+            int ncols = 0, nmatch = 0;
+            bool ok = brx_align_traceback(seq, F, g, tb, ops_end, &ncols, &nmatch);
+            if (ok && (ncols - nmatch) > (int)s.ub) ok = false;
+            if (lane == 0) {
+                RS *o = &rs[r];
+                if (!ok && phase == 0) {
+                    o->klass = s.klass | BRX_KL_RETRY;
+                    atomicAdd(retries, 1u);
+                    clk[(uint64_t)r * 8 + 2] = 1;
+                } else {
+                    o->status = s.status | (ok ? 0u : BRX_RS_BAND);
+                    o->n_cols = (uint32_t)ncols; o->n_match = (uint32_t)nmatch;
+                }
+                uint64_t *ck = clk + (uint64_t)r * 8;
+                ck[3] = __builtin_amdgcn_s_memtime() - t_begin; ck[7] = (uint64_t)klass | 0x200u;       /* + 0x200: aligned by a workgroup */
+            }
+        }
+    }
+}
+
 #include "brx_pair.h"
 /* BRX_FIN_PAIR=1: the one-word band class with two reads per wave where both bands fit half a wave (brx_pair.h); reads that
    do not pair -- wider bands, an odd one out, empty sequences -- go through brx_wave_align as in k_fin_align<1, 1, 1>. */
-__global__ void __launch_bounds__(64, 4) k_fin_align_pair(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
+__global__ void __launch_bounds__(64, 3) k_fin_align_pair(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                          uint32_t *queue, uint32_t *retries, int phase, const uint8_t *Fbuf,
                                                          uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
     const int lane = lane_id();

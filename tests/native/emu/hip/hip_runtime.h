@@ -61,6 +61,8 @@ struct Wave {
     int live = 0, arrived = 0;
     unsigned long long gen = 0;                     /* completed cross-lane operations of this wave */
     uint64_t slot[2][WAVE];                         /* operands, double-buffered by operation parity */
+    uint64_t part[2] = {0, 0};                      /* lanes that took part in the operation of each buffer: a lane that has
+                                                       left the kernel since then still counts for the slower readers */
 };
 struct State {
     ucontext_t sched;
@@ -89,10 +91,18 @@ inline const uint64_t *exchange(uint64_t v) {
     Wave &w = s.wave[s.cur / WAVE];
     const unsigned long long g = w.gen;
     uint64_t *buf = w.slot[g & 1];
+    if (w.arrived == 0) w.part[g & 1] = 0;
+    w.part[g & 1] |= 1ull << (s.cur % WAVE);
     buf[s.cur % WAVE] = v;
     if (++w.arrived >= w.live) { w.arrived = 0; w.gen = g + 1; }
     else while (w.gen == g) yield_to_scheduler();
     return buf;
+}
+/* the lanes that deposited into `buf` (the value exchange() returned) */
+inline uint64_t participants(const uint64_t *buf) {
+    State &s = S();
+    Wave &w = s.wave[s.cur / WAVE];
+    return w.part[buf == w.slot[1] ? 1 : 0];
 }
 inline void block_barrier() {
     State &s = S();
@@ -204,9 +214,8 @@ inline Idx gdim() { return Idx{S().grid, 1u, 1u}; }
 static inline unsigned long long __ballot(int pred) {
     const uint64_t *v = emu::exchange(pred ? 1u : 0u);
     unsigned long long m = 0;
-    const emu::State &s = emu::S();
-    const int w0 = (s.cur / emu::WAVE) * emu::WAVE;
-    for (int l = 0; l < emu::WAVE; ++l) if (!s.done[w0 + l]) m |= (unsigned long long)(v[l] & 1u) << l;      /* exited lanes: EXEC off */
+    const uint64_t part = emu::participants(v);                /* lanes that had left the kernel before this ballot: EXEC off */
+    for (int l = 0; l < emu::WAVE; ++l) if ((part >> l) & 1ull) m |= (unsigned long long)(v[l] & 1u) << l;
     return m;
 }
 static inline int __shfl(int v, int src, int width = 64) { (void)width; const int me = emu::S().cur % emu::WAVE; const uint64_t *a = emu::exchange((uint32_t)v); (void)me; return (int)(uint32_t)a[src & 63]; }
@@ -230,9 +239,8 @@ inline int dpp(int v, int ctrl) {
 }
 inline int readfirstlane(int v) {
     const uint64_t *a = exchange((uint32_t)v);
-    State &s = S();
-    const int w0 = (s.cur / WAVE) * WAVE;
-    for (int l = 0; l < WAVE; ++l) if (!s.done[w0 + l]) return (int)(uint32_t)a[l];
+    const uint64_t part = participants(a);
+    for (int l = 0; l < WAVE; ++l) if ((part >> l) & 1ull) return (int)(uint32_t)a[l];
     return v;
 }
 }  // namespace emu

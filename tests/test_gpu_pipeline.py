@@ -120,7 +120,8 @@ def test_alternative_kernel_routes_give_the_same_bytes(env, monkeypatch):
 
 
 EXPERIMENTAL = [{'BRX_FIN_PAIR': '1'}, {'BRX_FIN_PAIR': '1', 'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1'},
-                {'BRX_TB_SLABS': '1'}, {'BRX_TB_SLABS': '1', 'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1'}]
+                {'BRX_TB_SLABS': '1'}, {'BRX_TB_SLABS': '1', 'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1'},
+                {'BRX_FIN_WG': '1'}, {'BRX_FIN_WG': '1', 'BRX_FIN_PAIR': '1', 'BRX_TB_WINDOW': '-1'}]
 
 
 @pytest.mark.skipif(os.environ.get('BRX_TEST_EXPERIMENTAL') != '1',
