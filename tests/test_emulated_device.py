@@ -237,25 +237,25 @@ def _window_overflow(tmp_path):
 def test_wide_bands_on_a_workgroup_of_waves(monkeypatch):
     """BRX_FIN_WG=1 (csrc/brx_wg_align.h): the final alignments of the 4-word and the 8/16-word band classes run as ONE
     systolic array of 256 / 1024 lanes with one word per lane -- carries through LDS across the waves, a barrier per trip,
-    the target ring of the whole workgroup in LDS.  Two long fragments mutated down to ~60 % identity: bands of ~5 000 and
-    ~9 000 diagonals."""
+    the target ring of the whole workgroup in LDS.  A fragment mutated down to ~60 % identity (a band of ~5 000 diagonals: the
+    four-word class, 256 lanes) beside a short one that stays with the one-wave kernel; the 1024-lane instance is the next test."""
     monkeypatch.setenv('BRX_FIN_WG', '1')
     monkeypatch.setenv('BRX_MUTATE_WG', '0')
     rng = np.random.default_rng(8)
     pref, _ = H.small_reference()
     eng = H.configure(emu_engine(), pref, 'random', 'ideal', SimParams())
     orc = H.configure(H.oracle_engine(), pref, 'random', 'ideal', SimParams())
-    frags = [rng.integers(0, 4, n).astype(np.uint8) for n in (7000, 11000, 500)]
-    targets = [0.6, 0.62, 0.9]
+    frags = [rng.integers(0, 4, n).astype(np.uint8) for n in (7000, 500)]
+    targets = [0.6, 0.9]
     rh, sh = eng.sequence_fragments(3, 0, frags, targets)
     ro, so = orc.sequence_fragments(3, 0, frags, targets)
     for f in STAT_FIELDS:
         assert (sh[f] == so[f]).all(), f
     for a, b in zip(rh, ro):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-    marks = eng.read_cycles(3)[:, 7]
-    assert (marks[:2] & 0x200).all() and not (marks[2] & 0x200), marks       # the two wide reads were aligned by a workgroup
-    assert sorted(int(x) & 0xFF for x in marks[:2]) == [4, 8], marks
+    marks = eng.read_cycles(2)[:, 7]
+    assert (marks[0] & 0x200) and not (marks[1] & 0x200), marks              # the wide read was aligned by a workgroup
+    assert int(marks[0]) & 0xFF == 4, marks
 
 
 def test_workgroup_aligner_refills_its_target_ring(monkeypatch):
