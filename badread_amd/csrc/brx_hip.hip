@@ -52,12 +52,6 @@ struct brx_ctx {
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
     int wide_stream;             /* BRX_WIDE_STREAM: the head set's widest band class aligns on a third stream */
     hipStream_t side2;
-    hipStream_t side3, aux;      /* the bulk set's wide band classes; the wave-per-window kernel of a pass (beside the lane kernel) */
-    hipEvent_t ev_pf, ev_pj;     /* fork / join of that kernel */
-    int fin_wg;                  /* BRX_FIN_WG: wide band classes with one read per workgroup of 4 / 16 waves (brx_wg_align.h) */
-    int fin_pair;                /* BRX_FIN_PAIR: one-word band class with two reads per wave (brx_pair.h) */
-    int tb_slabs;                /* BRX_TB_SLABS: one traceback store per persistent wave of the final aligners instead of one per read */
-    int fin4_wide, wave_stream, bulk_wide;   /* BRX_FIN4_WIDE, BRX_WAVE_STREAM, BRX_BULK_WIDE (see run_pipeline) */
     hipEvent_t ev_fork2[2], ev_join2[2], ev_head_mut;
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
                                     three wide classes: a stream per class measured 30 % slower, r01d) */
@@ -118,10 +112,6 @@ static void release(brx_ctx *c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->side2) (void)hipStreamDestroy(c->side2);
-    if (c->side3) (void)hipStreamDestroy(c->side3);
-    if (c->aux) (void)hipStreamDestroy(c->aux);
-    if (c->ev_pf) (void)hipEventDestroy(c->ev_pf);
-    if (c->ev_pj) (void)hipEventDestroy(c->ev_pj);
     for (int i = 0; i < 2; ++i) { if (c->ev_fork2[i]) (void)hipEventDestroy(c->ev_fork2[i]); if (c->ev_join2[i]) (void)hipEventDestroy(c->ev_join2[i]); }
     if (c->ev_head_mut) (void)hipEventDestroy(c->ev_head_mut);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -165,8 +155,6 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     }
     if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
-    if ((e = hipEventCreateWithFlags(&c->ev_pf, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_pj, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     for (int i = 0; i < 2; ++i)
         if ((e = hipEventCreateWithFlags(&c->ev_fork2[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
@@ -176,16 +164,8 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
-    { const char *v = getenv("BRX_FIN4_WIDE"); c->fin4_wide = v ? atoi(v) : 0; }
-    { const char *v = getenv("BRX_TB_SLABS"); c->tb_slabs = v ? atoi(v) : 0; }
-    { const char *v = getenv("BRX_FIN_PAIR"); c->fin_pair = v ? atoi(v) : 0; }
-    { const char *v = getenv("BRX_FIN_WG"); c->fin_wg = v ? atoi(v) : 0; }
-    { const char *v = getenv("BRX_WAVE_STREAM"); c->wave_stream = v ? atoi(v) : 0; }
-    { const char *v = getenv("BRX_BULK_WIDE"); c->bulk_wide = v ? atoi(v) : 0; }
-    /* the streams of these experiments exist only when asked for: every stream of a context takes a hardware queue, and two idle
-       extra streams per context (6 contexts) cost 24 % of the rate (measured, A/B on one box: 2.97 -> 2.27 Gbases/s) */
-    if (c->bulk_wide && (e = hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
-    if (c->wave_stream && (e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking)) != hipSuccess) return create_fail(c, "hipStreamCreate", e);
+    /* a context owns exactly three streams besides the caller's: every stream of a context takes a hardware queue, and two idle
+       extra streams per context (6 contexts) cost 24 % of the rate (round 2, A/B on one box: 2.97 -> 2.27 Gbases/s) */
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
@@ -452,7 +432,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     };
     FinalSet sets[2];
     sets[0] = FinalSet{0, n_head, s_head, (c->wide_stream && n_bulk) ? c->side2 : s_head, 0, false, false, 0, 0, {0, 0, 0, 0, 0}};
-    sets[1] = FinalSet{n_head, n_reads, st, (c->bulk_wide && c->wide_stream) ? c->side3 : st, 1, false, false, 0, 0, {0, 0, 0, 0, 0}};
+    sets[1] = FinalSet{n_head, n_reads, st, st, 1, false, false, 0, 0, {0, 0, 0, 0, 0}};
     uint64_t *set_units = units_sorted, *set_tboff = tboff_sorted;      /* staging arrays, indexed by order position */
     std::vector<uint64_t> h_tboff(n_reads), h_units(n_reads);
     /* counters: [0],[3] join queues of head / bulk; [1] flags; [2],[4] window misses of head / bulk;
@@ -461,99 +441,8 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     bool legacy_handled = false;       /* the whole-read fallback already ran for every read (no separate mutate head chain) */
     uint64_t tail_bases = 0;           /* kernel statistics: bases of the bulk reads that finished in the in-place tail */
 
-    /* BRX_TB_SLABS=1: the same launches with one traceback store per persistent WAVE.  A read's store is dead as soon as its
-       path is written (k_fin_qscore reads the ops and col_of[], not the store), so the set needs (waves of a class) x (largest
-       store of the class) instead of the sum over its reads: no chunking by capacity, and a fraction of the arena.  Region of
-       the set: [col_of[] of every read][slabs of the 1-word class][2-word][4-word][wider]. */
-    auto launch_final_slabs = [&](FinalSet &S, int phase) -> int {
-        const uint32_t ns = S.e - S.b;
-        uint64_t max_u[4] = {0, 0, 0, 0}, col_bytes = 0;
-        uint32_t count[4] = {0, 0, 0, 0};
-        for (uint32_t i = S.b; i < S.e; ++i) {
-            const RS &r = h_rs[h_order[i]];
-            h_tboff[i] = col_bytes;
-            if (!r.n) continue;
-            const uint64_t col_units = ((uint64_t)r.m * 4 + 7) / 8 + 2;
-            col_bytes += ((col_units + 31) & ~31ull) * 8;
-            if (phase == 1 && !(r.klass & BRX_KL_RETRY)) continue;
-            bool too_wide = false;
-            const uint64_t u = phase == 1 ? brx_final_units(r.m, r.n, r.ub, 0, &too_wide) : r.units;
-            const uint32_t kl = r.klass & 0xFFFFu;
-            const int k = kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3;
-            count[k] += 1;
-            max_u[k] = std::max(max_u[k], u > col_units ? u - col_units : 0);
-        }
-        const uint32_t limit[4] = {(uint32_t)c->n_cu * (uint32_t)c->waves_per_cu, (uint32_t)c->n_cu * (uint32_t)c->waves_per_cu, (uint32_t)c->n_cu * 8u, (uint32_t)c->n_cu * 4u};
-        uint32_t grid[4];
-        for (int k = 0; k < 4; ++k) { grid[k] = std::max(1u, std::min(count[k], limit[k])); max_u[k] = (max_u[k] + 31) & ~31ull; }
-        const size_t at = (A.used + 255) & ~(size_t)255;
-        size_t left = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
-        if (phase == 0) {
-            const FinalSet &O = sets[1 - S.id];
-            if (!O.launched && O.e > O.b) left /= 2;                 /* the other set sizes itself the same way from what is left */
-        }
-        auto need = [&]() { uint64_t t = col_bytes + 4096; for (int k = 0; k < 4; ++k) t += (uint64_t)grid[k] * max_u[k] * 8; return t; };
-        for (int guard = 0; need() > left && guard < 64; ++guard) {    /* fewer waves for the class that takes the most */
-            int big = 0;
-            for (int k = 1; k < 4; ++k) if ((uint64_t)grid[k] * max_u[k] > (uint64_t)grid[big] * max_u[big]) big = k;
-            if (grid[big] <= 1) break;
-            grid[big] = (grid[big] + 1) / 2;
-        }
-        if (need() > left) return scratch_short(c, c->scratch_bytes + (size_t)(need() - left) + ((size_t)1 << 28));
-        if (phase == 0 || need() > S.tb_cap) { S.tb_at = at; S.tb_cap = (size_t)need(); (void)A.take(S.tb_cap); }
-        uint8_t *tb_base = c->scratch + S.tb_at;
-        uint8_t *slab[4];
-        { uint8_t *p = tb_base + ((col_bytes + 255) & ~255ull); for (int k = 0; k < 4; ++k) { slab[k] = p; p += (uint64_t)grid[k] * max_u[k] * 8; } }
-        HIPCHK(c, hipMemcpyAsync(set_tboff + S.b, h_tboff.data() + S.b, (size_t)ns * 8, hipMemcpyHostToDevice, S.st));
-        hipLaunchKernelGGL(k_set_tboff, dim3((ns + 63) / 64), dim3(64), 0, S.st, ns, rs, order + S.b, set_tboff + S.b, (uint64_t *)nullptr);
-        const uint32_t b = S.b, e = S.e;
-        const uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
-        uint32_t *cq = counters + 16 + 16 * (((size_t)S.id * 2 + (size_t)phase) * BRX_MAX_CHUNKS);
-        uint32_t *misses = set_counter(S, 1);
-        const bool fork = S.wide != S.st;
-        if (fork) {
-            HIPCHK(c, hipEventRecord(c->ev_fork2[S.id], S.st));
-            HIPCHK(c, hipStreamWaitEvent(S.wide, c->ev_fork2[S.id], 0));
-        }
-        if (count[3]) {
-            KTIMED(BRX_KERN_FIN_ALIGN16, S.wide);
-            hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(grid[3]), dim3(64), 0, S.wide, dev, rs, order, b, e, cq + 0, misses, phase, Fbuf,
-                               c->scratch, c->scratch, tb_base, clk, slab[3], max_u[3] ? max_u[3] : (uint64_t)32);
-        }
-        if (fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
-        if (count[2]) {
-            KTIMED(BRX_KERN_FIN_ALIGN4, S.st);
-            hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(grid[2]), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 4, misses, phase, Fbuf,
-                               c->scratch, c->scratch, tb_base, clk, slab[2], max_u[2] ? max_u[2] : (uint64_t)32);
-        }
-        if (count[1]) {
-            KTIMED(BRX_KERN_FIN_ALIGN2, S.st);
-            hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(grid[1]), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 1, misses, phase, Fbuf,
-                               c->scratch, c->scratch, tb_base, clk, slab[1], max_u[1] ? max_u[1] : (uint64_t)32);
-        }
-        if (count[0]) {
-            KTIMED(BRX_KERN_FIN_ALIGN1, S.st);
-            hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(grid[0]), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 2, misses, phase, Fbuf,
-                               c->scratch, c->scratch, tb_base, clk, slab[0], max_u[0] ? max_u[0] : (uint64_t)32);
-        }
-        {
-            KTIMED(BRX_KERN_FIN_QSCORE, S.st);
-            hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 3, phase, 1, 4,
-                               c->scratch, c->scratch, tb_base, clk, 1);
-        }
-        if (fork) HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join2[S.id], 0));
-        if (count[3]) {
-            KTIMED(BRX_KERN_FIN_QSCORE, S.st);
-            hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
-                               cq + 5, phase, 5, 0xFFFF, c->scratch, c->scratch, tb_base, clk, 1);
-        }
-        if (phase == 0) c->final_launches += 1;
-        return BRX_OK;
-    };
-
     /* launches of one phase of one set (phase 0: windowed store for every read; phase 1: full store for the misses) */
     auto launch_final_phase = [&](FinalSet &S, int phase) -> int {
-        if (c->tb_slabs) return launch_final_slabs(S, phase);
         const uint32_t ns = S.e - S.b;
         uint64_t max_units = 0, sum_units = 0;
         for (uint32_t i = S.b; i < S.e; ++i) {
@@ -630,57 +519,35 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
             }
             if (S.bases_by_class[3] || phase == 1) {
                 KTIMED(BRX_KERN_FIN_ALIGN16, S.wide);
-                if (c->fin_wg)          /* first the reads a 1024-lane workgroup can take with one word per lane, then the rest as before */
-                    hipLaunchKernelGGL((k_fin_align_wg<16, 8, 0xFFFF>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu)), dim3(1024), 0, S.wide,
-                                       dev, rs, order, b, e, cq + 6, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
-                if (c->fin_wg)
-                    hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF, 1024>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
-                                       dev, rs, order, b, e, cq + 0, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
-                else
-                    hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
-                                       dev, rs, order, b, e, cq + 0, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
+                hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
+                                   dev, rs, order, b, e, cq + 0, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
             }
-            /* BRX_FIN4_WIDE: the four-word class follows the widest one on the wide stream instead of leading the set's own stream */
-            const bool four_wide = fork && c->fin4_wide;
-            hipStream_t s4 = four_wide ? S.wide : S.st;
-            if (!four_wide && fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
+            if (fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
             if (S.bases_by_class[2] || phase == 1) {
-                KTIMED(BRX_KERN_FIN_ALIGN4, s4);
-                if (c->fin_wg)
-                    hipLaunchKernelGGL((k_fin_align_wg<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 2u)), dim3(256), 0, s4,
-                                       dev, rs, order, b, e, cq + 7, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
-                if (c->fin_wg)
-                    hipLaunchKernelGGL((k_fin_align<4, 4, 4, 256>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, s4,
-                                       dev, rs, order, b, e, cq + 4, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
-                else
-                    hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, s4,
-                                       dev, rs, order, b, e, cq + 4, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
+                KTIMED(BRX_KERN_FIN_ALIGN4, S.st);
+                hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st,
+                                   dev, rs, order, b, e, cq + 4, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
             }
-            if (four_wide) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
             if (S.bases_by_class[1] || phase == 1) {
                 KTIMED(BRX_KERN_FIN_ALIGN2, S.st);
                 hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, S.st,
-                                   dev, rs, order, b, e, cq + 1, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
+                                   dev, rs, order, b, e, cq + 1, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
             }
             {
                 KTIMED(BRX_KERN_FIN_ALIGN1, S.st);
-                if (c->fin_pair)
-                    hipLaunchKernelGGL(k_fin_align_pair, dim3(std::max(1u, (waves + 1) / 2)), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 2, misses, phase,
-                                       Fbuf, c->scratch, c->scratch, tb_base, clk);
-                else
-                    hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 2, misses, phase,
-                                       Fbuf, c->scratch, c->scratch, tb_base, clk, (uint8_t *)nullptr, (uint64_t)0);
+                hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 2, misses, phase,
+                                   Fbuf, c->scratch, c->scratch, tb_base, clk);
             }
             {
                 KTIMED(BRX_KERN_FIN_QSCORE, S.st);
-                hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 3, phase, 1, four_wide ? 2 : 4,
-                                   c->scratch, c->scratch, tb_base, clk, 0);
+                hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 3, phase, 1, 4,
+                                   c->scratch, c->scratch, tb_base, clk);
             }
             if (fork) HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join2[S.id], 0));
-            if (S.bases_by_class[3] || (four_wide && S.bases_by_class[2]) || phase == 1) {
+            if (S.bases_by_class[3] || phase == 1) {
                 KTIMED(BRX_KERN_FIN_QSCORE, S.st);
                 hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
-                                   cq + 5, phase, four_wide ? 3 : 5, 0xFFFF, c->scratch, c->scratch, tb_base, clk, 0);
+                                   cq + 5, phase, 5, 0xFFFF, c->scratch, c->scratch, tb_base, clk);
             }
         }
         if (phase == 0) c->final_launches += (uint32_t)chunks.size();
@@ -874,19 +741,6 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
                                        ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                        win, (uint64_t)c->win_bytes, counters + 1, phase);
             }
-            {   /* the windows the lane / pack kernel does not take: one per wave -- beside that kernel on a second stream
-                   (BRX_WAVE_STREAM=1) or after it; it also zeroes the counter block of the NEXT pass */
-                const bool ws_ = c->wave_stream != 0;
-                hipStream_t sw = ws_ ? c->aux : st;
-                if (ws_) { HIPCHK(c, hipEventRecord(c->ev_pf, st)); HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_pf, 0)); }
-                if (ws_) {
-                    KTIMED(BRX_KERN_WIN_WAVE, sw);
-                    hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, sw, msv, req_hard, ctr + MC_HARD,
-                                       ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1, mctr + ((pass + 1) & 1u) * MC_WORDS);
-                    HIPCHK(c, hipEventRecord(c->ev_pj, c->aux));
-                }
-            }
-            const bool ws = c->wave_stream != 0;
             if (n_up > lane_threshold) {
                 KTIMED(BRX_KERN_WIN_LANE, st);
                 hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64)), dim3(64), 0, st, msv, req_easy,
@@ -896,8 +750,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
                 hipLaunchKernelGGL(k_win_pack, dim3(std::min(pack_waves, (n_up + BRX_PACK_NG - 1) / BRX_PACK_NG)), dim3(64), 0, st, msv, req_easy,
                                    ctr + MC_EASY, ctr + 6, winbuf, pack_tb);
             }
-            if (ws) HIPCHK(c, hipStreamWaitEvent(st, c->ev_pj, 0));
-            else {
+            {   /* the windows the lane / pack kernel does not take: one per wave; it also zeroes the counter block of the NEXT pass */
                 KTIMED(BRX_KERN_WIN_WAVE, st);
                 hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
                                    ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1, mctr + ((pass + 1) & 1u) * MC_WORDS);
@@ -978,8 +831,6 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     if (c->ktiming) {
         if (n_head && n_bulk) HIPCHK(c, hipStreamSynchronize(c->side));
         if (sets[0].wide_forked) HIPCHK(c, hipStreamSynchronize(c->side2));
-        if (sets[1].wide_forked && sets[1].wide != st) HIPCHK(c, hipStreamSynchronize(c->side3));
-        if (c->wave_stream) HIPCHK(c, hipStreamSynchronize(c->aux));
         for (int i = 0; i < c->kev_n; ++i) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, c->kev_b[i], c->kev_e[i]) != hipSuccess) continue;

@@ -24,7 +24,6 @@
 #include "../../include/brx.h"
 #include "../../include/brx_spec.h"
 #include "brx_align.h"
-#include "brx_wg_align.h"
 
 #define BRX_ALIGN_INTERVAL 25     /* settings.ALIGNMENT_INTERVAL */
 #define BRX_ALIGN_SIZE 1000       /* settings.ALIGNMENT_SIZE     */
@@ -815,11 +814,10 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
     }
 }
 
-template <int MAXG, int GLO, int GHI, int WG_LANES = 0>
+template <int MAXG, int GLO, int GHI>
 __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                    uint32_t *queue, uint32_t *retries, int phase, const uint8_t *Fbuf,
-                                                   uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk,
-                                                   uint8_t *slab_base, uint64_t slab_units) {
+                                                   uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
     const int lane = lane_id();
     for (;;) {
         const uint32_t qi = q_begin + wave_pop(queue);
@@ -837,15 +835,8 @@ __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d,
         uint8_t *seq = seqbuf + s.seq_off;                                 /* joined and padded by k_fin_join */
         uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
         const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
-        /* BRX_FIN_WG: reads whose band fits the workgroup aligner were aligned by k_fin_align_wg (same test there) */
-        if constexpr (WG_LANES != 0) {
-            if (brx_wg_eligible(m, n, s.ub, (phase == 0 && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0, WG_LANES, s.units - col_units, nullptr)) continue;
-        }
-        /* the traceback store is dead once the read's path is written: with slabs (BRX_TB_SLABS) every persistent wave owns
-           one store sized for the largest read of its class and reuses it, instead of every read of the set owning a region */
-        uint2 *tb = slab_units ? reinterpret_cast<uint2 *>(slab_base) + (uint64_t)blockIdx.x * slab_units
-                               : reinterpret_cast<uint2 *>(tb_base + s.tb_off);
-        const uint64_t tb_cap = slab_units ? slab_units : s.units - col_units;
+        uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
+        const uint64_t tb_cap = s.units - col_units;
         int ncols = 0, nmatch = 0; bool nospace = false;
         const bool ok = brx_wave_align<MAXG, (GLO < MAXG ? GLO : MAXG)>(seq, (int)m, F, (int)n, (int)s.ub, tb, tb_cap, ops_end, &ncols, &nmatch,
                                              &nospace, nullptr, aclk, (phase == 0 && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0);
@@ -866,148 +857,10 @@ __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d,
     }
 }
 
-/* BRX_FIN_WG=1: the wide band classes with one read per WORKGROUP of W waves (brx_wg_align.h).  Reads whose band does not fit
-   64 W lanes with one word each (or whose store was sized too small for that geometry) are left to k_fin_align, which is
-   launched behind this kernel with the same eligibility test. */
-template <int W, int GLO, int GHI>
-__global__ void __launch_bounds__(64 * W) k_fin_align_wg(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
-                                                        uint32_t *queue, uint32_t *retries, int phase, const uint8_t *Fbuf,
-                                                        uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
-    __shared__ uint32_t s_next;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (;;) {
-        if (wave == 0) { const uint32_t q = q_begin + wave_pop(queue); if (lane == 0) s_next = q; }
-        __syncthreads();
-        const uint32_t qi = s_next;
-        __syncthreads();
-        if (qi >= q_end) break;
-        const uint32_t r = order[qi];
-        const RS s = rs[r];
-        if (s.n == 0) continue;
-        const int klass = (int)(s.klass & 0xFFFFu);
-        if (klass < GLO || klass > GHI) continue;
-        if (((s.klass & BRX_KL_RETRY) != 0u) != (phase != 0)) continue;
-        const uint32_t n = s.n, m = s.m;
-        const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
-        BrxGeom g;
-        if (!brx_wg_eligible(m, n, s.ub, (phase == 0 && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0, 64 * W, s.units - col_units, &g)) continue;
-        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
-        const uint8_t *F = Fbuf + s.F_off;
-        uint8_t *seq = seqbuf + s.seq_off;
-        uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
-        brx_align_forward_wg<W>(seq, F, g, tb);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();                                                    /* every wave's stores are visible to wave 0 */
-        if (wave == 0) {
-            uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
-            int ncols = 0, nmatch = 0;
-            bool ok = brx_align_traceback(seq, F, g, tb, ops_end, &ncols, &nmatch);
-            if (ok && (ncols - nmatch) > (int)s.ub) ok = false;
-            if (lane == 0) {
-                RS *o = &rs[r];
-                if (!ok && phase == 0) {
-                    o->klass = s.klass | BRX_KL_RETRY;
-                    atomicAdd(retries, 1u);
-                    clk[(uint64_t)r * 8 + 2] = 1;
-                } else {
-                    o->status = s.status | (ok ? 0u : BRX_RS_BAND);
-                    o->n_cols = (uint32_t)ncols; o->n_match = (uint32_t)nmatch;
-                }
-                uint64_t *ck = clk + (uint64_t)r * 8;
-                ck[3] = __builtin_amdgcn_s_memtime() - t_begin; ck[7] = (uint64_t)klass | 0x200u;       /* + 0x200: aligned by a workgroup */
-            }
-        }
-    }
-}
-
-#include "brx_pair.h"
-/* BRX_FIN_PAIR=1: the one-word band class with two reads per wave where both bands fit half a wave (brx_pair.h); reads that
-   do not pair -- wider bands, an odd one out, empty sequences -- go through brx_wave_align as in k_fin_align<1, 1, 1>. */
-__global__ void __launch_bounds__(64, 3) k_fin_align_pair(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
-                                                         uint32_t *queue, uint32_t *retries, int phase, const uint8_t *Fbuf,
-                                                         uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
-    const int lane = lane_id();
-    bool drained = false;
-    while (!drained) {
-        /* ---- up to two reads of this class and phase ---- */
-        uint32_t rr[2] = {0u, 0u};
-        int nc = 0;
-        while (nc < 2) {
-            const uint32_t qi = q_begin + wave_pop(queue);
-            if (qi >= q_end) { drained = true; break; }
-            const uint32_t r = order[qi];
-            const RS s = rs[r];
-            if (s.n == 0) continue;
-            if ((int)(s.klass & 0xFFFFu) != 1) continue;
-            if (((s.klass & BRX_KL_RETRY) != 0u) != (phase != 0)) continue;
-            rr[nc++] = r;
-        }
-        if (nc == 0) break;
-        RS s2[2];
-        BrxGeom g2[2];
-        bool pair_ok = nc == 2;
-        uint64_t col_units[2] = {0, 0};
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i >= nc) { g2[i] = brx_make_geom(1, 1, 0); g2[i].NS = 0; continue; }
-            s2[i] = rs[rr[i]];
-            col_units[i] = ((uint64_t)s2[i].m * 4 + 7) / 8 + 2;
-            const int hmul = (phase == 0 && !(s2[i].klass & BRX_KL_FULL)) ? d.tb_hmul : 0;
-            g2[i] = brx_make_geom((int)s2[i].m > 0 ? (int)s2[i].m : 1, (int)s2[i].n > 0 ? (int)s2[i].n : 1, (int)s2[i].ub, hmul);
-            pair_ok = pair_ok && s2[i].m > 0 && brx_pair_eligible(g2[i]) && brx_align_units(g2[i]) <= s2[i].units - col_units[i];
-        }
-        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
-        bool okv[2] = {false, false};
-        int ncolsv[2] = {0, 0}, nmatchv[2] = {0, 0};
-        if (pair_ok) {
-            brx_align_forward_k4_pair(seqbuf + s2[0].seq_off, Fbuf + s2[0].F_off, g2[0], reinterpret_cast<uint2 *>(tb_base + s2[0].tb_off),
-                                      seqbuf + s2[1].seq_off, Fbuf + s2[1].F_off, g2[1], reinterpret_cast<uint2 *>(tb_base + s2[1].tb_off));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-#pragma unroll 1
-            for (int i = 0; i < 2; ++i) {
-                const RS &s = s2[i];
-                uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)s.n + (uint64_t)s.m;
-                bool ok = brx_align_traceback(seqbuf + s.seq_off, Fbuf + s.F_off, g2[i], reinterpret_cast<uint2 *>(tb_base + s.tb_off), ops_end,
-                                              &ncolsv[i], &nmatchv[i]);
-                if (ok && (ncolsv[i] - nmatchv[i]) > (int)s.ub) ok = false;
-                okv[i] = ok;
-            }
-        } else {
-#pragma unroll 1
-            for (int i = 0; i < nc; ++i) {
-                const RS &s = s2[i];
-                uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)s.n + (uint64_t)s.m;
-                bool nospace = false;
-                okv[i] = brx_wave_align<1, 1>(seqbuf + s.seq_off, (int)s.m, Fbuf + s.F_off, (int)s.n, (int)s.ub, reinterpret_cast<uint2 *>(tb_base + s.tb_off),
-                                              s.units - col_units[i], ops_end, &ncolsv[i], &nmatchv[i], &nospace, nullptr, nullptr,
-                                              (phase == 0 && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0);
-            }
-        }
-        if (lane == 0) {
-            for (int i = 0; i < nc; ++i) {
-                const RS &s = s2[i];
-                RS *o = &rs[rr[i]];
-                if (!okv[i] && phase == 0) {
-                    o->klass = s.klass | BRX_KL_RETRY;
-                    atomicAdd(retries, 1u);
-                    clk[(uint64_t)rr[i] * 8 + 2] = 1;
-                } else {
-                    o->status = s.status | (okv[i] ? 0u : BRX_RS_BAND);
-                    o->n_cols = (uint32_t)ncolsv[i]; o->n_match = (uint32_t)nmatchv[i];
-                }
-                uint64_t *ck = clk + (uint64_t)rr[i] * 8;
-                ck[3] = (__builtin_amdgcn_s_memtime() - t_begin) / (uint64_t)nc; ck[7] = 1u | (pair_ok ? 0x100u : 0u);       /* brx_last_read_cycles[7]: band class, + 0x100 = aligned as one of a pair */
-            }
-        }
-    }
-}
-
 #define BRX_QS_HOT_MAX 128
 __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                     uint32_t *queue, int phase, int klo, int khi, uint8_t *seqbuf, const uint8_t *opsbuf,
-                                                    uint8_t *tb_base, uint64_t *clk, int slabs) {
+                                                    uint8_t *tb_base, uint64_t *clk) {
     __shared__ uint32_t qhist[256];
     __shared__ uint32_t hot_thr[BRX_QS_HOT_MAX], hot_score[BRX_QS_HOT_MAX];
     const int lane = lane_id();
@@ -1042,7 +895,7 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
         const uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
         uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
         const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
-        uint32_t *col_of = reinterpret_cast<uint32_t *>(slabs ? tb : tb + (s.units - col_units));      /* slabs: tb_off is the read's col_of[] */
+        uint32_t *col_of = reinterpret_cast<uint32_t *>(tb + (s.units - col_units));
         const bool ok = !(s.status & BRX_RS_BAND);
         const uint32_t ncols = s.n_cols;
         const uint8_t *ops = ops_end - ncols;

@@ -85,14 +85,6 @@ ROUTES = [
     # the one-launch mutate stage (BRX_MUTATE_WG=1: workgroups of 8 reads, packed window alignments)
     {'BRX_MUTATE_WG': 1},
     {'BRX_MUTATE_WG': 1, 'BRX_HEAD_READS': 9, 'BRX_TB_WINDOW': -1},              # final stage split into a head and a bulk set, retry phase
-    # one traceback store per persistent wave instead of one per read (BRX_TB_SLABS)
-    {'BRX_TB_SLABS': 1},
-    {'BRX_TB_SLABS': 1, 'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_TB_WINDOW': -1},   # two sets, retry phase with full stores
-    {'BRX_TB_SLABS': 1, 'BRX_TB_WINDOW': 0, 'BRX_WIDE_STREAM': 0, 'BRX_WAVES_PER_CU': 1},
-    # two final alignments per wave for narrow one-word bands (BRX_FIN_PAIR, brx_pair.h)
-    {'BRX_FIN_PAIR': 1},
-    {'BRX_FIN_PAIR': 1, 'BRX_TB_WINDOW': -1, 'BRX_HEAD_READS': 9, 'BRX_TAIL_READS': 6},      # two sets, most reads repeat with the full store
-    {'BRX_FIN_PAIR': 1, 'BRX_TB_WINDOW': 0, 'BRX_WAVES_PER_CU': 1},
 ]
 
 
@@ -114,9 +106,6 @@ def test_pipeline_routes_equal_the_oracle(env, monkeypatch):
         assert eng.mutate_passes() > 3
     if env.get('BRX_MUTATE_WG') == 1:
         assert eng.mutate_passes() == 1
-    if env.get('BRX_FIN_PAIR') == 1 and env.get('BRX_TB_WINDOW') != -1:
-        paired = (eng.read_cycles(n)[:, 7] & 0x100) != 0
-        assert paired.sum() >= n // 2 and paired.sum() % 2 == 0      # most reads were aligned two to a wave
 
 
 def test_lds_threshold_build_variant(monkeypatch):
@@ -232,50 +221,6 @@ def _window_overflow(tmp_path):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert int(sh["padded_len"][0]) > 8 * 900                      # the windows really overflowed
     return eng
-
-
-def test_wide_bands_on_a_workgroup_of_waves(monkeypatch):
-    """BRX_FIN_WG=1 (csrc/brx_wg_align.h): the final alignments of the 4-word and the 8/16-word band classes run as ONE
-    systolic array of 256 / 1024 lanes with one word per lane -- carries through LDS across the waves, a barrier per trip,
-    the target ring of the whole workgroup in LDS.  A fragment mutated down to ~60 % identity (a band of ~5 000 diagonals: the
-    four-word class, 256 lanes) beside a short one that stays with the one-wave kernel; the 1024-lane instance is the next test."""
-    monkeypatch.setenv('BRX_FIN_WG', '1')
-    monkeypatch.setenv('BRX_MUTATE_WG', '0')
-    rng = np.random.default_rng(8)
-    pref, _ = H.small_reference()
-    eng = H.configure(emu_engine(), pref, 'random', 'ideal', SimParams())
-    orc = H.configure(H.oracle_engine(), pref, 'random', 'ideal', SimParams())
-    frags = [rng.integers(0, 4, n).astype(np.uint8) for n in (7000, 500)]
-    targets = [0.6, 0.9]
-    rh, sh = eng.sequence_fragments(3, 0, frags, targets)
-    ro, so = orc.sequence_fragments(3, 0, frags, targets)
-    for f in STAT_FIELDS:
-        assert (sh[f] == so[f]).all(), f
-    for a, b in zip(rh, ro):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-    marks = eng.read_cycles(2)[:, 7]
-    assert (marks[0] & 0x200) and not (marks[1] & 0x200), marks              # the wide read was aligned by a workgroup
-    assert int(marks[0]) & 0xFF == 4, marks
-
-
-def test_workgroup_aligner_refills_its_target_ring(monkeypatch):
-    """A fragment of 21 kb (more than the five 4 KB chunks the 1024-lane ring holds and prefetches at the start) with an
-    N run inside (the rolled path of a trip) through the 16-wave aligner."""
-    monkeypatch.setenv('BRX_FIN_WG', '1')
-    monkeypatch.setenv('BRX_MUTATE_WG', '0')
-    rng = np.random.default_rng(9)
-    pref, _ = H.small_reference()
-    eng = H.configure(emu_engine(), pref, 'random', 'ideal', SimParams())
-    orc = H.configure(H.oracle_engine(), pref, 'random', 'ideal', SimParams())
-    frag = rng.integers(0, 4, 21000).astype(np.uint8)
-    frag[9000:9040] = 4
-    rh, sh = eng.sequence_fragments(5, 0, [frag], [0.6])
-    ro, so = orc.sequence_fragments(5, 0, [frag], [0.6])
-    for f in STAT_FIELDS:
-        assert (sh[f] == so[f]).all(), f
-    assert np.array_equal(rh[0][0], ro[0][0]) and np.array_equal(rh[0][1], ro[0][1])
-    mark = int(eng.read_cycles(1)[0, 7])
-    assert mark & 0x200 and (mark & 0xFF) in (8, 16), mark
 
 
 def test_final_stage_in_several_scratch_chunks(monkeypatch):

@@ -117,40 +117,3 @@ def test_alternative_kernel_routes_give_the_same_bytes(env, monkeypatch):
     if env.get('BRX_TB_WINDOW') == '-1':
         assert misses > 50, misses                     # the retry pass really ran
     eng.close()
-
-
-EXPERIMENTAL = [{'BRX_FIN_PAIR': '1'}, {'BRX_FIN_PAIR': '1', 'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1'},
-                {'BRX_TB_SLABS': '1'}, {'BRX_TB_SLABS': '1', 'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1'},
-                {'BRX_FIN_WG': '1'}, {'BRX_FIN_WG': '1', 'BRX_FIN_PAIR': '1', 'BRX_TB_WINDOW': '-1'}]
-
-
-@pytest.mark.skipif(os.environ.get('BRX_TEST_EXPERIMENTAL') != '1',
-                    reason='routes that are bit-exact on the interpreted kernels but were finished after the round\'s GPU budget: '
-                           'BRX_TEST_EXPERIMENTAL=1 runs them on the MI355X')
-@pytest.mark.parametrize('env', EXPERIMENTAL)
-def test_experimental_routes_give_the_same_bytes(env, monkeypatch):
-    test_alternative_kernel_routes_give_the_same_bytes(env, monkeypatch)
-
-
-@pytest.mark.skipif(os.environ.get('BRX_TEST_EXPERIMENTAL') != '1', reason='BRX_TEST_EXPERIMENTAL=1 runs the experimental routes on the MI355X')
-def test_experimental_workgroup_aligner_on_wide_bands(monkeypatch):
-    """BRX_FIN_WG=1 with reads that really reach the four-word and the wider band classes (long fragments mutated down to ~60 %
-    identity, one with an N run): bytes and statistics of the oracle, and the reads were aligned by a workgroup."""
-    from badread_amd.engine import HipEngine
-    monkeypatch.setenv('BRX_FIN_WG', '1')
-    rng = np.random.default_rng(8)
-    pref, _ = H.small_reference()
-    eng = H.configure(HipEngine(0, scratch_bytes=4 << 30), pref, 'random', 'ideal', SimParams())
-    orc = H.configure(H.oracle_engine(), pref, 'random', 'ideal', SimParams())
-    frags = [rng.integers(0, 4, n).astype(np.uint8) for n in (7000, 21000, 30000, 500)]
-    frags[1][9000:9040] = 4
-    targets = [0.6, 0.6, 0.62, 0.9]
-    rh, sh = eng.sequence_fragments(3, 0, frags, targets)
-    ro, so = orc.sequence_fragments(3, 0, frags, targets)
-    for f in STAT_FIELDS:
-        assert (sh[f] == so[f]).all(), f
-    for a, b in zip(rh, ro):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-    marks = eng.read_cycles(4)[:, 7]
-    assert (marks[:3] & 0x200).all() and not (marks[3] & 0x200), marks
-    eng.close()
