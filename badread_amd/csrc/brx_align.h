@@ -189,7 +189,7 @@ __shared__ uint32_t brx_ring32[BRX_RING_BYTES / 4];
 /* Kernels whose workgroups hold several independent waves (k_mutate_seg: 8 waves sharing the LDS copy of the error
  * model's thresholds) give every wave its own window (template parameter MW of the forward passes); a kernel only pays
  * for the variant it references. */
-#define BRX_RING_WAVES 8
+#define BRX_RING_WAVES 4
 __shared__ uint32_t brx_ring32_mw[BRX_RING_WAVES][BRX_RING_BYTES / 4];
 template <bool MW> __device__ __forceinline__ uint32_t *brx_ring() {
     if constexpr (MW) return brx_ring32_mw[threadIdx.x >> 6]; else return brx_ring32;

@@ -21,7 +21,6 @@
 
 #include "brx_kernels.h"
 
-#define BRX_MAX_CHUNKS 60
 #define BRX_KEV_MAX 2048
 
 struct brx_ctx {
@@ -47,6 +46,9 @@ struct brx_ctx {
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
     int run_wg;                  /* BRX_RUN_WG=1: head chain and tail run as k_mutate_wg (packed identity checks) instead of k_mutate_seg<true> (default 0: measured slower) */
+    int persist;                 /* BRX_MUTATE_PERSIST (default 1): the mutate stage is ONE persistent launch with device queues (brx_persist.h); 0 = round 2's pass pipeline */
+    uint32_t ps_wg_per_cu, ps_long, ps_low, ps_patience, ps_exit_idle;   /* BRX_PS_WG_PER_CU, BRX_PS_LONG, BRX_PS_LOW, BRX_PS_PATIENCE (PsArgs) */
+    uint32_t ps_stats[8];        /* PQGlobal of the last batch */
     int mutate_wg;               /* BRX_MUTATE_WG=1: the mutate stage is one launch of k_mutate_wg (brx_mutate_wg.h; measured slower at batch scale); default 0 = the pass pipeline */
     uint32_t fin_head_reads;     /* BRX_FIN_HEAD_READS: the longest reads of a batch form the head set of the final stage (side streams) */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
@@ -161,6 +163,12 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *rw = getenv("BRX_RUN_WG"); c->run_wg = rw ? atoi(rw) : 0; }
     { const char *mw = getenv("BRX_MUTATE_WG"); c->mutate_wg = mw ? atoi(mw) : 0; }
+    { const char *v = getenv("BRX_MUTATE_PERSIST"); c->persist = v ? atoi(v) : 1; }
+    { const char *v = getenv("BRX_PS_WG_PER_CU"); c->ps_wg_per_cu = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 2u; }
+    { const char *v = getenv("BRX_PS_LONG"); c->ps_long = v ? (uint32_t)atoi(v) : 1000000u; }
+    { const char *v = getenv("BRX_PS_LOW"); c->ps_low = v ? (uint32_t)atoi(v) : 512u; }
+    { const char *v = getenv("BRX_PS_PATIENCE"); c->ps_patience = v ? (uint32_t)atoi(v) : 8u; }
+    { const char *v = getenv("BRX_PS_EXIT_IDLE"); c->ps_exit_idle = v ? (uint32_t)atoi(v) : 64u; }
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
@@ -281,6 +289,11 @@ struct KTimer {
 #define KTIMED(kind, stream) KTimer ktimer_##__LINE__(c, (kind), (stream))
 
 extern "C" uint32_t brx_last_mutate_passes(const brx_ctx *c) { return c ? c->mutate_passes : 0; }
+extern "C" int brx_last_mutate_stats(const brx_ctx *c, uint32_t out[8]) {
+    if (!c || !out) return BRX_E_ARG;
+    for (int i = 0; i < 8; ++i) out[i] = c->ps_stats[i];
+    return BRX_OK;
+}
 extern "C" uint32_t brx_last_final_launches(const brx_ctx *c) { return c ? c->final_launches : 0; }
 extern "C" uint32_t brx_last_window_misses(const brx_ctx *c) { return c ? c->window_misses : 0; }
 
@@ -297,9 +310,28 @@ static int scratch_short(brx_ctx *c, size_t needed) {
 /* ---------------------------------------------------------------------------------------------
  * the shared pipeline: plan (or raw fragments) -> build -> mutate -> final -> records
  * ------------------------------------------------------------------------------------------- */
+static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t n_reads, bool raw,
+                             const uint8_t *d_frags, const uint64_t *d_frag_off, const double *d_target,
+                             uint8_t *d_out, size_t out_cap, brx_read_stats *d_stats, size_t *out_bytes, hipStream_t st);
+
+/* A batch runs on the caller's stream AND on the context's side streams.  Whatever the status, nothing of the batch is
+   in flight when the call returns: an early BRX_E_SCRATCH / BRX_E_OUTPUT return (the caller then replaces the arena or the
+   output buffer and repeats the batch) must not leave kernels of the abandoned attempt reading and writing the old arena. */
 static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t n_reads, bool raw,
                         const uint8_t *d_frags, const uint64_t *d_frag_off, const double *d_target,
                         uint8_t *d_out, size_t out_cap, brx_read_stats *d_stats, size_t *out_bytes, hipStream_t st) {
+    const int rc = run_pipeline_impl(c, seed, first_read, n_reads, raw, d_frags, d_frag_off, d_target, d_out, out_cap, d_stats, out_bytes, st);
+    if (rc != BRX_OK && rc != BRX_E_ARG && rc != BRX_E_STATE) {
+        (void)hipStreamSynchronize(st);
+        if (c->side) (void)hipStreamSynchronize(c->side);
+        if (c->side2) (void)hipStreamSynchronize(c->side2);
+    }
+    return rc;
+}
+
+static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t n_reads, bool raw,
+                             const uint8_t *d_frags, const uint64_t *d_frag_off, const double *d_target,
+                             uint8_t *d_out, size_t out_cap, brx_read_stats *d_stats, size_t *out_bytes, hipStream_t st) {
     if (!c->has_em || !c->has_qm) return fail(c, BRX_E_STATE, "error/qscore model not set");
     if (!raw && (!c->has_ref || !c->has_params)) return fail(c, BRX_E_STATE, "reference or parameters not set");
     if (!c->scratch) return fail(c, BRX_E_STATE, "scratch arena not set");
@@ -317,7 +349,8 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     uint64_t *totals = (uint64_t *)A.take(16 * sizeof(uint64_t));
     uint32_t *order = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *counters = (uint32_t *)A.take(4096 * 4);      /* [0] join queue, [1] flags, [2] window misses of the final stage, [16 + 16 x (phase, chunk)] final-stage queue heads */
-    uint64_t *units_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
+    uint64_t *units_sorted = (uint64_t *)A.take(((size_t)n_reads + 32) * 8);
+    uint32_t *fin_lists = (uint32_t *)A.take(((size_t)n_reads + 32) * 4);   /* class-pure read lists of the final align kernels */
     uint64_t *tboff_sorted = (uint64_t *)A.take((size_t)n_reads * 8);
     uint64_t *clk = (uint64_t *)A.take((size_t)n_reads * 64);     /* per-read cycle counters, brx_last_read_cycles() */
     uint64_t *phase = (uint64_t *)A.take((size_t)n_reads * 64);   /* mutate phase cycles (BRX_PROFILE=1), brx_last_phase_cycles() */
@@ -353,9 +386,13 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     PPiece *pieces = (PPiece *)A.take((size_t)(tot_pieces + 1) * sizeof(PPiece));
     uint8_t *Fbuf = (uint8_t *)A.take((size_t)f_bytes + 64);
     uint32_t *repl = (uint32_t *)A.take(((size_t)f_bytes + 64) * 4);
-    const uint32_t side_waves = std::min<uint32_t>(n_reads, 4096u);                 /* wave-level window aligner / legacy */
+    const bool use_ps = c->persist && !c->mutate_inline && !c->mutate_wg;
+    /* the persistent mutate stage (brx_persist.h): workgroups of BRX_PS_WAVES waves; per wave the window bytes + traceback store
+       of the in-place aligner (win_bytes), per workgroup one move-code store of the lane aligner */
+    const uint32_t ps_blocks = std::max<uint32_t>(1u, std::min<uint32_t>((n_reads + BRX_PS_WAVES - 1) / BRX_PS_WAVES, (uint32_t)c->n_cu * c->ps_wg_per_cu));
+    const uint32_t side_waves = use_ps ? std::min<uint32_t>(n_reads, ps_blocks * BRX_PS_WAVES) : std::min<uint32_t>(n_reads, 4096u);   /* wave-level window aligner / legacy */
     const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, 512u);      /* lane-level window aligner          */
-    uint8_t *win = (uint8_t *)A.take((size_t)(side_waves + BRX_SEG_WAVES) * c->win_bytes);      /* one slot per wave; workgroups of BRX_SEG_WAVES */
+    uint8_t *win = (uint8_t *)A.take((size_t)((use_ps ? ps_blocks * BRX_PS_WAVES : side_waves) + BRX_SEG_WAVES) * c->win_bytes);      /* one slot per wave */
     MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
     uint32_t *mctr = (uint32_t *)A.take(8 * MC_WORDS * sizeof(uint32_t));   /* pass counters 0/1, 2 first bulk input, 3 bulk legacy, 4 head input, 5 head legacy, 6 head pass */
     uint32_t *active_a = (uint32_t *)A.take((size_t)n_reads * 4);
@@ -365,16 +402,22 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     uint32_t *req_legacy = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy_head = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *active_head = (uint32_t *)A.take((size_t)n_reads * 4);
-    uint8_t *winbuf = (uint8_t *)A.take((size_t)n_reads * BRX_WIN_STRIDE + 64);
-    const bool use_wg = c->mutate_wg && !c->mutate_inline;
+    uint8_t *winbuf = (uint8_t *)A.take((use_ps && n_reads <= 2 * c->head_reads) ? 64 : (size_t)n_reads * BRX_WIN_STRIDE + 64);   /* window slots per READ: the pass pipeline, the head chain */
+    uint32_t ps_ring = 64;
+    while (ps_ring < (n_reads + BRX_PQ_NX - 1) / BRX_PQ_NX + 1) ps_ring *= 2;
+    PQ *ps_pq = (PQ *)A.take(use_ps ? BRX_PQ_NX * sizeof(PQ) + sizeof(PQGlobal) + 2 * (size_t)BRX_PQ_NX * ps_ring * 4 : 64);   /* sets, global block, lane rings, return rings: one memset */
+    uint32_t *ps_planes = (uint32_t *)A.take(use_ps ? (size_t)n_reads * BRX_PL_WORDS * 4 : 64);
+    uint2 *ps_lane_tb = (uint2 *)A.take(use_ps ? (size_t)ps_blocks * BRX_PL_TB_UNITS * sizeof(uint2) : 64);
+    const bool use_wg = use_ps || (c->mutate_wg && !c->mutate_inline);      /* one launch for the whole mutate stage: the two sets only split the final stage */
     const uint32_t wg_blocks = std::min<uint32_t>((n_reads + BRX_WG_WAVES - 1) / BRX_WG_WAVES, (uint32_t)c->n_cu * 2u);
     uint2 *lane_tb = use_wg ? nullptr : (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
+    (void)lane_waves;
     /* traceback stores of the packed window aligner: one set of 8 per workgroup of k_mutate_wg, or per wave of k_win_pack */
     const uint32_t pack_waves = std::min<uint32_t>((std::min<uint32_t>(n_reads, c->lane_threshold) + BRX_PACK_NG - 1) / BRX_PACK_NG, (uint32_t)c->n_cu * 4u);
     const uint32_t tail_eff = c->tail_reads != 0xFFFFFFFFu ? c->tail_reads : std::max<uint32_t>(1024u, n_reads / 12u);
     const bool all_head = c->mutate_inline || (!use_wg && n_reads <= tail_eff);      /* the whole batch in one run-to-completion launch */
     const uint32_t run_blocks = ((all_head ? n_reads : std::min<uint32_t>(n_reads, std::max<uint32_t>(tail_eff, 1u))) + BRX_WG_WAVES - 1) / BRX_WG_WAVES;   /* the tail (or everything) as k_mutate_wg */
-    uint2 *pack_tb = (uint2 *)A.take((size_t)(use_wg ? wg_blocks : std::max<uint32_t>(std::max(pack_waves, run_blocks), 1u)) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
+    uint2 *pack_tb = (uint2 *)A.take(use_ps ? 64 : (size_t)(use_wg ? wg_blocks : std::max<uint32_t>(std::max(pack_waves, run_blocks), 1u)) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
     if (!raw) { KTIMED(BRX_KERN_PLAN, st); hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces); }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_PLAN], st));
@@ -409,13 +452,14 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
        64-read tail (218 passes, the small ones with the packed window aligner) 1.63, 512-read tail 1.82 -- a pass costs
        1.5-2.6 ms beside the other batches' kernels whatever it aligns, an in-place cycle 0.3-0.6 ms. */
     const uint32_t n_mh = all_head ? n_reads
+                          : use_ps ? (n_reads > 2 * c->head_reads ? c->head_reads : 0u)      /* a small batch goes through the persistent launch whole */
                           : use_wg ? 0u : std::min<uint32_t>(c->head_reads, n_reads);
     const uint32_t n_mb = n_reads - n_mh;
     const uint32_t n_head = n_mh ? n_mh : (n_reads <= 2 * c->fin_head_reads ? 0u : c->fin_head_reads);
     const uint32_t n_bulk = n_reads - n_head;
     uint8_t *win_head = nullptr;
     uint2 *pack_head = pack_tb;
-    if (n_mh && n_mb && !use_wg) {
+    if (n_mh && n_mb && (!use_wg || use_ps)) {
         pack_head = (uint2 *)A.take((size_t)((n_mh + BRX_WG_WAVES - 1) / BRX_WG_WAVES) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
         win_head = (uint8_t *)A.take((size_t)(std::min(n_mh, side_waves) + BRX_SEG_WAVES) * c->win_bytes);
         if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
@@ -427,130 +471,150 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         hipStream_t st, wide;          /* its stream; the stream of the widest band class (may be the same) */
         int id;                        /* 0 head, 1 bulk: selects counter slots and events */
         bool launched, wide_forked;
-        size_t tb_at, tb_cap;
+        size_t tb_at, tb_cap, col_bytes;   /* the set's region of the arena: col_of[] of its reads, then the slabs of its align kernels */
         uint64_t bases_by_class[5];    /* G = 1, 2, 4, 8+, all */
     };
     FinalSet sets[2];
-    sets[0] = FinalSet{0, n_head, s_head, (c->wide_stream && n_bulk) ? c->side2 : s_head, 0, false, false, 0, 0, {0, 0, 0, 0, 0}};
-    sets[1] = FinalSet{n_head, n_reads, st, st, 1, false, false, 0, 0, {0, 0, 0, 0, 0}};
-    uint64_t *set_units = units_sorted, *set_tboff = tboff_sorted;      /* staging arrays, indexed by order position */
-    std::vector<uint64_t> h_tboff(n_reads), h_units(n_reads);
+    sets[0] = FinalSet{0, n_head, s_head, (c->wide_stream && n_bulk) ? c->side2 : s_head, 0, false, false, 0, 0, 0, {0, 0, 0, 0, 0}};
+    sets[1] = FinalSet{n_head, n_reads, st, st, 1, false, false, 0, 0, 0, {0, 0, 0, 0, 0}};
+    uint64_t *set_tboff = tboff_sorted;       /* staging array of the col_of[] offsets, indexed by order position */
+    uint64_t *fin_slabs = units_sorted;        /* slab offset tables of the sets' align kernels (n_reads + 16 words) */
+    std::vector<uint64_t> h_tboff(n_reads);
     /* counters: [0],[3] join queues of head / bulk; [1] flags; [2],[4] window misses of head / bulk;
-       [16 + 16 x ((set x 2 + phase) x BRX_MAX_CHUNKS + chunk)] final-stage queue heads */
+       [16 + 16 x (set x 2 + phase)] final-stage queue heads (four 64-bit class counters, two qscore counters) */
     auto set_counter = [&](const FinalSet &S, int which) -> uint32_t * { return counters + (which == 0 ? (S.id ? 3 : 0) : (S.id ? 4 : 2)); };
     bool legacy_handled = false;       /* the whole-read fallback already ran for every read (no separate mutate head chain) */
     uint64_t tail_bases = 0;           /* kernel statistics: bases of the bulk reads that finished in the in-place tail */
 
-    /* launches of one phase of one set (phase 0: windowed store for every read; phase 1: full store for the misses) */
+    /* launches of one phase of one set (phase 0: windowed store for every read; phase 1: full store for the misses).
+     *
+     * Traceback stores are SLABS owned by the persistent waves of the align kernels, not regions owned by reads: a read's
+     * store is dead as soon as its path (the ops) is written, and round 2's one-region-per-read layout held ~50 GB of them
+     * per 49152-read batch.  A band class walks ITS reads (a class-pure list, longest first) with one 64-bit counter whose
+     * low half is the list position and whose high half counts the waves that have started: a wave's FIRST pop adds to
+     * both halves in one atomic, so its ticket t is never larger than the position i0 it popped, and everything it will
+     * ever pop comes after i0.  Slab t is therefore sized max(units of list[t..]) -- the suffix maximum -- and the set
+     * needs the sum of the first W suffix maxima (W = waves of the class) instead of the sum over all its reads
+     * (measured model, configs[3]: 51.7 -> 19 GB per batch at 4096 / 1024 / 256 / 64 waves).  A set that does not fit
+     * halves the waves of its fattest class until it does; only when ONE wave per class does not fit is the arena short.
+     * col_of[] (k_fin_qscore: 4 bytes per read base) stays per read, in front of the slabs. */
     auto launch_final_phase = [&](FinalSet &S, int phase) -> int {
         const uint32_t ns = S.e - S.b;
-        uint64_t max_units = 0, sum_units = 0;
+        std::vector<uint32_t> cls_list[4];
+        std::vector<uint64_t> cls_units[4];
+        uint64_t col_total = 0;
         for (uint32_t i = S.b; i < S.e; ++i) {
             const RS &r = h_rs[h_order[i]];
-            uint64_t u = r.units;
-            if (phase == 1) {
-                bool too_wide;
-                u = (r.n && (r.klass & BRX_KL_RETRY)) ? brx_final_units(r.m, r.n, r.ub, 0, &too_wide) : 0;
-            }
-            h_units[i] = u;
-            max_units = std::max(max_units, u); sum_units += u;
+            const uint64_t col_units = r.n ? ((((uint64_t)r.m * 4 + 7) / 8 + 2 + 31) & ~31ull) : 0;
+            h_tboff[i] = col_total * 8;                       /* RS.tb_off: byte offset of the read's col_of[] in the set's region */
+            col_total += col_units;
+            if (!r.n) continue;
+            if (phase == 1 && !(r.klass & BRX_KL_RETRY)) continue;
+            bool too_wide = false;
+            const uint64_t raw_cols = ((uint64_t)r.m * 4 + 7) / 8 + 2;
+            const uint64_t u = (phase == 1 ? brx_final_units(r.m, r.n, r.ub, 0, &too_wide) : r.units) - raw_cols;     /* the aligner's share */
+            const uint32_t kl = r.klass & 0xFFFFu;
+            const int k = kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3;
+            cls_list[k].push_back(h_order[i]);
+            cls_units[k].push_back((u + 31) & ~31ull);
         }
+        const uint32_t limit[4] = {(uint32_t)c->n_cu * (uint32_t)c->waves_per_cu, (uint32_t)c->n_cu * (uint32_t)c->waves_per_cu,
+                                   (uint32_t)c->n_cu * 8u, (uint32_t)c->n_cu * 4u};
+        uint32_t grid[4];
+        std::vector<uint64_t> sufmax[4];
+        for (int k = 0; k < 4; ++k) {
+            const size_t n = cls_list[k].size();
+            sufmax[k].assign(n + 1, 0);
+            for (size_t x = n; x-- > 0;) sufmax[k][x] = std::max(sufmax[k][x + 1], cls_units[k][x]);
+            grid[k] = (uint32_t)std::min<size_t>(n, limit[k]);
+        }
+        auto slab_units = [&](int k) { uint64_t t = 0; for (uint32_t w = 0; w < grid[k]; ++w) t += sufmax[k][w]; return t; };
+        auto need = [&]() { uint64_t t = (phase == 0 ? col_total : 0) + 512; for (int k = 0; k < 4; ++k) t += slab_units(k); return t * 8; };
+        size_t at = (A.used + 255) & ~(size_t)255;
+        size_t left = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
         if (phase == 0) {
-            /* this set's share of the arena: everything that is left, minus (for whichever set comes first) an
-               estimate of what the other set will ask for */
-            const size_t at = (A.used + 255) & ~(size_t)255;
-            size_t left = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
             const FinalSet &O = sets[1 - S.id];
-            if (!O.launched && O.e > O.b) {
-                uint64_t other = 0;
-                for (uint32_t i = O.b; i < O.e; ++i) other += h_rs[h_order[i]].n;
-                const size_t reserve = (size_t)std::min<uint64_t>(other * (O.id == 0 ? 260ull : 110ull) + ((uint64_t)64 << 20), (uint64_t)left / 2);
-                left -= reserve;
-            }
-            const size_t want = (size_t)std::min<uint64_t>((sum_units + 32ull * ns) * 8 + 4096, (uint64_t)left);
-            if ((max_units + 64) * 8 > want) {
-                size_t ask = std::min<uint64_t>((sum_units + 64ull * n_reads) * 8, (uint64_t)8 << 30);
-                return scratch_short(c, c->scratch_bytes + std::max<size_t>((size_t)(max_units + 64) * 8, ask));
-            }
-            S.tb_at = at; S.tb_cap = want;
-            (void)A.take(want);
-        } else if ((sum_units + 32ull * ns) * 8 > S.tb_cap) {
-            /* the full stores of the misses do not fit the region phase 0 used: by now both sets have taken what they
-               need, so the rest of the arena is free */
-            const size_t at = (A.used + 255) & ~(size_t)255;
-            const size_t left = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
-            if (left > S.tb_cap) {
-                const size_t want = (size_t)std::min<uint64_t>((sum_units + 32ull * ns) * 8 + 4096, (uint64_t)left);
-                S.tb_at = at; S.tb_cap = want;
-                (void)A.take(want);
-            }
-            if ((max_units + 64) * 8 > S.tb_cap) return scratch_short(c, c->scratch_bytes + (size_t)(max_units + 64) * 8);
+            if (!O.launched && O.e > O.b) left = left / 2;         /* the other set sizes itself the same way from what is left */
+        } else if (S.tb_cap > left) { at = S.tb_at + S.col_bytes; left = S.tb_cap - S.col_bytes; }      /* the set's own slab area is free again */
+        for (int guard = 0; need() > left && guard < 96; ++guard) {
+            int big = -1;
+            for (int k = 0; k < 4; ++k) if (grid[k] > 1 && (big < 0 || slab_units(k) > slab_units(big))) big = k;
+            if (big < 0) break;
+            grid[big] = (grid[big] + 1) / 2;
         }
-        uint8_t *tb_base = c->scratch + S.tb_at;
-        std::vector<std::pair<uint32_t, uint32_t>> chunks;
+        if (need() > left) return scratch_short(c, c->scratch_bytes + (size_t)(need() - left) + ((size_t)1 << 28));
+        uint8_t *region = c->scratch + at;
+        if (phase == 0) { S.tb_at = at; S.tb_cap = (size_t)need(); S.col_bytes = (size_t)col_total * 8; (void)A.take(S.tb_cap); }
+        else if (at == ((A.used + 255) & ~(size_t)255)) (void)A.take((size_t)need());
+        uint8_t *col_base = c->scratch + S.tb_at;                   /* col_of[] of every read of the set (written by k_fin_qscore) */
+        uint8_t *slab_base = phase == 0 ? region + S.col_bytes : region;
+        /* device tables, in the set's share [S.b, S.e) of the staging arrays: read lists (u32) and slab offsets (u64, in units) */
+        std::vector<uint32_t> h_lists; h_lists.reserve(ns + 8);
+        std::vector<uint64_t> h_slabs; h_slabs.reserve(ns + 16);
+        uint32_t list_at[4], slab_at[4];
+        uint64_t run = 0;
+        for (int k = 0; k < 4; ++k) {
+            list_at[k] = (uint32_t)h_lists.size(); slab_at[k] = (uint32_t)h_slabs.size();
+            h_lists.insert(h_lists.end(), cls_list[k].begin(), cls_list[k].end());
+            for (uint32_t w = 0; w < grid[k]; ++w) { h_slabs.push_back(run); run += sufmax[k][w]; }
+            h_slabs.push_back(run);                                 /* end of the class's last slab */
+        }
+        if (h_slabs.size() > (size_t)ns + 8) return fail(c, BRX_E_INTERNAL, "final stage: slab table larger than its staging area");
+        uint32_t *d_lists = fin_lists + S.b;
+        uint64_t *d_slabs = fin_slabs + S.b + 8 * (size_t)S.id;
+        if (!h_lists.empty()) HIPCHK(c, hipMemcpyAsync(d_lists, h_lists.data(), h_lists.size() * 4, hipMemcpyHostToDevice, S.st));
+        HIPCHK(c, hipMemcpyAsync(d_slabs, h_slabs.data(), h_slabs.size() * 8, hipMemcpyHostToDevice, S.st));
+        if (phase == 0) {
+            HIPCHK(c, hipMemcpyAsync(set_tboff + S.b, h_tboff.data() + S.b, (size_t)ns * 8, hipMemcpyHostToDevice, S.st));
+            hipLaunchKernelGGL(k_set_tboff, dim3((ns + 63) / 64), dim3(64), 0, S.st, ns, rs, order + S.b, set_tboff + S.b, (uint64_t *)nullptr);
+        }
+        HIPCHK(c, hipStreamSynchronize(S.st));                      /* the host vectors above go out of scope */
+        const uint32_t b = S.b, e = S.e;
+        const uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
+        uint32_t *cq = counters + 16 + 16 * (((size_t)S.id * 2 + (size_t)phase));      /* queue heads of this set and phase: [0..7] four 64-bit class counters, [8], [9] qscore */
+        uint32_t *misses = set_counter(S, 1);
+        const uint32_t cnt[4] = {(uint32_t)cls_list[0].size(), (uint32_t)cls_list[1].size(), (uint32_t)cls_list[2].size(), (uint32_t)cls_list[3].size()};
+        /* The widest bands (8+ words per lane: a few dozen reads, each a chain of ~100 k column steps of ~2 us) go first, on
+           the set's wide stream when it has one; then the 4-, 2- and 1-word classes on the set's own stream, each scored
+           (k_fin_qscore) as soon as its class is aligned. */
+        const bool fork = S.wide != S.st;
+        if (fork) {
+            HIPCHK(c, hipEventRecord(c->ev_fork2[S.id], S.st));
+            HIPCHK(c, hipStreamWaitEvent(S.wide, c->ev_fork2[S.id], 0));
+        }
+        if (cnt[3]) {
+            KTIMED(BRX_KERN_FIN_ALIGN16, S.wide);
+            hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(grid[3]), dim3(64), 0, S.wide, dev, rs, d_lists + list_at[3], cnt[3],
+                               reinterpret_cast<unsigned long long *>(cq + 6), d_slabs + slab_at[3], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
+        }
+        if (fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
+        if (cnt[2]) {
+            KTIMED(BRX_KERN_FIN_ALIGN4, S.st);
+            hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(grid[2]), dim3(64), 0, S.st, dev, rs, d_lists + list_at[2], cnt[2],
+                               reinterpret_cast<unsigned long long *>(cq + 4), d_slabs + slab_at[2], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
+        }
+        if (cnt[1]) {
+            KTIMED(BRX_KERN_FIN_ALIGN2, S.st);
+            hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(grid[1]), dim3(64), 0, S.st, dev, rs, d_lists + list_at[1], cnt[1],
+                               reinterpret_cast<unsigned long long *>(cq + 2), d_slabs + slab_at[1], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
+        }
+        if (cnt[0]) {
+            KTIMED(BRX_KERN_FIN_ALIGN1, S.st);
+            hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(grid[0]), dim3(64), 0, S.st, dev, rs, d_lists + list_at[0], cnt[0],
+                               reinterpret_cast<unsigned long long *>(cq + 0), d_slabs + slab_at[0], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
+        }
         {
-            uint32_t begin = S.b; uint64_t used = 0;
-            for (uint32_t i = S.b; i < S.e; ++i) {
-                uint64_t need = ((h_units[i] + 31) & ~31ull) * 8;      /* 256-byte granules */
-                if (used + need > S.tb_cap) { chunks.push_back({begin, i}); begin = i; used = 0; }
-                h_tboff[i] = used; used += need;
-            }
-            chunks.push_back({begin, S.e});
+            KTIMED(BRX_KERN_FIN_QSCORE, S.st);
+            hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 8, phase, 1, 4,
+                               c->scratch, c->scratch, col_base, clk);
         }
-        if (chunks.size() > BRX_MAX_CHUNKS) return scratch_short(c, c->scratch_bytes + (size_t)std::min<uint64_t>((sum_units + 64ull * ns) * 8 / 8 + 1, (uint64_t)64 << 30));
-        /* tb_off (and, in phase 1, the full-band units) go back through staging arrays in processing order */
-        HIPCHK(c, hipMemcpyAsync(set_tboff + S.b, h_tboff.data() + S.b, (size_t)ns * 8, hipMemcpyHostToDevice, S.st));
-        if (phase == 1) HIPCHK(c, hipMemcpyAsync(set_units + S.b, h_units.data() + S.b, (size_t)ns * 8, hipMemcpyHostToDevice, S.st));
-        hipLaunchKernelGGL(k_set_tboff, dim3((ns + 63) / 64), dim3(64), 0, S.st, ns, rs, order + S.b, set_tboff + S.b,
-                           phase == 1 ? set_units + S.b : (uint64_t *)nullptr);
-        for (size_t ci = 0; ci < chunks.size(); ++ci) {
-            uint32_t b = chunks[ci].first, e = chunks[ci].second;
-            if (e == b) continue;
-            uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
-            uint32_t *cq = counters + 16 + 16 * (((size_t)S.id * 2 + (size_t)phase) * BRX_MAX_CHUNKS + ci);     /* this chunk's queue heads */
-            uint32_t *misses = set_counter(S, 1);
-            /* The widest bands (8+ words per lane: a few dozen reads, each a chain of ~100 k column steps of ~2 us)
-               go first, on the set's wide stream when it has one; then the 4-, 2- and 1-word classes on the set's
-               own stream, each scored (k_fin_qscore) as soon as its class is aligned. */
-            const bool fork = S.wide != S.st;
-            if (fork) {
-                HIPCHK(c, hipEventRecord(c->ev_fork2[S.id], S.st));
-                HIPCHK(c, hipStreamWaitEvent(S.wide, c->ev_fork2[S.id], 0));
-            }
-            if (S.bases_by_class[3] || phase == 1) {
-                KTIMED(BRX_KERN_FIN_ALIGN16, S.wide);
-                hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 4u)), dim3(64), 0, S.wide,
-                                   dev, rs, order, b, e, cq + 0, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
-            }
-            if (fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
-            if (S.bases_by_class[2] || phase == 1) {
-                KTIMED(BRX_KERN_FIN_ALIGN4, S.st);
-                hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st,
-                                   dev, rs, order, b, e, cq + 4, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
-            }
-            if (S.bases_by_class[1] || phase == 1) {
-                KTIMED(BRX_KERN_FIN_ALIGN2, S.st);
-                hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(waves), dim3(64), 0, S.st,
-                                   dev, rs, order, b, e, cq + 1, misses, phase, Fbuf, c->scratch, c->scratch, tb_base, clk);
-            }
-            {
-                KTIMED(BRX_KERN_FIN_ALIGN1, S.st);
-                hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 2, misses, phase,
-                                   Fbuf, c->scratch, c->scratch, tb_base, clk);
-            }
-            {
-                KTIMED(BRX_KERN_FIN_QSCORE, S.st);
-                hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 3, phase, 1, 4,
-                                   c->scratch, c->scratch, tb_base, clk);
-            }
-            if (fork) HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join2[S.id], 0));
-            if (S.bases_by_class[3] || phase == 1) {
-                KTIMED(BRX_KERN_FIN_QSCORE, S.st);
-                hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
-                                   cq + 5, phase, 5, 0xFFFF, c->scratch, c->scratch, tb_base, clk);
-            }
+        if (fork) HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join2[S.id], 0));
+        if (cnt[3]) {
+            KTIMED(BRX_KERN_FIN_QSCORE, S.st);
+            hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
+                               cq + 9, phase, 5, 0xFFFF, c->scratch, c->scratch, col_base, clk);
         }
-        if (phase == 0) c->final_launches += (uint32_t)chunks.size();
+        if (phase == 0) c->final_launches += grid[0] + grid[1] + grid[2] + grid[3];     /* slabs = waves of the set's align kernels */
         return BRX_OK;
     };
 
@@ -667,7 +731,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
     };
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_MUTATE], st));
     /* ---- BRX_MUTATE_WG (default): the whole mutate stage is one launch (brx_mutate_wg.h); the two sets only split the final stage ---- */
-    if (use_wg) {
+    if (use_wg && !use_ps) {
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;
         {
@@ -682,7 +746,7 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         c->mutate_passes = 1;
     }
     /* ---- head chain: mutate to completion ---- */
-    if (n_mh && !use_wg) {
+    if (n_mh && (!use_wg || use_ps)) {
         if (n_mb) {
             HIPCHK(c, hipEventRecord(c->ev_fork, st));
             HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
@@ -690,6 +754,24 @@ static int run_pipeline(brx_ctx *c, uint64_t seed, uint64_t first_read, uint32_t
         launch_run(s_head, n_mh, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, req_legacy_head,
                    mctr + 5 * MC_WORDS, win_head, pack_head);
         if (n_mb) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
+        c->mutate_passes = 1;
+    }
+    /* ---- bulk chain, persistent: ONE launch on the caller's stream (brx_persist.h), beside the head chain ---- */
+    if (use_ps && n_mb) {
+        uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;
+        const size_t ps_bytes = BRX_PQ_NX * sizeof(PQ) + sizeof(PQGlobal) + 2 * (size_t)BRX_PQ_NX * ps_ring * 4;
+        HIPCHK(c, hipMemsetAsync(ps_pq, 0, ps_bytes, st));
+        PsArgs P;
+        P.rs = rs; P.msv = msv; P.order = order + n_mh; P.n_items = n_mb; P.pq = ps_pq; P.pg = reinterpret_cast<PQGlobal *>(ps_pq + BRX_PQ_NX);
+        P.lane_ring = reinterpret_cast<uint32_t *>(P.pg + 1); P.ret_ring = P.lane_ring + (size_t)BRX_PQ_NX * ps_ring; P.ring_mask = ps_ring - 1;
+        P.req_legacy = req_legacy; P.legacy_ctr = legacy_ctr; P.Fbuf = Fbuf; P.repl = repl; P.planes = ps_planes;
+        P.scr_base = win; P.scr_bytes = (uint64_t)c->win_bytes; P.lane_tb = ps_lane_tb; P.flags = counters + 1; P.clk = clk;
+        P.long_cycles = c->ps_long; P.low_water = c->ps_low; P.patience = c->ps_patience; P.exit_idle = std::max(c->ps_exit_idle, c->ps_patience + 2u);   /* a wave must reach its patience (and take what is parked) before it may leave */
+        {
+            KTIMED(BRX_KERN_MUTATE_SEG, st);
+            hipLaunchKernelGGL(k_mutate_persist, dim3(ps_blocks), dim3(64 * BRX_PS_WAVES), 0, st, dev, P);
+        }
+        HIPCHK(c, hipMemcpyAsync(c->ps_stats, P.pg, sizeof(c->ps_stats), hipMemcpyDeviceToHost, st));   /* waited for with the legacy counters below */
         c->mutate_passes = 1;
     }
     /* ---- bulk chain: passes ---- */

@@ -718,6 +718,7 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
 #include "brx_pack.h"
 #include "brx_mutate.h"
 #include "brx_mutate_wg.h"
+#include "brx_persist.h"
 #include "brx_model.h"
 #include "brx_gzip_dev.h"
 
@@ -814,29 +815,31 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
     }
 }
 
+/* One band class of one set: `list` holds the class's reads (longest first), `ctr` is the 64-bit counter of the slab scheme
+   (brx_hip.hip, launch_final_phase): low half = list position, high half = waves that have started.  A wave's first pop adds
+   to both halves at once -- its ticket t is then at most the position it popped -- and slab t (slabs[t] .. slabs[t + 1], in
+   8-byte units from slab_base) holds the traceback store of every read the wave will ever pop. */
 template <int MAXG, int GLO, int GHI>
-__global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
-                                                   uint32_t *queue, uint32_t *retries, int phase, const uint8_t *Fbuf,
-                                                   uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *tb_base, uint64_t *clk) {
+__global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *list, uint32_t n_list,
+                                                   unsigned long long *ctr, const uint64_t *slabs, uint32_t *retries, int phase, const uint8_t *Fbuf,
+                                                   uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *slab_base, uint64_t *clk) {
     const int lane = lane_id();
-    for (;;) {
-        const uint32_t qi = q_begin + wave_pop(queue);
-        if (qi >= q_end) break;
-        const uint32_t r = order[qi];
+    const uint64_t first = uni((uint64_t)atomicAdd(ctr, lane == 0 ? ((1ull << 32) | 1ull) : 0ull));
+    uint32_t qi = (uint32_t)first;
+    if (qi >= n_list) return;
+    const uint32_t ticket = (uint32_t)(first >> 32);
+    const uint64_t slab_at = slabs[ticket], tb_cap = slabs[ticket + 1] - slab_at;
+    uint2 *tb = reinterpret_cast<uint2 *>(slab_base) + slab_at;
+    for (; qi < n_list; qi = (uint32_t)uni((uint64_t)atomicAdd(ctr, lane == 0 ? 1ull : 0ull))) {
+        const uint32_t r = list[qi];
         const RS s = rs[r];
-        if (s.n == 0) continue;
         const int klass = (int)(s.klass & 0xFFFFu);
-        if (klass < GLO || klass > GHI) continue;                          /* another band class */
-        if (((s.klass & BRX_KL_RETRY) != 0u) != (phase != 0)) continue;     /* phase 1 repeats the window misses only */
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
         uint64_t aclk[2] = {0, 0};
         const uint32_t n = s.n, m = s.m;
         const uint8_t *F = Fbuf + s.F_off;
         uint8_t *seq = seqbuf + s.seq_off;                                 /* joined and padded by k_fin_join */
         uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
-        const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
-        uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
-        const uint64_t tb_cap = s.units - col_units;
         int ncols = 0, nmatch = 0; bool nospace = false;
         const bool ok = brx_wave_align<MAXG, (GLO < MAXG ? GLO : MAXG)>(seq, (int)m, F, (int)n, (int)s.ub, tb, tb_cap, ops_end, &ncols, &nmatch,
                                              &nospace, nullptr, aclk, (phase == 0 && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0);
@@ -893,9 +896,7 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
         uint8_t *seq = seqbuf + s.seq_off;
         uint8_t *qual = seq + (((uint64_t)m + 16 + 15) & ~15ull);
         const uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
-        uint2 *tb = reinterpret_cast<uint2 *>(tb_base + s.tb_off);
-        const uint64_t col_units = ((uint64_t)m * 4 + 7) / 8 + 2;
-        uint32_t *col_of = reinterpret_cast<uint32_t *>(tb + (s.units - col_units));
+        uint32_t *col_of = reinterpret_cast<uint32_t *>(tb_base + s.tb_off);       /* the set's col_of[] region, RS.tb_off = this read's share */
         const bool ok = !(s.status & BRX_RS_BAND);
         const uint32_t ncols = s.n_cols;
         const uint8_t *ops = ops_end - ncols;

@@ -147,8 +147,10 @@ __global__ void __launch_bounds__(256) k_mb_qscore(BrxMbJob j) {
     }
     if (nread < ks) return;
     if (odd || shift > 52 || q > 127u) {
+        /* the host counts this window: the word names it completely (alignment, size index, start column), so the host never
+           has to restate these rules */
         const uint32_t at = atomicAdd(&j.flags[2], 1u);
-        if (at < j.spill_cap) j.spill[at] = ((uint64_t)a << 32) | (uint64_t)(s - c0);
+        if (at < j.spill_cap) j.spill[at] = ((uint64_t)a << 36) | ((uint64_t)ki << 32) | (uint64_t)(s - c0);
         return;
     }
     const uint64_t key = (uint64_t)q | ((uint64_t)ki << 7) | (ops << 11);

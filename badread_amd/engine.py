@@ -283,6 +283,8 @@ def bind_library(lib):
     lib.brx_model_count.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(BrxModelJob), ctypes.c_void_p]
     lib.brx_last_mutate_passes.restype = ctypes.c_uint32
     lib.brx_last_mutate_passes.argtypes = [ctypes.c_void_p]
+    lib.brx_last_mutate_stats.restype = ctypes.c_int
+    lib.brx_last_mutate_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32 * 8)]
     lib.brx_last_final_launches.restype = ctypes.c_uint32
     lib.brx_last_final_launches.argtypes = [ctypes.c_void_p]
     lib.brx_last_window_misses.restype = ctypes.c_uint32
@@ -601,6 +603,12 @@ class HipEngine(EngineBase):
     def mutate_passes(self):
         return int(self.lib.brx_last_mutate_passes(self.ctx))
 
+    def mutate_stats(self):
+        """Scheduling counters of the persistent mutate stage of the last batch (include/brx.h: brx_last_mutate_stats)."""
+        arr = (ctypes.c_uint32 * 8)()
+        self._check(self.lib.brx_last_mutate_stats(self.ctx, ctypes.byref(arr)))
+        return dict(zip(('finished', 'lane_batches', 'lane_windows', 'inplace_windows', 'steals'), [int(v) for v in arr[:5]]))
+
     def final_launches(self):
         return int(self.lib.brx_last_final_launches(self.ctx))
 
@@ -616,7 +624,8 @@ def default_engine():
     """Process-wide HipEngine on LOCAL_RANK (or device 0)."""
     global _default_engine
     if _default_engine is None:
-        _default_engine = HipEngine(int(os.environ.get('LOCAL_RANK', '0')))
+        # BRX_DEVICE: several ranks on one GPU (tests on a 1-GPU box; see simulate.Shard.from_env)
+        _default_engine = HipEngine(int(os.environ.get('BRX_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
     return _default_engine
 
 

@@ -100,24 +100,27 @@ RANDOM_SEQ_DICT = {0: 'A', 1: 'C', 2: 'G', 3: 'T'}
 
 
 def load_fastq(filename, output=sys.stderr, dot_interval=1000):
-    """{name: (sequence upper-cased, qualities)} like the reference's loader (misc.py:97-119): header lines are the
-    lines that start with '@', the three lines after a header are taken unseen."""
+    """{read name: (bases upper-cased, qualities)} with the record rule of the reference's loader (misc.py:97-119): a line
+    whose first non-blank byte is '@' opens a record and the three lines behind it belong to it whatever they hold (a
+    quality string may itself start with '@').  The file is read in one piece and walked by line index."""
     if get_sequence_file_type(filename) != 'FASTQ':
         sys.exit('Error: {} is not FASTQ format'.format(filename))
-    reads = {}
     print('Loading reads', end='', file=output, flush=True)
-    with get_open_func(filename)(filename, 'rb') as fastq:
-        for line in fastq:
-            stripped = line.strip()
-            if not stripped.startswith(b'@'):
-                continue
-            name = stripped[1:].split()[0]
-            sequence = next(fastq).strip().upper()
-            next(fastq)
-            qualities = next(fastq).strip()
-            reads[name.decode()] = (sequence.decode(), qualities.decode())
-            if len(reads) % dot_interval == 0:
-                print('.', end='', file=output, flush=True)
+    with get_open_func(filename)(filename, 'rb') as handle:
+        lines = handle.read().split(b'\n')
+    reads, at = {}, 0
+    while at < len(lines):
+        head = lines[at].strip()
+        at += 1
+        if head[:1] != b'@':
+            continue
+        if at + 2 >= len(lines):
+            raise EOFError('{}: the last record is cut short'.format(filename))
+        name = head[1:].split()[0].decode()
+        reads[name] = (lines[at].strip().upper().decode(), lines[at + 2].strip().decode())
+        at += 3
+        if len(reads) % dot_interval == 0:
+            print('.', end='', file=output, flush=True)
     print('', file=output, flush=True)
     return reads
 

@@ -196,17 +196,16 @@ def make_qscore_model(args, output=sys.stderr, dot_interval=1000, engine=None, s
         entry = per_cigar.setdefault(''.join(cigar), [rank, collections.Counter()])
         entry[0] = min(entry[0], rank)
         entry[1][q] += n
-    for word in sorted(set(spill.tolist())):         # windows a key cannot hold: counted here, for every window size
-        a, start = word >> 32, word & 0xFFFFFFFF
+    for word in sorted(set(spill.tolist())):         # windows a key cannot hold (k_mb_qscore names each: alignment, size index, start)
+        a, ki, start = word >> 36, (word >> 32) & 15, word & 0xFFFFFFFF
         read_g, qual_g, ref_g = job.gapped(a, ' ')
-        for ki in range(n_ksizes):
-            hit = _qscore_window(read_g, qual_g, ref_g, start, 2 * ki + 1, args.max_del)
-            if hit is None or not _qscore_spilled(hit[0], start, read_g):
-                continue
-            rank = (a << 40) | (ki << 36) | start
-            entry = per_cigar.setdefault(hit[0], [rank, collections.Counter()])
-            entry[0] = min(entry[0], rank)
-            entry[1][hit[1]] += 1
+        hit = _qscore_window(read_g, qual_g, ref_g, start, 2 * ki + 1, args.max_del)
+        if hit is None:
+            continue
+        rank = (a << 40) | (ki << 36) | start
+        entry = per_cigar.setdefault(hit[0], [rank, collections.Counter()])
+        entry[0] = min(entry[0], rank)
+        entry[1][hit[1]] += 1
     overall = collections.Counter()
     for cigar, (_, qs) in per_cigar.items():
         if len(cigar.replace('D', '')) == 1:         # every window of one read base (qscore_model.py:141-142)
@@ -233,12 +232,6 @@ def _qscore_window(read_g, qual_g, ref_g, start, k_size, max_del):
     cigar = re.sub('D{' + str(max_del) + ',}', 'D' * max_del, cigar)
     qual = qual_g[start:end].replace(' ', '')
     return cigar, ord(qual[(k_size - 1) // 2]) - 33
-
-
-def _qscore_spilled(cigar, start, read_g):
-    """Did the device leave this window to the host?  (the rules of k_mb_qscore)"""
-    bits = 2 * len(cigar.replace('D', '')) + 4 * (len(cigar.replace('D', '')) - 1)
-    return cigar.startswith('D') or bits > 52
 
 
 def print_qscore_fractions(cigar, qscores, min_occur, stdout):

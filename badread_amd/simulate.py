@@ -214,9 +214,12 @@ class Shard(object):
         import torch.distributed as dist
         if not dist.is_initialized():
             import torch
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-            if backend == 'nccl':
-                torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+            # BRX_DIST_BACKEND=gloo keeps the exchange on the host (CPU tensors) whatever the engine computes on: several ranks
+            # can then share ONE GPU (BRX_DEVICE picks it), which is how the tests run the HIP engine under world > 1 on a 1-GPU box
+            backend = os.environ.get('BRX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            if torch.cuda.is_available():
+                n_dev = max(torch.cuda.device_count(), 1)
+                torch.cuda.set_device(int(os.environ.get('BRX_DEVICE', int(os.environ.get('LOCAL_RANK', '0')) % n_dev)))
             dist.init_process_group(backend=backend)
         return cls(dist.get_rank(), dist.get_world_size(), dist)
 
@@ -260,7 +263,10 @@ class Shard(object):
                     self.dist.recv(buf, src=r)
                     yield r, buf
         elif sizes[self.rank]:
-            self.dist.send(mine[:sizes[self.rank]].contiguous(), dst=0)
+            part = mine[:sizes[self.rank]].contiguous()
+            if self.dist.get_backend() != 'nccl' and part.device.type != 'cpu':
+                part = part.cpu()                # host exchange (gloo) of an engine that computes on the GPU
+            self.dist.send(part, dst=0)
 
 
 FLAG_NOFRAG, FLAG_BAD = 1 << 31, 1 << 30          # status bits packed beside the read length in the 4 B/read gather
@@ -317,12 +323,15 @@ class _HostRing(object):
                     t0 = time.perf_counter()
                     self.sink(memoryview(buf.numpy())[:n])
                     self.sink_seconds += time.perf_counter() - t0
-            except BaseException as ex:             # surfaced by flush()
+            except BaseException as ex:             # surfaced by the next stage() / write() of the producer, or by flush()
                 self.error = ex
             self.free.put(buf)
 
     def stage(self, nbytes):
-        """A host buffer of at least nbytes (blocks while all buffers are with the writer)."""
+        """A host buffer of at least nbytes (blocks while all buffers are with the writer).  A sink that has failed
+        (BrokenPipe behind `| head`, a full disk) stops the run here, at the next batch, not after the whole target."""
+        if self.error is not None:
+            raise self.error
         buf = self.free.get()
         if buf is None or buf.numel() < nbytes:
             cap = max(int(nbytes * 1.25), 1 << 20)
@@ -339,10 +348,10 @@ class _HostRing(object):
             buf[:n].copy_(tensor, non_blocking=False)
         self.todo.put((buf, n))
 
-    def flush(self):
+    def flush(self, reraise=True):
         self.todo.put(None)
         self.thread.join()
-        if self.error is not None:
+        if reraise and self.error is not None:
             raise self.error
 
 
@@ -524,6 +533,11 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             t0 = time.perf_counter()
             if pool.on_gpu and my_bytes and not packed:
                 out = out[:my_bytes].clone()
+                # the copy runs on THIS thread's stream, the engine's next batch (which overwrites the buffer) on its own:
+                # the engine is released only when the copy is done (~1 ms for 0.5 GB)
+                torch_mod = getattr(pool.engines[slot], 'torch', None)
+                if torch_mod is not None:
+                    torch_mod.cuda.current_stream().synchronize()
             timing['clone'] += time.perf_counter() - t0
             pool.release(slot)                      # the engine's output buffer may be overwritten from here on
             used = lens[:last + 1]
@@ -555,7 +569,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         timing['close_engines'] = time.perf_counter() - t0
         t0 = time.perf_counter()
         if ring is not None:
-            ring.flush()
+            ring.flush(reraise=sys.exc_info()[0] is None)     # a sink error must not mask the exception that is already propagating
             timing['sink'] = ring.sink_seconds
             timing['ring_alloc'] = ring.alloc_seconds
         timing['flush'] = time.perf_counter() - t0

@@ -346,7 +346,7 @@ def main():
         """The device batches of steps `step_indices`, C in flight: worker i owns context i / stream i and takes
         every C-th device batch; batch b of step k covers read indices ((k*C + b)*world + rank)*R ..."""
         indices = [k * C + b for k in step_indices for b in range(C)]
-        acc = [{'bases': 0, 'passes': 0, 'stages': {}, 'kernels': {}, 'final_launches': 0, 'misses': 0, 'bad': 0, 'host_ms': 0.0, 'error': None} for _ in range(C)]
+        acc = [{'bases': 0, 'passes': 0, 'stages': {}, 'kernels': {}, 'final_launches': 0, 'misses': 0, 'bad': 0, 'host_ms': 0.0, 'error': None, 'mutate': {}} for _ in range(C)]
 
         def worker(i):
             try:
@@ -370,6 +370,8 @@ def main():
                             k[0] += n_l; k[1] += ms; k[2] += b
                         acc[i]['final_launches'] += engines[i].final_launches()
                         acc[i]['misses'] += engines[i].window_misses()
+                        for name, v in engines[i].mutate_stats().items():
+                            acc[i]['mutate'][name] = acc[i]['mutate'].get(name, 0) + v
                     if not dry:
                         streams[i].synchronize()
             except BaseException as ex:          # surfaced on the main thread
@@ -468,6 +470,7 @@ def main():
                    'parallelism': f'reads sharded by index over {world} GPU(s), reference replicated per GPU, no collectives on the data path'},
         'reference_load': ref_timing,
         'reads_flagged_band_segs_qmiss': bad,
+        'mutate_stage_per_device_batch': {k: sum(a['mutate'].get(k, 0) for a in acc) / n_batches for k in ('finished', 'lane_batches', 'lane_windows', 'inplace_windows', 'steals')},
     }
     if dry:
         result['INVALID'] = 'dry run on the CPU checker engine (--cpu-engine): exercises launch / sharding / reporting only'

@@ -250,6 +250,11 @@ int brx_last_read_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
  * Zeros without BRX_PROFILE (the default kernels do not contain the clock reads). */
 int brx_last_phase_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
 uint32_t brx_last_mutate_passes(const brx_ctx *ctx);
+/* Counters of the persistent mutate stage (k_mutate_persist) of the last call:
+ *   [0] reads that left the stage  [1] lane batches (waves that aligned parked windows, one window per lane)
+ *   [2] windows aligned that way   [3] windows aligned in place by a whole wave  [4] work items taken from the queue set
+ *   of another XCD  [5..7] reserved.  Scheduling only: results never depend on these. */
+int brx_last_mutate_stats(const brx_ctx *ctx, uint32_t out[8]);
 /* Per-kernel launch timing, opt-in (brx_set_kernel_timing(ctx, 1); bench.py and the profiling tools use it): every
  * launch of the kernels below is bracketed by two HIP events ON THE STREAM THE KERNEL IS LAUNCHED ON, and
  * brx_last_kernel_stats() returns, for the last brx_simulate_batch / brx_sequence_fragments call, the number of
@@ -277,6 +282,8 @@ typedef struct {
 } brx_kernel_stat;
 int brx_set_kernel_timing(brx_ctx *ctx, int on);
 int brx_last_kernel_stats(const brx_ctx *ctx, brx_kernel_stat out[BRX_KERN_COUNT]);
+/* Traceback slabs (= persistent waves of the final align kernels, summed over band classes and the two sets) of the last
+ * call: one per read of a class up to the class's wave limit; fewer when the scratch arena could not hold that many. */
 uint32_t brx_last_final_launches(const brx_ctx *ctx);
 /* Reads of the last call whose final traceback asked for a cell outside the windowed traceback store and were
  * aligned a second time with the full store (environment BRX_TB_WINDOW: window height in
@@ -299,7 +306,8 @@ uint32_t brx_last_window_misses(const brx_ctx *ctx);
  *   first[slot] = the earliest (alignment, [size index,] window start) that produced the key: Python dictionaries and its
  *   stable sort order equal counts by first insertion.
  * Windows a key cannot hold (error model: a read k-mer of more than 21 bases; qscore model: more than 52 key bits, a
- * window opening with deletion columns) are appended to `spill` as (alignment << 32 | start column) for the host to count.
+ * window opening with deletion columns) are appended to `spill` for the host to count: kind 0 as (alignment << 32 | start column), kind 1 as
+ * (alignment << 36 | window size index << 32 | start column).
  * Returns BRX_E_OUTPUT when the table is full.                                                                        */
 typedef struct {
     uint32_t n_align, k, max_del, n_ksizes;

@@ -72,19 +72,20 @@ def test_aligner_band_classes_iupac_and_hints():
 
 
 ROUTES = [
-    {},                                                        # defaults: pass pipeline (all head here: few reads), windowed store
+    # the persistent mutate stage (brx_persist.h; the default): 40 reads are below the low-water mark, every identity check runs in place
+    {},
     {'BRX_TB_WINDOW': -1},                                     # 8-row traceback window: most reads repeat (phase 1)
     {'BRX_TB_WINDOW': 0, 'BRX_WIDE_STREAM': 0},                # full store, no third stream for the widest class
-    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0},         # bulk passes only: every window through the lane kernel
-    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 1000000},   # bulk passes only: eight windows per wave (k_win_pack), the rest through the wave kernel
-    {'BRX_TAIL_READS': 6, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_FIN_HEAD_READS': 9},   # passes with packed windows, a 6-read in-place tail, final stage in two sets
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},         # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
-    {'BRX_RUN_WG': 0},                                                           # run-to-completion launches as k_mutate_seg<true> (every read aligns its own windows)
-    {'BRX_RUN_WG': 0, 'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},
-    # the one-launch mutate stage (BRX_MUTATE_WG=1: workgroups of 8 reads, packed window alignments)
-    {'BRX_MUTATE_WG': 1},
-    {'BRX_MUTATE_WG': 1, 'BRX_HEAD_READS': 9, 'BRX_TB_WINDOW': -1},              # final stage split into a head and a bulk set, retry phase
+    # every window the lane aligner can take goes through the queues: parked as planes, aligned one per lane, handed back
+    {'BRX_PS_LOW': 0, 'BRX_PS_LONG': 100000},
+    {'BRX_PS_LOW': 0, 'BRX_PS_LONG': 100000, 'BRX_PS_PATIENCE': 0, 'BRX_PS_WG_PER_CU': 1, 'BRX_FIN_HEAD_READS': 9},   # partial lane batches at once, two workgroups, final stage in two sets
+    {'BRX_PS_LOW': 0, 'BRX_PS_LONG': 1, 'BRX_TB_WINDOW': -1},  # reads with more than one check ahead align in place, the last check of each is parked
+    {'BRX_PS_LOW': 0, 'BRX_PS_LONG': 100000, 'BRX_PS_EXIT_IDLE': 1, 'BRX_PS_PATIENCE': 0},   # waves leave the launch at the first idle scan: whoever holds work finishes it
+    # round 2's pass pipeline (BRX_MUTATE_PERSIST=0)
+    {'BRX_MUTATE_PERSIST': 0},
+    {'BRX_MUTATE_PERSIST': 0, 'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0},         # bulk passes only: every window through the lane kernel
+    {'BRX_MUTATE_PERSIST': 0, 'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 1000000},   # bulk passes only: eight windows per wave (k_win_pack), the rest through the wave kernel
+    {'BRX_MUTATE_PERSIST': 0, 'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},         # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
 ]
 
 
@@ -104,32 +105,26 @@ def test_pipeline_routes_equal_the_oracle(env, monkeypatch):
         assert eng.window_misses() >= 3                     # the retry phase ran (short reads: few windows are narrower than the band)
     if env.get('BRX_TAIL_READS') == 0:
         assert eng.mutate_passes() > 3
-    if env.get('BRX_MUTATE_WG') == 1:
-        assert eng.mutate_passes() == 1
+    if 'BRX_MUTATE_PERSIST' not in env:
+        ms = eng.mutate_stats()
+        assert eng.mutate_passes() == 1 and ms['finished'] == n
+        if env.get('BRX_PS_LONG') == 100000:
+            assert ms['lane_windows'] > 50 and ms['lane_windows'] > 4 * ms['inplace_windows'], ms     # what stays in place: windows with N / IUPAC symbols
+        elif env.get('BRX_PS_LONG') == 1:
+            assert ms['lane_windows'] >= 10 and ms['inplace_windows'] >= 10, ms
+        else:
+            assert ms['lane_windows'] == 0, ms
 
 
-def test_lds_threshold_build_variant(monkeypatch):
-    """The pass kernels built as 8-wave workgroups with the error model's self thresholds staged in LDS (the build variant
-    measured in round 2, csrc/brx_mutate.h): same bytes, bulk passes and in-place tail."""
-    import emu_engine as EE
-    pref, _ = H.small_reference()
-    p = SimParams(frag_mean=1100, frag_stdev=900)
-    for k, v in {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0}.items():
-        monkeypatch.setenv(k, str(v))
-    eng = H.configure(EE.EmuEngine(1 << 29, defines=('-DBRX_SEG_WAVES=8', '-DBRX_SEG_THR_ROWS=16384')), pref, 'nanopore2023', 'nanopore2023', p)
-    orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
-    out_h, st_h = eng.simulate_batch(42, 0, 40)
-    out_o, st_o = orc.simulate_batch(42, 0, 40)
-    for f in STAT_FIELDS:
-        assert (st_h[f] == st_o[f]).all(), f
-    assert H.first_diff(out_h, out_o) < 0
+MUTATE_ROUTES = {'persist': {}, 'lanes': {'BRX_PS_LOW': 0, 'BRX_PS_LONG': 100000, 'BRX_PS_PATIENCE': 2}, 'passes': {'BRX_MUTATE_PERSIST': 0}}
 
 
-@pytest.mark.parametrize('wg', [0, 1])
-def test_pipeline_other_models_and_fragment_kinds(wg, monkeypatch):
+@pytest.mark.parametrize('route', sorted(MUTATE_ROUTES))
+def test_pipeline_other_models_and_fragment_kinds(route, monkeypatch):
     """random / ideal models (k = 1), low identity, chimeras, junk and random reads, glitches, N runs and hairpins;
-    through the pass pipeline and through the one-launch mutate kernel."""
-    monkeypatch.setenv('BRX_MUTATE_WG', str(wg))
+    through the persistent mutate stage (identity checks in place / through the lane queue) and through the pass pipeline."""
+    for k, v in MUTATE_ROUTES[route].items():
+        monkeypatch.setenv(k, str(v))
     pref, _ = H.small_reference(with_n=True)
     p = SimParams(frag_mean=700, frag_stdev=0, identity_mode=0, id_max=0.88, glitch_rate=400, glitch_size=10, glitch_skip=10,
                   chimera_rate=0.2, junk_rate=0.1, random_rate=0.1)
@@ -184,9 +179,10 @@ def test_driver_on_the_emulated_device_equals_the_oracle_driver(monkeypatch):
     assert a.getvalue() == b.getvalue() and a.getvalue().count(b'\n') >= 4 * 20
 
 
-@pytest.mark.parametrize('wg', [0, 1])
-def test_window_overflow_goes_through_the_whole_read_kernel(tmp_path, wg, monkeypatch):
-    monkeypatch.setenv('BRX_MUTATE_WG', str(wg))
+@pytest.mark.parametrize('route', sorted(MUTATE_ROUTES))
+def test_window_overflow_goes_through_the_whole_read_kernel(tmp_path, route, monkeypatch):
+    for k, v in MUTATE_ROUTES[route].items():
+        monkeypatch.setenv(k, str(v))
     _window_overflow(tmp_path)
 
 
@@ -223,19 +219,23 @@ def _window_overflow(tmp_path):
     return eng
 
 
-def test_final_stage_in_several_scratch_chunks(monkeypatch):
-    """A scratch arena that holds the largest traceback store but not all of them: the final stage runs in several
-    chunks over the same arena; same bytes."""
+def test_final_stage_with_fewer_slabs_than_reads(monkeypatch):
+    """The traceback stores of the final stage are slabs owned by the waves of the align kernels, sized by queue position
+    (brx_hip.hip, launch_final_phase).  An arena that holds the largest store but not one slab per read: the set runs with
+    fewer waves, every wave reusing its slab for several reads; same bytes."""
     pref, _ = H.small_reference()
     p = SimParams(frag_mean=5000, frag_stdev=2000)
-    eng = H.configure(emu_engine(monkeypatch, scratch=24 << 20, BRX_TB_WINDOW=0, BRX_WIN_KB=128), pref, 'nanopore2023', 'nanopore2023', p)
     orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
-    out_h, st_h = eng.simulate_batch(8, 0, 28)
     out_o, st_o = orc.simulate_batch(8, 0, 28)
-    assert eng.final_launches() >= 2, eng.final_launches()
-    for f in STAT_FIELDS:
-        assert (st_h[f] == st_o[f]).all(), f
-    assert H.first_diff(out_h, out_o) < 0
+    slabs = []
+    for scratch in (1 << 29, 24 << 20):
+        eng = H.configure(emu_engine(monkeypatch, scratch=scratch, BRX_TB_WINDOW=0, BRX_WIN_KB=128, BRX_PS_WG_PER_CU=1), pref, 'nanopore2023', 'nanopore2023', p)
+        out_h, st_h = eng.simulate_batch(8, 0, 28)
+        slabs.append(eng.final_launches())
+        for f in STAT_FIELDS:
+            assert (st_h[f] == st_o[f]).all(), f
+        assert H.first_diff(out_h, out_o) < 0
+    assert slabs[0] == 28 and slabs[1] < 20, slabs
 
 
 def test_long_segment_lists_continue_in_the_overflow_lists():
