@@ -186,15 +186,6 @@ __device__ __forceinline__ int brx_from_lane_above(int v) {
  * visible to the compiler (ds_read_u8 / ds_write_b32); a generic or volatile pointer to it turns
  * every access into a flat load that waits on vmcnt -- exactly what the window is there to avoid. */
 __shared__ uint32_t brx_ring32[BRX_RING_BYTES / 4];
-/* Kernels whose workgroups hold several independent waves (k_mutate_seg: 8 waves sharing the LDS copy of the error
- * model's thresholds) give every wave its own window (template parameter MW of the forward passes); a kernel only pays
- * for the variant it references. */
-#define BRX_RING_WAVES 4
-__shared__ uint32_t brx_ring32_mw[BRX_RING_WAVES][BRX_RING_BYTES / 4];
-template <bool MW> __device__ __forceinline__ uint32_t *brx_ring() {
-    if constexpr (MW) return brx_ring32_mw[threadIdx.x >> 6]; else return brx_ring32;
-}
-
 /* ---------------------------------------------------------------------------------------------
  * forward pass: fills tb[(t*WSp + s%WSp)*G + g] = {Pv after column j, Ph before its shift}
  * Qs and Ts must be readable up to 16 bytes past their ends (buffers are padded by the caller) and
@@ -249,11 +240,11 @@ __device__ __forceinline__ uint32_t brx_eq_acgt(const BrxQPlanes &p, uint32_t k0
     return ~(p.lo ^ k0) & ~(p.hi ^ k1) & p.acgt;
 }
 
-template <int G, bool MW = false>
+template <int G>
 __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                   const BrxGeom g, uint2 *__restrict__ tb, uint32_t *prog = nullptr) {
     const int lane = threadIdx.x & 63;
-    uint32_t *const ring32 = brx_ring<MW>();
+    uint32_t *const ring32 = brx_ring32;
     constexpr int NEVER = 0x7FFFFFFF;
     /* A lane works on superblock s during time steps [tf, tl] (column j = t - s), then hops to s + 64.
      * The band is narrower than 62 superblocks (brx_make_geom), so whenever the lane above was active
@@ -560,11 +551,10 @@ __device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32
  * one-column trip) is paid once per four columns.  Traceback row of column j of superblock s is
  * j + 4s = 4 tau + c + 1: the same for every lane of a trip, so the stores stay slot-contiguous.
  * ------------------------------------------------------------------------------------------- */
-template <bool MW = false>
 __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                             const BrxGeom g, uint2 *__restrict__ tb) {
     const int lane = threadIdx.x & 63;
-    uint32_t *const ring32 = brx_ring<MW>();
+    uint32_t *const ring32 = brx_ring32;
     /* the store base is the same in every lane: say so (and that it is global memory), and the traceback stores take the
        scalar-base form -- row address in SGPRs + a 32-bit lane offset -- instead of a 64-bit vector add per column */
     const uint64_t tb_addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)tb >> 32)) << 32) |
@@ -756,7 +746,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
  * Register use grows with it (7 VGPRs per word), so kernels that only ever meet narrow bands are
  * instantiated with a small MAXG and run at a higher occupancy; geometries above MAXG take the
  * slow memory-resident path below (correct, rare). */
-template <int MAXG, int MING = 1, bool MW = false>
+template <int MAXG, int MING = 1>
 __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *Ts, const BrxGeom &g, uint2 *tb,
                                              uint32_t *prog = nullptr) {
     if (g.G > MAXG || g.G < MING) {
@@ -768,16 +758,16 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
         brx_align_forward_wide(Qs, Ts, g, tb, peq, st);
         return;
     }
-    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_k4<MW>(Qs, Ts, g, tb); return; } }
-    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2, MW>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4, MW>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8, MW>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 16 && MING <= 16) { if (g.G == 16) { brx_align_forward<16, MW>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_k4(Qs, Ts, g, tb); return; } }
+    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, prog); return; } }
+    if constexpr (MAXG >= 16 && MING <= 16) { if (g.G == 16) { brx_align_forward<16>(Qs, Ts, g, tb, prog); return; } }
 }
 
 /* Full alignment with a given band bound k.  Returns false if the band was too narrow.
  * Handles empty inputs.  All lanes of the wave must call; results are wave-uniform. */
-template <int MAXG = 16, int MING = 1, bool MW = false>
+template <int MAXG = 16, int MING = 1>
 __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *Ts, int T, int k,
                                       uint2 *tb, uint64_t tb_cap_units, uint8_t *ops_end,
                                       int *n_cols, int *n_match, bool *no_space, uint32_t *prog = nullptr,
@@ -797,7 +787,7 @@ __device__ inline bool brx_wave_align(const uint8_t *Qs, int Q, const uint8_t *T
     BRX_PROG(prog, 3, 1);
     BRX_PROG(prog, 6, (uint32_t)g.t_end);
     const uint64_t c0 = __builtin_amdgcn_s_memtime();
-    brx_align_forward_any<MAXG, MING, MW>(Qs, Ts, g, tb, prog);
+    brx_align_forward_any<MAXG, MING>(Qs, Ts, g, tb, prog);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);      /* stores of this wave visible to its own later loads */
     BRX_PROG(prog, 3, 2);

@@ -45,11 +45,6 @@ struct brx_ctx {
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
-    int run_wg;                  /* BRX_RUN_WG=1: head chain and tail run as k_mutate_wg (packed identity checks) instead of k_mutate_seg<true> (default 0: measured slower) */
-    int persist;                 /* BRX_MUTATE_PERSIST (default 1): the mutate stage is ONE persistent launch with device queues (brx_persist.h); 0 = round 2's pass pipeline */
-    uint32_t ps_wg_per_cu, ps_long, ps_low, ps_patience, ps_exit_idle;   /* BRX_PS_WG_PER_CU, BRX_PS_LONG, BRX_PS_LOW, BRX_PS_PATIENCE (PsArgs) */
-    uint32_t ps_stats[8];        /* PQGlobal of the last batch */
-    int mutate_wg;               /* BRX_MUTATE_WG=1: the mutate stage is one launch of k_mutate_wg (brx_mutate_wg.h; measured slower at batch scale); default 0 = the pass pipeline */
     uint32_t fin_head_reads;     /* BRX_FIN_HEAD_READS: the longest reads of a batch form the head set of the final stage (side streams) */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
     int wide_stream;             /* BRX_WIDE_STREAM: the head set's widest band class aligns on a third stream */
@@ -161,14 +156,6 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         if ((e = hipEventCreateWithFlags(&c->ev_fork2[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
-    { const char *rw = getenv("BRX_RUN_WG"); c->run_wg = rw ? atoi(rw) : 0; }
-    { const char *mw = getenv("BRX_MUTATE_WG"); c->mutate_wg = mw ? atoi(mw) : 0; }
-    { const char *v = getenv("BRX_MUTATE_PERSIST"); c->persist = v ? atoi(v) : 1; }
-    { const char *v = getenv("BRX_PS_WG_PER_CU"); c->ps_wg_per_cu = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 2u; }
-    { const char *v = getenv("BRX_PS_LONG"); c->ps_long = v ? (uint32_t)atoi(v) : 1000000u; }
-    { const char *v = getenv("BRX_PS_LOW"); c->ps_low = v ? (uint32_t)atoi(v) : 512u; }
-    { const char *v = getenv("BRX_PS_PATIENCE"); c->ps_patience = v ? (uint32_t)atoi(v) : 8u; }
-    { const char *v = getenv("BRX_PS_EXIT_IDLE"); c->ps_exit_idle = v ? (uint32_t)atoi(v) : 64u; }
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
@@ -289,11 +276,6 @@ struct KTimer {
 #define KTIMED(kind, stream) KTimer ktimer_##__LINE__(c, (kind), (stream))
 
 extern "C" uint32_t brx_last_mutate_passes(const brx_ctx *c) { return c ? c->mutate_passes : 0; }
-extern "C" int brx_last_mutate_stats(const brx_ctx *c, uint32_t out[8]) {
-    if (!c || !out) return BRX_E_ARG;
-    for (int i = 0; i < 8; ++i) out[i] = c->ps_stats[i];
-    return BRX_OK;
-}
 extern "C" uint32_t brx_last_final_launches(const brx_ctx *c) { return c ? c->final_launches : 0; }
 extern "C" uint32_t brx_last_window_misses(const brx_ctx *c) { return c ? c->window_misses : 0; }
 
@@ -386,13 +368,9 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     PPiece *pieces = (PPiece *)A.take((size_t)(tot_pieces + 1) * sizeof(PPiece));
     uint8_t *Fbuf = (uint8_t *)A.take((size_t)f_bytes + 64);
     uint32_t *repl = (uint32_t *)A.take(((size_t)f_bytes + 64) * 4);
-    const bool use_ps = c->persist && !c->mutate_inline && !c->mutate_wg;
-    /* the persistent mutate stage (brx_persist.h): workgroups of BRX_PS_WAVES waves; per wave the window bytes + traceback store
-       of the in-place aligner (win_bytes), per workgroup one move-code store of the lane aligner */
-    const uint32_t ps_blocks = std::max<uint32_t>(1u, std::min<uint32_t>((n_reads + BRX_PS_WAVES - 1) / BRX_PS_WAVES, (uint32_t)c->n_cu * c->ps_wg_per_cu));
-    const uint32_t side_waves = use_ps ? std::min<uint32_t>(n_reads, ps_blocks * BRX_PS_WAVES) : std::min<uint32_t>(n_reads, 4096u);   /* wave-level window aligner / legacy */
+    const uint32_t side_waves = std::min<uint32_t>(n_reads, 4096u);                 /* wave-level window aligner / legacy */
     const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, 512u);      /* lane-level window aligner          */
-    uint8_t *win = (uint8_t *)A.take((size_t)((use_ps ? ps_blocks * BRX_PS_WAVES : side_waves) + BRX_SEG_WAVES) * c->win_bytes);      /* one slot per wave */
+    uint8_t *win = (uint8_t *)A.take((size_t)(side_waves + 1) * c->win_bytes);      /* one slot per wave */
     MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
     uint32_t *mctr = (uint32_t *)A.take(8 * MC_WORDS * sizeof(uint32_t));   /* pass counters 0/1, 2 first bulk input, 3 bulk legacy, 4 head input, 5 head legacy, 6 head pass */
     uint32_t *active_a = (uint32_t *)A.take((size_t)n_reads * 4);
@@ -402,22 +380,13 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *req_legacy = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy_head = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *active_head = (uint32_t *)A.take((size_t)n_reads * 4);
-    uint8_t *winbuf = (uint8_t *)A.take((use_ps && n_reads <= 2 * c->head_reads) ? 64 : (size_t)n_reads * BRX_WIN_STRIDE + 64);   /* window slots per READ: the pass pipeline, the head chain */
-    uint32_t ps_ring = 64;
-    while (ps_ring < (n_reads + BRX_PQ_NX - 1) / BRX_PQ_NX + 1) ps_ring *= 2;
-    PQ *ps_pq = (PQ *)A.take(use_ps ? BRX_PQ_NX * sizeof(PQ) + sizeof(PQGlobal) + 2 * (size_t)BRX_PQ_NX * ps_ring * 4 : 64);   /* sets, global block, lane rings, return rings: one memset */
-    uint32_t *ps_planes = (uint32_t *)A.take(use_ps ? (size_t)n_reads * BRX_PL_WORDS * 4 : 64);
-    uint2 *ps_lane_tb = (uint2 *)A.take(use_ps ? (size_t)ps_blocks * BRX_PL_TB_UNITS * sizeof(uint2) : 64);
-    const bool use_wg = use_ps || (c->mutate_wg && !c->mutate_inline);      /* one launch for the whole mutate stage: the two sets only split the final stage */
-    const uint32_t wg_blocks = std::min<uint32_t>((n_reads + BRX_WG_WAVES - 1) / BRX_WG_WAVES, (uint32_t)c->n_cu * 2u);
-    uint2 *lane_tb = use_wg ? nullptr : (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
-    (void)lane_waves;
-    /* traceback stores of the packed window aligner: one set of 8 per workgroup of k_mutate_wg, or per wave of k_win_pack */
+    uint8_t *winbuf = (uint8_t *)A.take((size_t)n_reads * BRX_WIN_STRIDE + 64);
+    uint2 *lane_tb = (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
+    /* traceback stores of the packed window aligner: one set of 8 per wave of k_win_pack */
     const uint32_t pack_waves = std::min<uint32_t>((std::min<uint32_t>(n_reads, c->lane_threshold) + BRX_PACK_NG - 1) / BRX_PACK_NG, (uint32_t)c->n_cu * 4u);
     const uint32_t tail_eff = c->tail_reads != 0xFFFFFFFFu ? c->tail_reads : std::max<uint32_t>(1024u, n_reads / 12u);
-    const bool all_head = c->mutate_inline || (!use_wg && n_reads <= tail_eff);      /* the whole batch in one run-to-completion launch */
-    const uint32_t run_blocks = ((all_head ? n_reads : std::min<uint32_t>(n_reads, std::max<uint32_t>(tail_eff, 1u))) + BRX_WG_WAVES - 1) / BRX_WG_WAVES;   /* the tail (or everything) as k_mutate_wg */
-    uint2 *pack_tb = (uint2 *)A.take(use_ps ? 64 : (size_t)(use_wg ? wg_blocks : std::max<uint32_t>(std::max(pack_waves, run_blocks), 1u)) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
+    const bool all_head = c->mutate_inline || n_reads <= tail_eff;      /* the whole batch in one run-to-completion launch */
+    uint2 *pack_tb = (uint2 *)A.take((size_t)std::max<uint32_t>(pack_waves, 1u) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
     if (!raw) { KTIMED(BRX_KERN_PLAN, st); hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces); }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_PLAN], st));
@@ -451,17 +420,13 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
        (profiles/README.md r02g/r02h): head 1024 + tail 1024 2.08 Gbases/s, head 2048 + tail 2048 2.01, no head chain and a
        64-read tail (218 passes, the small ones with the packed window aligner) 1.63, 512-read tail 1.82 -- a pass costs
        1.5-2.6 ms beside the other batches' kernels whatever it aligns, an in-place cycle 0.3-0.6 ms. */
-    const uint32_t n_mh = all_head ? n_reads
-                          : use_ps ? (n_reads > 2 * c->head_reads ? c->head_reads : 0u)      /* a small batch goes through the persistent launch whole */
-                          : use_wg ? 0u : std::min<uint32_t>(c->head_reads, n_reads);
+    const uint32_t n_mh = all_head ? n_reads : std::min<uint32_t>(c->head_reads, n_reads);
     const uint32_t n_mb = n_reads - n_mh;
     const uint32_t n_head = n_mh ? n_mh : (n_reads <= 2 * c->fin_head_reads ? 0u : c->fin_head_reads);
     const uint32_t n_bulk = n_reads - n_head;
     uint8_t *win_head = nullptr;
-    uint2 *pack_head = pack_tb;
-    if (n_mh && n_mb && (!use_wg || use_ps)) {
-        pack_head = (uint2 *)A.take((size_t)((n_mh + BRX_WG_WAVES - 1) / BRX_WG_WAVES) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
-        win_head = (uint8_t *)A.take((size_t)(std::min(n_mh, side_waves) + BRX_SEG_WAVES) * c->win_bytes);
+    if (n_mh && n_mb) {
+        win_head = (uint8_t *)A.take((size_t)(std::min(n_mh, side_waves) + 1) * c->win_bytes);
         if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
     } else win_head = win;
     hipStream_t s_head = n_bulk ? c->side : st;            /* an all-head batch stays on the caller's stream */
@@ -518,11 +483,24 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             cls_list[k].push_back(h_order[i]);
             cls_units[k].push_back((u + 31) & ~31ull);
         }
-        const uint32_t limit[4] = {(uint32_t)c->n_cu * (uint32_t)c->waves_per_cu, (uint32_t)c->n_cu * (uint32_t)c->waves_per_cu,
-                                   (uint32_t)c->n_cu * 8u, (uint32_t)c->n_cu * 4u};
+        /* waves per class: what the chip can hold of each kernel beside the other batches' work (96 / 129 / 155 / 256 VGPRs: 5 / 3 / 3 /
+           1-2 waves per SIMD) -- more waves than that only add slabs.  A class's list is walked by STORE SIZE, largest first (a
+           store grows with length x band width, and so does the work: the order is also longest-processing-time first), so the
+           suffix maximum at position t is the t-th largest store and W waves hold the W largest stores of the class. */
+        const uint32_t wpc = (uint32_t)c->waves_per_cu;
+        const uint32_t limit[4] = {(uint32_t)c->n_cu * std::max(wpc / 2u, 1u), (uint32_t)c->n_cu * std::max(wpc / 4u, 1u),
+                                   (uint32_t)c->n_cu * std::max(wpc / 8u, 1u), (uint32_t)c->n_cu * std::max(wpc / 16u, 1u)};
         uint32_t grid[4];
         std::vector<uint64_t> sufmax[4];
         for (int k = 0; k < 4; ++k) {
+            {
+                std::vector<uint32_t> idx(cls_list[k].size());
+                for (size_t x = 0; x < idx.size(); ++x) idx[x] = (uint32_t)x;
+                std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a_, uint32_t b_) { return cls_units[k][a_] > cls_units[k][b_]; });
+                std::vector<uint32_t> l2(idx.size()); std::vector<uint64_t> u2(idx.size());
+                for (size_t x = 0; x < idx.size(); ++x) { l2[x] = cls_list[k][idx[x]]; u2[x] = cls_units[k][idx[x]]; }
+                cls_list[k].swap(l2); cls_units[k].swap(u2);
+            }
             const size_t n = cls_list[k].size();
             sufmax[k].assign(n + 1, 0);
             for (size_t x = n; x-- > 0;) sufmax[k][x] = std::max(sufmax[k][x + 1], cls_units[k][x]);
@@ -542,6 +520,9 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             if (big < 0) break;
             grid[big] = (grid[big] + 1) / 2;
         }
+        DBG("final set %d phase %d: %u reads, classes %zu/%zu/%zu/%zu, slabs %u/%u/%u/%u, need %.2f GB, left %.2f GB, arena used %.2f GB", S.id, phase, ns,
+            cls_list[0].size(), cls_list[1].size(), cls_list[2].size(), cls_list[3].size(), grid[0], grid[1], grid[2], grid[3],
+            (double)need() / 1e9, (double)left / 1e9, (double)A.used / 1e9);
         if (need() > left) return scratch_short(c, c->scratch_bytes + (size_t)(need() - left) + ((size_t)1 << 28));
         uint8_t *region = c->scratch + at;
         if (phase == 0) { S.tb_at = at; S.tb_cap = (size_t)need(); S.col_bytes = (size_t)col_total * 8; (void)A.take(S.tb_cap); }
@@ -701,82 +682,36 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     }
     const uint32_t lane_threshold = c->lane_threshold;   /* fewer active reads than this: one wave per window (lower latency) */
     /* reads taken to completion in ONE launch (the head set from the start; the last BRX_TAIL_READS of the bulk set):
-       k_mutate_seg<true> (default), every read aligning its own windows with a whole wave (61 k wave-instructions per
-       window; 53 of the batch's 195 VALU instructions per base in profiles/r02_valu_per_base.json), or BRX_RUN_WG=1
-       k_mutate_wg -- workgroups of 8 reads whose identity checks are aligned eight to a wave (12 k per window).
-       Measured (r02i, configs[3], 8 batches in flight): seg<true> 2.04 Gbases/s, k_mutate_wg 1.71 -- a lockstep round
-       of the workgroup kernel (slowest of 8 segments + the packed alignment) takes ~1.3 M cycles against ~0.65 M for an
-       in-place cycle, and the launch is on the batch's critical path */
+       k_mutate_seg<true>, every read aligning its own windows with a whole wave.  (Rounds 2 and 3 measured three ways of
+       taking these windows to a cheaper aligner -- workgroups of 8 reads with packed alignments, 8-wave pass kernels, a
+       persistent launch with device queues -- and every one lost to this chain on the batch's critical path: DESIGN.md section 7.) */
     auto launch_run = [&](hipStream_t s, uint32_t count, const uint32_t *act_in, const uint32_t *n_in, uint32_t *act_out, uint32_t *ctr,
-                          uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr, uint2 *packscr) {
+                          uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr) {
         KTIMED(BRX_KERN_MUTATE_RUN, s);
-        if (c->run_wg) {
-            const uint32_t blocks = (count + BRX_WG_WAVES - 1) / BRX_WG_WAVES;
-            if (c->profile)
-                hipLaunchKernelGGL((k_mutate_wg<true>), dim3(blocks), dim3(64 * BRX_WG_WAVES), 0, s, dev, rs, msv, act_in, count, ctr + MC_QUEUE,
-                                   legacy_list, legacy_ctr, Fbuf, repl, winbuf, packscr, winscr, (uint64_t)c->win_bytes, counters + 1, clk, phase);
-            else
-                hipLaunchKernelGGL((k_mutate_wg<false>), dim3(blocks), dim3(64 * BRX_WG_WAVES), 0, s, dev, rs, msv, act_in, count, ctr + MC_QUEUE,
-                                   legacy_list, legacy_ctr, Fbuf, repl, winbuf, packscr, winscr, (uint64_t)c->win_bytes, counters + 1, clk, phase);
-            return;
-        }
         if (c->profile)
-            hipLaunchKernelGGL((k_mutate_seg<true, true>), dim3((std::min(count, side_waves) + BRX_SEG_WAVES - 1) / BRX_SEG_WAVES), dim3(64 * BRX_SEG_WAVES), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
+            hipLaunchKernelGGL((k_mutate_seg<true, true>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
                                req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                winscr, (uint64_t)c->win_bytes, counters + 1, phase);
         else
-            hipLaunchKernelGGL((k_mutate_seg<true, false>), dim3((std::min(count, side_waves) + BRX_SEG_WAVES - 1) / BRX_SEG_WAVES), dim3(64 * BRX_SEG_WAVES), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
+            hipLaunchKernelGGL((k_mutate_seg<true, false>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
                                req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                winscr, (uint64_t)c->win_bytes, counters + 1, phase);
     };
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_MUTATE], st));
-    /* ---- BRX_MUTATE_WG (default): the whole mutate stage is one launch (brx_mutate_wg.h); the two sets only split the final stage ---- */
-    if (use_wg && !use_ps) {
-        uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
-        uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;
-        {
-            KTIMED(BRX_KERN_MUTATE_RUN, st);
-            if (c->profile)
-                hipLaunchKernelGGL((k_mutate_wg<true>), dim3(wg_blocks), dim3(64 * BRX_WG_WAVES), 0, st, dev, rs, msv, order, n_reads, mctr + MC_QUEUE,
-                                   req_legacy, legacy_ctr, Fbuf, repl, winbuf, pack_tb, win, (uint64_t)c->win_bytes, counters + 1, clk, phase);
-            else
-                hipLaunchKernelGGL((k_mutate_wg<false>), dim3(wg_blocks), dim3(64 * BRX_WG_WAVES), 0, st, dev, rs, msv, order, n_reads, mctr + MC_QUEUE,
-                                   req_legacy, legacy_ctr, Fbuf, repl, winbuf, pack_tb, win, (uint64_t)c->win_bytes, counters + 1, clk, phase);
-        }
-        c->mutate_passes = 1;
-    }
     /* ---- head chain: mutate to completion ---- */
-    if (n_mh && (!use_wg || use_ps)) {
+    if (n_mh) {
         if (n_mb) {
             HIPCHK(c, hipEventRecord(c->ev_fork, st));
             HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
         }
         launch_run(s_head, n_mh, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, req_legacy_head,
-                   mctr + 5 * MC_WORDS, win_head, pack_head);
+                   mctr + 5 * MC_WORDS, win_head);
         if (n_mb) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
-        c->mutate_passes = 1;
-    }
-    /* ---- bulk chain, persistent: ONE launch on the caller's stream (brx_persist.h), beside the head chain ---- */
-    if (use_ps && n_mb) {
-        uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;
-        const size_t ps_bytes = BRX_PQ_NX * sizeof(PQ) + sizeof(PQGlobal) + 2 * (size_t)BRX_PQ_NX * ps_ring * 4;
-        HIPCHK(c, hipMemsetAsync(ps_pq, 0, ps_bytes, st));
-        PsArgs P;
-        P.rs = rs; P.msv = msv; P.order = order + n_mh; P.n_items = n_mb; P.pq = ps_pq; P.pg = reinterpret_cast<PQGlobal *>(ps_pq + BRX_PQ_NX);
-        P.lane_ring = reinterpret_cast<uint32_t *>(P.pg + 1); P.ret_ring = P.lane_ring + (size_t)BRX_PQ_NX * ps_ring; P.ring_mask = ps_ring - 1;
-        P.req_legacy = req_legacy; P.legacy_ctr = legacy_ctr; P.Fbuf = Fbuf; P.repl = repl; P.planes = ps_planes;
-        P.scr_base = win; P.scr_bytes = (uint64_t)c->win_bytes; P.lane_tb = ps_lane_tb; P.flags = counters + 1; P.clk = clk;
-        P.long_cycles = c->ps_long; P.low_water = c->ps_low; P.patience = c->ps_patience; P.exit_idle = std::max(c->ps_exit_idle, c->ps_patience + 2u);   /* a wave must reach its patience (and take what is parked) before it may leave */
-        {
-            KTIMED(BRX_KERN_MUTATE_SEG, st);
-            hipLaunchKernelGGL(k_mutate_persist, dim3(ps_blocks), dim3(64 * BRX_PS_WAVES), 0, st, dev, P);
-        }
-        HIPCHK(c, hipMemcpyAsync(c->ps_stats, P.pg, sizeof(c->ps_stats), hipMemcpyDeviceToHost, st));   /* waited for with the legacy counters below */
         c->mutate_passes = 1;
     }
     /* ---- bulk chain: passes ---- */
     int rc2 = BRX_OK;
-    if (n_mb && !use_wg) {
+    if (n_mb) {
         const uint32_t seg_waves = std::min<uint64_t>(n_mb, (uint64_t)c->n_cu * (uint64_t)c->seg_waves_per_cu);
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;                                 /* [0] count, [1] queue; not reset per pass */
@@ -805,7 +740,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                     HIPCHK(c, hipStreamSynchronize(st));
                     for (uint32_t x : h_act) if (x < n_reads) tail_bases += h_rs[x].n;
                 }
-                launch_run(st, n_up, act_in, n_in, act_out, ctr, req_legacy, legacy_ctr, win, pack_tb);
+                launch_run(st, n_up, act_in, n_in, act_out, ctr, req_legacy, legacy_ctr, win);
                 rc2 = read_counts(ctr);
                 if (rc2) return rc2;
                 n_up = h_ctr[MC_OUT];                   /* 0 unless a window overflowed its slot (then: legacy list) */
@@ -815,11 +750,11 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             {
                 KTIMED(BRX_KERN_MUTATE_SEG, st);
                 if (c->profile)
-                    hipLaunchKernelGGL((k_mutate_seg<false, true>), dim3((std::min(seg_waves, n_up) + BRX_SEG_WAVES - 1) / BRX_SEG_WAVES), dim3(64 * BRX_SEG_WAVES), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                    hipLaunchKernelGGL((k_mutate_seg<false, true>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
                                        ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                        win, (uint64_t)c->win_bytes, counters + 1, phase);
                 else
-                    hipLaunchKernelGGL((k_mutate_seg<false, false>), dim3((std::min(seg_waves, n_up) + BRX_SEG_WAVES - 1) / BRX_SEG_WAVES), dim3(64 * BRX_SEG_WAVES), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                    hipLaunchKernelGGL((k_mutate_seg<false, false>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
                                        ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                        win, (uint64_t)c->win_bytes, counters + 1, phase);
             }

@@ -489,25 +489,14 @@ __device__ inline void dev_random_change(const uint8_t *kmer, int k, uint32_t w3
 }
 
 /* returns false if the k-mer is unchanged */
-/* thr16: the high halves of self_thr[] staged in LDS (k_mutate_wg; nullptr elsewhere).  hi(w2) < thr16[row] proves
-   w2 < self_thr[row] and hi(w2) > thr16[row] the opposite: the ~93 % of draws that leave the k-mer unchanged
-   (simulate.py:300) are rejected without touching global memory; one draw in 65536 needs the full word. */
-__device__ inline bool dev_choose_alt(const brx_error_model &em, const uint8_t *kmer, uint32_t w2, uint32_t w3, uint32_t *rep,
-                                      const uint16_t *thr16 = nullptr) {
+__device__ inline bool dev_choose_alt(const brx_error_model &em, const uint8_t *kmer, uint32_t w2, uint32_t w3, uint32_t *rep) {
     const int k = em.k;
     if (em.type == 0) { dev_random_change(kmer, k, w3, rep); return true; }
     uint32_t row = 0; bool bad = false;
 #pragma unroll
     for (int j = 0; j < 16; ++j) if (j < k) { bad |= kmer[j] > 3; row = (row << 2) | (kmer[j] & 3u); }
     if (bad) { dev_random_change(kmer, k, w3, rep); return true; }
-    if (thr16) {
-        const uint32_t h = thr16[row], wh = w2 >> 16;
-        if (wh < h) return false;                                /* the common case: unchanged */
-        if (wh == h && w2 < em.d_self_thr[row]) return false;
-    } else {
-        uint32_t st = em.d_self_thr[row];
-        if (w2 < st) return false;                               /* the common case: unchanged */
-    }
+    if (w2 < em.d_self_thr[row]) return false;                   /* the common case (~93 % of draws, simulate.py:300): unchanged */
     uint32_t a0 = em.d_row_off[row], a1 = em.d_row_off[row + 1];
     if (a0 == a1) { dev_random_change(kmer, k, w3, rep); return true; }
     /* first alternative whose cumulative threshold exceeds the draw (thresholds are non-decreasing):
@@ -717,8 +706,6 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
 
 #include "brx_pack.h"
 #include "brx_mutate.h"
-#include "brx_mutate_wg.h"
-#include "brx_persist.h"
 #include "brx_model.h"
 #include "brx_gzip_dev.h"
 

@@ -38,7 +38,8 @@
 #define BRX_WIN_STRIDE (BRX_WIN_BYTES + 4 * BRX_WIN_PLANE_WORDS)   /* slot bytes per read */
 #define BRX_LANE_W 8                                     /* lane kernel: band blocks alive in one column      */
 #define BRX_LANE_TBC 16                                  /* lane kernel: traceback columns fetched per round  */
-#define BRX_LANE_TB_UNITS ((uint64_t)(BRX_LANE_TMAX + 1) * BRX_LANE_W * 64)   /* uint2 units per wave       */
+#define BRX_LANE_QW 32                                   /* lane kernel: query plane words (windows of up to 1024 rows) */
+#define BRX_LANE_TB_UNITS ((uint64_t)(BRX_LANE_TMAX + 34) * BRX_LANE_W * 64)  /* uint2 units of move codes per wave: [trip][slot][lane] */
 
 struct MS {                       /* loop state of a parked read */
     double errors, est;
@@ -101,37 +102,23 @@ __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F
              ph_last = now_; ph0 += ph_cur == 0 ? dt_ : 0; ph1 += ph_cur == 1 ? dt_ : 0; ph2 += ph_cur == 2 ? dt_ : 0;   \
              ph3 += ph_cur == 3 ? dt_ : 0; ph4 += ph_cur == 4 ? dt_ : 0; ph_cur = (next); } } while (0)
 
-/* BRX_SEG_WAVES / BRX_SEG_THR_ROWS (build macros): workgroups of BRX_SEG_WAVES independent waves (one read each, no
- * barrier after the prologue) can share an LDS copy of the high halves of the error model's self thresholds (32 KB for
- * k = 7: SURVEY.md section 0.6 / Appendix C), so that the ~93 % of k-mer draws that leave the k-mer unchanged
- * (simulate.py:300) are rejected by one 16-bit LDS compare (dev_choose_alt).  MEASURED (round 2, profiles/README.md r02e,
- * 8 batches in flight, configs[1]): 8 waves + table 1.69 Gbases/s, 8 waves without the table 1.77, 4 waves + table 1.75,
- * one wave per workgroup and the thresholds read through L2 2.02 -- the pass kernels are short (2 ms) and run beside
- * dozens of other kernels, and a workgroup that needs 4-8 free wave slots on ONE compute unit is dispatched much later
- * than single waves that fill any free slot (k_mutate_seg<false>: 110 -> 320 ms per batch).  The shipped build therefore
- * keeps one wave per workgroup and no LDS table here; the LDS variant stays buildable (-DBRX_SEG_WAVES=8
- * -DBRX_SEG_THR_ROWS=16384), is interpreted by the CPU tests, and is what k_mutate_wg (brx_mutate_wg.h) uses. */
-#ifndef BRX_SEG_WAVES
-#define BRX_SEG_WAVES 1
-#endif
-#ifndef BRX_SEG_THR_ROWS
-#define BRX_SEG_THR_ROWS 1
-#endif
+/* One wave per workgroup and the self thresholds read through L2.  Staging the thresholds in LDS (32 KB of 16-bit halves for
+ * k = 7: SURVEY.md section 0.6 / Appendix C) needs workgroups of several waves to pay for the table, and was measured three
+ * times, bit-exact each time, slower each time: pass kernels as 4-8-wave workgroups (round 2: 1.69-1.75 vs 2.02 Gbases/s -- a short
+ * kernel that needs 4-8 free wave slots on ONE CU is dispatched late), a workgroup kernel with packed alignments (round 2: 1.57-1.71
+ * vs 2.04), a persistent launch with device queues (round 3: 0.65-1.6 vs 2.96).  What the table would save
+ * is one 4-byte L2 hit per proposal. */
 template <bool INLINE, bool PROFILE = false>
-__global__ void __launch_bounds__(64 * BRX_SEG_WAVES, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
+__global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
                                                     const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,
                                                     uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
                                                     const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk,
                                                     uint32_t lane_threshold, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags,
                                                     uint64_t *phase) {
-    __shared__ uint16_t s_thr16[BRX_SEG_THR_ROWS];
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
-    const bool use_thr = em.type == 1 && em.n_rows <= BRX_SEG_THR_ROWS;
-    if (use_thr) for (uint32_t x = threadIdx.x; x < em.n_rows; x += blockDim.x) s_thr16[x] = (uint16_t)(em.d_self_thr[x] >> 16);
-    __syncthreads();
-    const uint32_t wave_index = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      /* scratch slot of this wave */
+    const uint32_t wave_index = blockIdx.x;                                               /* scratch slot of this wave */
     const uint32_t n_in = uni(*n_in_ptr);
     uint64_t ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, ph_last = 0, pclk[2] = {0, 0};
     int ph_cur = 4;
@@ -199,7 +186,7 @@ __global__ void __launch_bounds__(64 * BRX_SEG_WAVES, 4) k_mutate_seg(BrxDev d, 
                 uint8_t kmer[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) kmer[j] = j < k ? F[ipos + j] : 0;
-                live = dev_choose_alt(em, kmer, w[2], w[3], rep, use_thr ? s_thr16 : (const uint16_t *)nullptr);
+                live = dev_choose_alt(em, kmer, w[2], w[3], rep);
             }
             unsigned long long surv = __ballot(live);
             BRX_PHASE(1);
@@ -317,7 +304,7 @@ __global__ void __launch_bounds__(64 * BRX_SEG_WAVES, 4) k_mutate_seg(BrxDev d, 
             uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)wave_index * scr_bytes);
             int ncols = 0, nmatch = 0; bool nospace = false;
             BRX_PHASE(3);
-            const bool ok = brx_wave_align<1, 1, true>(qb, (int)(ms.win_b - ms.win_a), tbuf, (int)ms.tl, (int)ms.cost, tb, scr_bytes / 8, nullptr,
+            const bool ok = brx_wave_align<1, 1>(qb, (int)(ms.win_b - ms.win_a), tbuf, (int)ms.tl, (int)ms.cost, tb, scr_bytes / 8, nullptr,
                                               &ncols, &nmatch, &nospace, nullptr, PROFILE ? pclk : nullptr);
             BRX_PHASE(4);
             ms.res_ncols = (uint32_t)ncols; ms.res_nmatch = (uint32_t)nmatch;
@@ -394,11 +381,178 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
-__global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr,
-                                                  const uint8_t *winbuf, uint2 *tbw_base) {
-    __shared__ uint32_t q_lo[32][64], q_hi[32][64];                       /* query planes, block x lane  */
-    __shared__ uint32_t t_lo[BRX_LANE_TMAX / 32][64], t_hi[BRX_LANE_TMAX / 32][64];
-    __shared__ uint32_t st_pv[BRX_LANE_W][64], st_mv[BRX_LANE_W][64];     /* band state, slot x lane     */
+/* -----------------------------------------------------------------------------------------------------------------
+ * brx_lanes_align: up to 64 window alignments, one per LANE, band state in registers
+ * -----------------------------------------------------------------------------------------------------------------
+ * Same band (brx_make_geom), same cell recurrence and the same canonical traceback (up / 'I', left / 'D', diagonal) as
+ * brx_wave_align; only the distance columns and matches of the path are produced (all the mutate loop uses).
+ *
+ * A lane holds BRX_LANE_W consecutive 32-row blocks of its window: slot x = block s_lo + x, s_lo = the first block of
+ * the band.  The band moves down one block every 32 columns, at a column that depends on the lane's geometry; the
+ * lanes are therefore skewed against each other: in loop trip jj a lane works on ITS column j = jj - off, with off
+ * chosen so that every lane's band moves exactly in the trips jj = 0 (mod 32) -- the register shift is one uniform
+ * block of code instead of a dynamically indexed register file (round 2 kept the band in LDS for that reason: 45 KB per
+ * wave, three waves per CU, and ~60 of its ~200 instructions per column were LDS addressing and traffic).  Query planes enter a lane's
+ * registers one block per shift, the target planes as a 32-column window per shift (two funnel shifts), straight from
+ * the parked planes in global memory: no LDS at all.
+ *
+ * What the forward pass stores per cell is the MOVE of the canonical traceback in two bits -- up = 10, left = 01,
+ * diagonal on equal symbols = 00, diagonal on different symbols = 11 -- instead of {Pv, Ph}: the walk then counts
+ * matches without looking at the sequences again.  Layout [trip][slot][lane]: a store instruction writes 512
+ * contiguous bytes at a wave-uniform base.
+ */
+__device__ __forceinline__ uint32_t brx_bfe_mask(uint32_t v, int b) { return (uint32_t)((int32_t)(v << (31 - b)) >> 31); }
+
+template <int TW>
+__device__ inline void brx_lanes_align(const bool valid, const uint32_t *__restrict__ pl, const int Q, const int T, const int kb,
+                                       uint2 *__restrict__ tbw, uint32_t *out_ncols, uint32_t *out_nmatch, bool *out_ok) {
+    constexpr int W = BRX_LANE_W;
+    const int lane = lane_id();
+    const BrxGeom g = brx_make_geom(Q > 0 ? Q : 1, T > 0 ? T : 1, kb);
+    const int NS = (Q + 31) >> 5;
+    const int Wb = (int)wave_max_u32(valid ? (uint32_t)((g.dhi - g.dlo) / 32 + 2) : 0u);      /* slots in use: the widest band of the wave */
+    const int off = (g.dlo - 1) & 31;                       /* jj = j + off; (j + dlo - 1) >> 5 = (jj >> 5) + qb */
+    const int qb = (g.dlo - 1 - off) >> 5;                  /* exact: dlo - 1 - off is a multiple of 32; negative */
+    const int JJ = (int)wave_max_u32(valid ? (uint32_t)(T + off) : 0u);
+
+    uint32_t P[W], M[W], QL[W], QH[W];
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+        P[x] = 0xFFFFFFFFu; M[x] = 0u;                      /* cells below the band grow by +1 per row */
+        const bool in = valid && x < NS;
+        QL[x] = in ? pl[x] : 0u; QH[x] = in ? pl[BRX_LANE_QW + x] : 0u;
+    }
+    int slo = 0;                                            /* block held in slot 0 */
+    uint32_t TLw = 0u, THw = 0u;                            /* target planes of columns j0 .. j0 + 31, j0 = (jj & ~31) - off */
+    const uint32_t *tlo = pl + 2 * BRX_LANE_QW, *thi = tlo + TW;
+    for (int jj = 0; jj <= JJ; ++jj) {
+        if ((jj & 31) == 0) {
+            /* ---- the band moves down one block (lanes whose band still starts at block 0 stay) ---- */
+            const int bq = (jj >> 5) + qb;
+            if (valid && bq >= 1) {
+#pragma unroll
+                for (int x = 0; x + 1 < W; ++x) { P[x] = P[x + 1]; M[x] = M[x + 1]; QL[x] = QL[x + 1]; QH[x] = QH[x + 1]; }
+                const int nb = bq + W - 1;
+                P[W - 1] = 0xFFFFFFFFu; M[W - 1] = 0u;
+                QL[W - 1] = nb < NS ? pl[nb] : 0u; QH[W - 1] = nb < NS ? pl[BRX_LANE_QW + nb] : 0u;
+                slo = bq;
+            }
+            /* ---- target planes of the next 32 trips: bit t = target index (jj - off - 1) + t ---- */
+            const int t0 = jj - off - 1;
+            const int w0 = t0 >> 5, sh = t0 & 31;
+            const bool in0 = valid && w0 >= 0 && w0 < TW, in1 = valid && w0 + 1 >= 0 && w0 + 1 < TW;
+            const uint32_t l0 = in0 ? tlo[w0] : 0u, l1 = in1 ? tlo[w0 + 1] : 0u;
+            const uint32_t h0 = in0 ? thi[w0] : 0u, h1 = in1 ? thi[w0 + 1] : 0u;
+            TLw = __builtin_amdgcn_alignbit(l1, l0, (uint32_t)sh);
+            THw = __builtin_amdgcn_alignbit(h1, h0, (uint32_t)sh);
+        }
+        const int j = jj - off;
+        const bool act = valid && j >= 1 && j <= T;
+        int hi = (j + g.dhi - 1) >> 5;                      /* last block of the band in column j ... */
+        if (hi > NS - 1) hi = NS - 1;
+        hi = act ? hi - slo : -1;                           /* ... as a slot; slots 0 .. hi are computed */
+        const int b = jj & 31;
+        const uint32_t m0 = brx_bfe_mask(TLw, b), m1 = brx_bfe_mask(THw, b);
+        uint32_t hp = 1u, hm = 0u;                          /* above the band (and above row 1): +1 per column */
+        uint2 *dst = tbw + ((uint64_t)jj * (uint64_t)Wb) * 64u + (uint32_t)lane;
+#pragma unroll
+        for (int x = 0; x < W; ++x) {
+            if (x >= Wb) break;
+            const uint32_t pv0 = P[x], mv0 = M[x];
+            const uint32_t Eq = ~((QL[x] ^ m0) | (QH[x] ^ m1));
+            const uint32_t Xv = Eq | mv0;
+            const uint32_t Eq2 = Eq | hm;
+            const uint32_t Xh = (((Eq2 & pv0) + pv0) ^ pv0) | Eq2;
+            const uint32_t Ph = mv0 | ~(Xh | pv0);
+            const uint32_t Mh = pv0 & Xh;
+            const uint32_t PhS = (Ph << 1) | hp;
+            const uint32_t MhS = (Mh << 1) | hm;
+            const uint32_t pv = MhS | ~(Xv | PhS);
+            const uint32_t mv = PhS & Xv;
+            const bool on = x <= hi;
+            P[x] = on ? pv : pv0;
+            M[x] = on ? mv : mv0;
+            if (on) {
+                const uint32_t dX = ~(pv | Ph | Eq);        /* diagonal move on different symbols */
+                dst[(uint32_t)x * 64u] = make_uint2(pv | dX, (Ph & ~pv) | dX);
+            }
+            hp = Ph >> 31; hm = Mh >> 31;                   /* the computed slots are 0 .. hi: every carry that is used was computed */
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                          /* this wave's stores are visible to its loads below */
+
+    /* ---- traceback, canonical (up, left, diagonal), BRX_LANE_TBC columns fetched per round trip ----
+       A lane owns its window, so the walk is bit arithmetic on the two code words it holds per column (block s0 of the
+       row it starts the round in, and s0 - 1): the run of up moves in a column is the run of 'up' codes below the current
+       row (one count-leading-zeros), the code of the row it stops in says left, match or mismatch. */
+    int i = Q, j = T;
+    uint32_t ncols = 0, nmatch = 0;
+    bool ok = valid;
+    bool go = valid && i > 0 && j > 0;
+    while (__ballot(go) != 0ull) {
+        const int s0 = go ? ((i - 1) >> 5) : 0;
+        const int jst = j;
+        uint2 A[BRX_LANE_TBC], Bv[BRX_LANE_TBC];
+#pragma unroll
+        for (int x = 0; x < BRX_LANE_TBC; ++x) {
+            const int col = jst - x;
+            A[x] = make_uint2(0u, 0u); Bv[x] = make_uint2(0u, 0u);
+            if (go && col >= 1) {
+                int sl = (col + g.dlo - 1) >> 5; if (sl < 0) sl = 0;
+                const int xa = s0 - sl;
+                const uint64_t rowb = (uint64_t)(col + off) * (uint64_t)Wb;
+                if (xa >= 0 && xa < Wb) A[x] = tbw[(rowb + (uint32_t)xa) * 64u + (uint32_t)lane];
+                if (xa >= 1 && xa - 1 < Wb) Bv[x] = tbw[(rowb + (uint32_t)(xa - 1)) * 64u + (uint32_t)lane];
+            }
+        }
+        bool walk = go;
+#pragma unroll
+        for (int x = 0; x < BRX_LANE_TBC; ++x) {
+            bool done = !(walk && i > 0 && j > 0);
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                if (!done) {
+                    const int sb = (i - 1) >> 5;
+                    if (sb != s0 && sb != s0 - 1) { walk = false; done = true; }
+                    else {
+                        const int jf = 32 * sb - g.dhi + 1 < 1 ? 1 : 32 * sb - g.dhi + 1;
+                        long long jl = 32ll * (sb + 1) - g.dlo; if (jl > T) jl = T;
+                        if (j < jf || j > jl) { ok = false; walk = false; go = false; done = true; }
+                        else {
+                            const bool top = sb == s0;
+                            const uint32_t c1 = top ? A[x].x : Bv[x].x, c0 = top ? A[x].y : Bv[x].y;
+                            const int bit = (i - 1) & 31;
+                            const uint32_t stay = ~(c1 & ~c0) & (0xFFFFFFFFu >> (31 - bit));      /* rows at or above this one whose move is not 'up' */
+                            if (stay == 0u) {
+                                i -= bit + 1; ncols += (uint32_t)(bit + 1);
+                                if (i == 0) done = true;
+                            } else {
+                                const int row = 31 - __clz((int)stay);
+                                i -= bit - row; ncols += (uint32_t)(bit - row);
+                                const uint32_t r1 = (c1 >> row) & 1u, r0 = (c0 >> row) & 1u;
+                                if (r0 && !r1) { j -= 1; ncols += 1; }                              /* left */
+                                else { nmatch += r1 ^ 1u; i -= 1; j -= 1; ncols += 1; }           /* diagonal: 00 match, 11 mismatch */
+                                done = true;
+                            }
+                        }
+                    }
+                }
+            }
+            if (!done) walk = false;
+        }
+        go = go && ok && i > 0 && j > 0;
+    }
+    if (valid) {
+        ncols += (uint32_t)(i + j);
+        if (ok && (ncols - nmatch) > (uint32_t)kb) ok = false;
+    }
+    *out_ncols = ok ? ncols : 0u; *out_nmatch = ok ? nmatch : 0u; *out_ok = ok;
+}
+
+
+__global__ void __launch_bounds__(64, 4) k_win_lane(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr,
+                                                     const uint8_t *winbuf, uint2 *tbw_base) {
     const int lane = lane_id();
     const uint32_t n_req = uni(*n_req_ptr);
     uint2 *tbw = tbw_base + (uint64_t)blockIdx.x * BRX_LANE_TB_UNITS;
@@ -409,161 +563,12 @@ __global__ void __launch_bounds__(64) k_win_lane(MS *msv, const uint32_t *req, c
         MS ms;
         if (valid) ms = msv[r];
         const int Q = valid ? (int)(ms.win_b - ms.win_a) : 0, T = valid ? (int)ms.tl : 0, kb = valid ? (int)ms.cost : 0;
-
-        /* ---- the window pair of every lane as bit planes: written by the parking wave behind the bytes of its slot ---- */
-        {
-            const uint32_t *pl = reinterpret_cast<const uint32_t *>(winbuf + (uint64_t)r * BRX_WIN_STRIDE + BRX_WIN_PLANES);
-            const int nq = (Q + 31) >> 5, nt = (T + 31) >> 5;
-            const int nq_max = (int)wave_max_u32((uint32_t)nq), nt_max = (int)wave_max_u32((uint32_t)nt);
-            for (int w = 0; w < nq_max; ++w) {
-                const bool in = w < nq;
-                q_lo[w][lane] = in ? pl[w] : 0u; q_hi[w][lane] = in ? pl[32 + w] : 0u;
-            }
-            for (int w = 0; w < nt_max; ++w) {
-                const bool in = w < nt;
-                t_lo[w][lane] = in ? pl[64 + w] : 0u; t_hi[w][lane] = in ? pl[64 + BRX_LANE_TMAX / 32 + w] : 0u;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-
-        /* ---- forward: banded block Myers, one window per lane ---- */
-        const BrxGeom g = brx_make_geom(Q > 0 ? Q : 1, T > 0 ? T : 1, kb);
-        const int NS = (Q + 31) >> 5;
-        const uint32_t lastmask = (Q & 31) ? ((1u << (Q & 31)) - 1u) : 0xFFFFFFFFu;
-        const int Tmax = (int)wave_max_u32((uint32_t)T);
-        const int Wb = (int)wave_max_u32(valid ? (uint32_t)((g.dhi - g.dlo) / 32 + 2) : 0u);
-        int s_hi = -1;
-        for (int j = 1; j <= Tmax; ++j) {
-            const bool act = j <= T;
-            /* blocks entering the band at this column: cells below the band grow by +1 per row */
-            int new_hi = (j + g.dhi - 1) >> 5;
-            if (new_hi > NS - 1) new_hi = NS - 1;
-            if (!act) new_hi = s_hi;
-            while (__ballot(s_hi < new_hi) != 0ull) {
-                if (s_hi < new_hi) { s_hi += 1; st_pv[s_hi & (BRX_LANE_W - 1)][lane] = 0xFFFFFFFFu; st_mv[s_hi & (BRX_LANE_W - 1)][lane] = 0u; }
-            }
-            int s_lo = (j + g.dlo - 1) >> 5;
-            if (s_lo < 0) s_lo = 0;
-            const int w = (j - 1) >> 5, bit = (j - 1) & 31;
-            const uint32_t c0 = (t_lo[w][lane] >> bit) & 1u, c1 = (t_hi[w][lane] >> bit) & 1u;
-            const uint32_t m0 = 0u - c0, m1 = 0u - c1;
-            uint32_t hp = 1u, hm = 0u;
-            uint2 *dstj = tbw + ((uint64_t)j * BRX_LANE_W) * 64u + (uint32_t)lane;
-            /* all band words of this column are fetched from LDS first (independent loads, one latency), the carry
-               chain then runs in registers, and the words go back: the loop used to pay ~6 dependent LDS round trips
-               per word with one wave per SIMD and nothing to hide them */
-            uint32_t P[BRX_LANE_W], M[BRX_LANE_W], QL[BRX_LANE_W], QH[BRX_LANE_W];
-#pragma unroll
-            for (int x = 0; x < BRX_LANE_W; ++x) {
-                if (x >= Wb) break;                                /* Wb: widest band of the wave's windows, in blocks */
-                const int sb = s_lo + x;
-                const bool on = act && sb <= s_hi;
-                const int sbc = on ? sb : 0;
-                const int slot = sbc & (BRX_LANE_W - 1);
-                P[x] = st_pv[slot][lane]; M[x] = st_mv[slot][lane];
-                QL[x] = q_lo[sbc][lane]; QH[x] = q_hi[sbc][lane];
-            }
-#pragma unroll
-            for (int x = 0; x < BRX_LANE_W; ++x) {
-                if (x >= Wb) break;
-                const int sb = s_lo + x;
-                const bool on = act && sb <= s_hi;
-                const int sbc = on ? sb : 0;
-                const int slot = sbc & (BRX_LANE_W - 1);
-                uint32_t pv = P[x], mv = M[x];
-                uint32_t Eq = ~((QL[x] ^ m0) | (QH[x] ^ m1));
-                if (sbc == NS - 1) Eq &= lastmask;
-                const uint32_t Xv = Eq | mv;
-                const uint32_t Eq2 = Eq | hm;
-                const uint32_t Xh = (((Eq2 & pv) + pv) ^ pv) | Eq2;
-                const uint32_t Ph = mv | ~(Xh | pv);
-                const uint32_t Mh = pv & Xh;
-                const uint32_t op = Ph >> 31, om = Mh >> 31;
-                const uint32_t PhS = (Ph << 1) | hp;
-                const uint32_t MhS = (Mh << 1) | hm;
-                pv = MhS | ~(Xv | PhS);
-                mv = PhS & Xv;
-                if (on) {
-                    st_pv[slot][lane] = pv; st_mv[slot][lane] = mv;
-                    dstj[(uint32_t)slot * 64u] = make_uint2(pv, Ph);
-                    hp = op; hm = om;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-
-        /* ---- traceback, canonical (up, left, diagonal), BRX_LANE_TBC columns fetched per round trip ----
-           A lane owns its window, so the walk is bit arithmetic on the two words it holds per column (block s0 of the row
-           it starts the round in, and s0 - 1): the run of up moves in a column is the run of set Pv bits below the current
-           row (one count-leading-zeros), then the Ph bit of the row it stops in says left or diagonal.  No per-move loop, no
-           ballots inside a round; a climb that leaves the two fetched blocks ends the lane's round early. */
-        int i = Q, j = T;
-        uint32_t ncols = 0, nmatch = 0;
-        bool ok = valid;
-        bool go = valid && i > 0 && j > 0;
-        while (__ballot(go) != 0ull) {
-            const int s0 = go ? ((i - 1) >> 5) : 0;           /* block of the current row; rows may cross into s0 - 1 */
-            const int jst = j;
-            uint2 A[BRX_LANE_TBC], Bv[BRX_LANE_TBC];
-#pragma unroll
-            for (int x = 0; x < BRX_LANE_TBC; ++x) {
-                const int col = jst - x;
-                A[x] = make_uint2(0u, 0u); Bv[x] = make_uint2(0u, 0u);
-                if (go && col >= 1) {
-                    A[x] = tbw[((uint64_t)col * BRX_LANE_W + (uint32_t)(s0 & (BRX_LANE_W - 1))) * 64u + (uint32_t)lane];
-                    if (s0 > 0) Bv[x] = tbw[((uint64_t)col * BRX_LANE_W + (uint32_t)((s0 - 1) & (BRX_LANE_W - 1))) * 64u + (uint32_t)lane];
-                }
-            }
-            bool walk = go;
-#pragma unroll
-            for (int x = 0; x < BRX_LANE_TBC; ++x) {
-                /* column jst - x (every completed column moves the lane exactly one column left) */
-                bool done = !(walk && i > 0 && j > 0);
-#pragma unroll
-                for (int part = 0; part < 2; ++part) {             /* at most two blocks per column per round */
-                    if (!done) {
-                        const int sb = (i - 1) >> 5;
-                        if (sb != s0 && sb != s0 - 1) { walk = false; done = true; }     /* left the two fetched blocks: refetch */
-                        else {
-                            const int jf = 32 * sb - g.dhi + 1 < 1 ? 1 : 32 * sb - g.dhi + 1;
-                            long long jl = 32ll * (sb + 1) - g.dlo; if (jl > T) jl = T;
-                            if (j < jf || j > jl) { ok = false; walk = false; go = false; done = true; }
-                            else {
-                                const bool top = sb == s0;
-                                const uint32_t vx = top ? A[x].x : Bv[x].x, vy = top ? A[x].y : Bv[x].y;
-                                const int bit = (i - 1) & 31;
-                                const uint32_t stay = ~vx & (0xFFFFFFFFu >> (31 - bit));   /* rows of the block, at or above this one, that do not move up */
-                                if (stay == 0u) {                  /* up all the way out of the block */
-                                    i -= bit + 1; ncols += (uint32_t)(bit + 1);
-                                    if (i == 0) done = true;
-                                } else {
-                                    const int row = 31 - __clz((int)stay);
-                                    i -= bit - row; ncols += (uint32_t)(bit - row);
-                                    if ((vy >> row) & 1u) { j -= 1; ncols += 1; }
-                                    else {
-                                        const int qi_ = i - 1, tj = j - 1;
-                                        const uint32_t qc = ((q_lo[qi_ >> 5][lane] >> (qi_ & 31)) & 1u) | (((q_hi[qi_ >> 5][lane] >> (qi_ & 31)) & 1u) << 1);
-                                        const uint32_t tc = ((t_lo[tj >> 5][lane] >> (tj & 31)) & 1u) | (((t_hi[tj >> 5][lane] >> (tj & 31)) & 1u) << 1);
-                                        nmatch += (uint32_t)(qc == tc);
-                                        i -= 1; j -= 1; ncols += 1;
-                                    }
-                                    done = true;
-                                }
-                            }
-                        }
-                    }
-                }
-                if (!done) walk = false;                           /* a third block in one column: next round */
-            }
-            go = go && ok && i > 0 && j > 0;
-        }
+        /* the window pair of every lane as bit planes: written by the parking wave behind the bytes of its slot */
+        const uint32_t *pl = reinterpret_cast<const uint32_t *>(winbuf + (uint64_t)r * BRX_WIN_STRIDE + BRX_WIN_PLANES);
+        uint32_t ncols = 0, nmatch = 0; bool ok = false;
+        brx_lanes_align<BRX_LANE_TMAX / 32>(valid, pl, Q, T, kb, tbw, &ncols, &nmatch, &ok);
         if (valid) {
-            ncols += (uint32_t)(i + j);
-            if (ok && (ncols - nmatch) > (uint32_t)kb) ok = false;
-            msv[r].res_ncols = ok ? ncols : 0u;
-            msv[r].res_nmatch = ok ? nmatch : 0u;
+            msv[r].res_ncols = ncols; msv[r].res_nmatch = nmatch;
             if (!ok) msv[r].status = ms.status | BRX_RS_BAND;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

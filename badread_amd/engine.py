@@ -222,11 +222,12 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.isfile(LIB_PATH):
-        raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m badread_amd.build` '
+    path = os.environ.get('BRX_LIB_PATH') or LIB_PATH         # BRX_LIB_PATH: another BUILD of the same library (A/B measurements), never a fallback
+    if not os.path.isfile(path):
+        raise RuntimeError(f'{path} is missing: build it with `python -m badread_amd.build` '
                            '(hipcc, --offload-arch=gfx950).  There is no CPU fallback.')
     import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime torch ships, not a second copy
-    _lib = bind_library(ctypes.CDLL(LIB_PATH))
+    _lib = bind_library(ctypes.CDLL(path))
     return _lib
 
 
@@ -283,8 +284,6 @@ def bind_library(lib):
     lib.brx_model_count.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(BrxModelJob), ctypes.c_void_p]
     lib.brx_last_mutate_passes.restype = ctypes.c_uint32
     lib.brx_last_mutate_passes.argtypes = [ctypes.c_void_p]
-    lib.brx_last_mutate_stats.restype = ctypes.c_int
-    lib.brx_last_mutate_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32 * 8)]
     lib.brx_last_final_launches.restype = ctypes.c_uint32
     lib.brx_last_final_launches.argtypes = [ctypes.c_void_p]
     lib.brx_last_window_misses.restype = ctypes.c_uint32
@@ -602,12 +601,6 @@ class HipEngine(EngineBase):
 
     def mutate_passes(self):
         return int(self.lib.brx_last_mutate_passes(self.ctx))
-
-    def mutate_stats(self):
-        """Scheduling counters of the persistent mutate stage of the last batch (include/brx.h: brx_last_mutate_stats)."""
-        arr = (ctypes.c_uint32 * 8)()
-        self._check(self.lib.brx_last_mutate_stats(self.ctx, ctypes.byref(arr)))
-        return dict(zip(('finished', 'lane_batches', 'lane_windows', 'inplace_windows', 'steals'), [int(v) for v in arr[:5]]))
 
     def final_launches(self):
         return int(self.lib.brx_last_final_launches(self.ctx))

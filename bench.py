@@ -56,6 +56,7 @@ for _p in (REPO, os.path.join(REPO, 'tools')):
 
 ALGO_BYTES_PER_BASE = 2.26          # 0.25 B packed reference read + 2 B FASTQ written + header share
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+SCRATCH_GB_DEFAULT = 42.0           # scratch arena per in-flight device batch (tests/test_gpu_fullsize.py runs the shipped geometry with it)
 VALU_PEAK_PER_S = 6.56e11           # wave64 32-bit integer VALU instructions/s, chip-wide, MEASURED (profiles/valu_rate.json, tools/native/valu_bench.hip):
                                     # 4 cycles per instruction per SIMD -- half of what the 2-cycle v_fma_f32 rate of MI355X_MICROARCH.md would give
 SEED = 42
@@ -255,7 +256,7 @@ def main():
     ap.add_argument('--workload', default='human', choices=sorted(WORKLOADS))
     ap.add_argument('--reads-per-step', type=int, default=294912,
                     help='read indices per GPU per step; split into --streams device batches')
-    ap.add_argument('--scratch-gb', type=float, default=42.0, help='scratch arena per in-flight batch')
+    ap.add_argument('--scratch-gb', type=float, default=SCRATCH_GB_DEFAULT, help='scratch arena per in-flight batch')
     ap.add_argument('--streams', type=int, default=6,
                     help='device batches in flight per GPU (one context + HIP stream + host thread each): the slowest '
                          'read of one device batch overlaps the bulk of the others')
@@ -346,7 +347,7 @@ def main():
         """The device batches of steps `step_indices`, C in flight: worker i owns context i / stream i and takes
         every C-th device batch; batch b of step k covers read indices ((k*C + b)*world + rank)*R ..."""
         indices = [k * C + b for k in step_indices for b in range(C)]
-        acc = [{'bases': 0, 'passes': 0, 'stages': {}, 'kernels': {}, 'final_launches': 0, 'misses': 0, 'bad': 0, 'host_ms': 0.0, 'error': None, 'mutate': {}} for _ in range(C)]
+        acc = [{'bases': 0, 'passes': 0, 'stages': {}, 'kernels': {}, 'final_launches': 0, 'misses': 0, 'bad': 0, 'host_ms': 0.0, 'error': None} for _ in range(C)]
 
         def worker(i):
             try:
@@ -370,8 +371,6 @@ def main():
                             k[0] += n_l; k[1] += ms; k[2] += b
                         acc[i]['final_launches'] += engines[i].final_launches()
                         acc[i]['misses'] += engines[i].window_misses()
-                        for name, v in engines[i].mutate_stats().items():
-                            acc[i]['mutate'][name] = acc[i]['mutate'].get(name, 0) + v
                     if not dry:
                         streams[i].synchronize()
             except BaseException as ex:          # surfaced on the main thread
@@ -470,7 +469,6 @@ def main():
                    'parallelism': f'reads sharded by index over {world} GPU(s), reference replicated per GPU, no collectives on the data path'},
         'reference_load': ref_timing,
         'reads_flagged_band_segs_qmiss': bad,
-        'mutate_stage_per_device_batch': {k: sum(a['mutate'].get(k, 0) for a in acc) / n_batches for k in ('finished', 'lane_batches', 'lane_windows', 'inplace_windows', 'steals')},
     }
     if dry:
         result['INVALID'] = 'dry run on the CPU checker engine (--cpu-engine): exercises launch / sharding / reporting only'

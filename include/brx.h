@@ -250,11 +250,6 @@ int brx_last_read_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
  * Zeros without BRX_PROFILE (the default kernels do not contain the clock reads). */
 int brx_last_phase_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
 uint32_t brx_last_mutate_passes(const brx_ctx *ctx);
-/* Counters of the persistent mutate stage (k_mutate_persist) of the last call:
- *   [0] reads that left the stage  [1] lane batches (waves that aligned parked windows, one window per lane)
- *   [2] windows aligned that way   [3] windows aligned in place by a whole wave  [4] work items taken from the queue set
- *   of another XCD  [5..7] reserved.  Scheduling only: results never depend on these. */
-int brx_last_mutate_stats(const brx_ctx *ctx, uint32_t out[8]);
 /* Per-kernel launch timing, opt-in (brx_set_kernel_timing(ctx, 1); bench.py and the profiling tools use it): every
  * launch of the kernels below is bracketed by two HIP events ON THE STREAM THE KERNEL IS LAUNCHED ON, and
  * brx_last_kernel_stats() returns, for the last brx_simulate_batch / brx_sequence_fragments call, the number of

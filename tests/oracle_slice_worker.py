@@ -15,7 +15,7 @@ for p in (REPO, os.path.join(REPO, 'oracle'), os.path.join(REPO, 'tools')):
         sys.path.insert(0, p)
 
 if __name__ == '__main__':
-    workload, ref_dir, seed, first, count, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    workload, ref_dir, seed, first, count, out = sys.argv[1], (None if sys.argv[2] == '-' else sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
     import bench
     import pyoracle
     eng = bench.configure(pyoracle.OracleEngine(), bench.build_workload(io.StringIO(), workload, ref_dir))

@@ -90,3 +90,31 @@ def test_gpu_streams_and_batch_size_do_not_change_the_output():
     for extra in (('--gpu-streams', '3', '--gpu-batch', '16'), ('--gpu-streams', '5', '--gpu-batch', '64')):
         out, _ = run_cli(*extra)
         assert out == base, extra
+
+
+def test_two_ranks_on_one_gpu_give_the_single_rank_bytes(tmp_path):
+    """SURVEY.md 8e on the real engine: the CLI under torch.distributed.run with world size 2 -- both ranks on device 0
+    (BRX_DEVICE), the 4 B/read exchange and the records to rank 0 over gloo (BRX_DIST_BACKEND: a 1-GPU box cannot run
+    RCCL between two ranks of one device) -- writes the bytes of the single-process run.  Exercises run_batches, the
+    sharded stop rule and collect_bytes with the HIP engine and device tensors on the sending side."""
+    import socket
+    single, _ = run_cli('--quantity', '40x')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    out_path = tmp_path / 'ranks.fastq'
+    script = tmp_path / 'rank.py'
+    script.write_text(
+        'import os, sys\n'
+        f'sys.path.insert(0, {REPO!r})\n'
+        'from badread_amd.__main__ import main\n'
+        f'sys.argv = ["badread", "simulate", "--reference", {SMALL_REF!r}, "--quantity", "40x", "--length", "400,300", "--seed", "11"]\n'
+        'if int(os.environ.get("RANK", "0")) == 0:\n'
+        f'    sys.stdout = open({str(out_path)!r}, "w")\n'
+        'main()\n'
+        'sys.stdout.flush()\n')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), BRX_DIST_BACKEND='gloo', BRX_DEVICE='0')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), str(script)], cwd=REPO, env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert open(out_path, 'rb').read() == single

@@ -1,6 +1,6 @@
 """
 BASELINE.json configs[1] at full batch size on the GPU (16384 reads of ~15 kb from the 5.5 Mb reference of bench.py),
-checked through properties that do not need the oracle at that size, plus oracle spot checks:
+checked through properties that do not need the oracle at that size, and against the oracle:
 
   * batch-split invariance: one 16384-read call == two 8192-read calls, byte for byte;
   * the windowed traceback store is invisible: the first 2048 reads with BRX_TB_WINDOW=0 (full store) and with the
@@ -9,7 +9,11 @@ checked through properties that do not need the oracle at that size, plus oracle
     error-free_length= and read_identity= fields equal the statistics (identity = n_match / n_cols to 3 decimals),
     qualities inside the model's range, no status bits other than EMPTY;
   * alignment sanity per read: n_cols >= max(fragment, read) length, distance <= number of changes applied x 58;
-  * 24 reads spread over the batch and the longest read: the oracle reproduces their records exactly.
+  * ALL 16384 reads: the oracle (one process per host core) reproduces every record and every statistic.
+
+configs[3] and configs[4] (the 3.09 Gb reference) run at the SHIPPED launch geometry -- the bench's and the CLI's device batch
+of 49152 reads with the bench's scratch arena and the default environment -- and every read of that batch is compared with
+the oracle.
 """
 import io
 import re
@@ -22,8 +26,44 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 N = 16384
+SHIPPED_BATCH = 49152          # bench.py / CLI device batch (--reads-per-step 294912 as --streams 6)
 SEED = 42
 HEADER = re.compile(rb'length=(\d+) error-free_length=(\d+) read_identity=([0-9.]+)%$')
+
+
+def compare_with_oracle_slices(wlname, ref_dir, n, st, raw, tmp_path, fields):
+    """Every read of [0, n): one oracle process per usable host core on disjoint slices; FASTQ bytes and statistics."""
+    import os
+    import subprocess
+    import sys
+    import bench
+    cores = max(1, min(bench.usable_cores(), 32))
+    per = -(-n // cores)
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='')
+    procs = []
+    for i in range(cores):
+        first, count = i * per, max(0, min(per, n - i * per))
+        if count == 0:
+            continue
+        path = str(tmp_path / f'slice{i}.npz')
+        procs.append((first, count, path, subprocess.Popen([sys.executable, os.path.join(here, 'oracle_slice_worker.py'), wlname, ref_dir or '-',
+                                                            str(SEED), str(first), str(count), path], env=env,
+                                                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
+    for first, count, path, pr in procs:
+        _, err = pr.communicate(timeout=1500)
+        assert pr.returncode == 0, err.decode()[-2000:]
+        z = np.load(path)
+        so = z['stats']
+        lo = int(st['rec_off'][first])
+        hi = int(st['rec_off'][first + count - 1] + st['rec_len'][first + count - 1])
+        assert z['data'].tobytes() == raw[lo:hi], f'{wlname}: reads {first}..{first + count - 1} differ from the oracle'
+        for f in fields:
+            assert (so[f] == st[f][first:first + count]).all(), (wlname, f, first)
+
+
+ALL_FIELDS = ('status', 'frag_len', 'seq_len', 'n_cols', 'n_match', 'padded_len', 'loop_count', 'change_count', 'n_alignments',
+              'rec_len', 'target_identity', 'qerr_sum')
 
 
 @pytest.fixture(scope='module')
@@ -32,7 +72,7 @@ def workload():
     return bench, bench.build_workload(io.StringIO())
 
 
-def test_configs1_full_batch_properties(workload, monkeypatch):
+def test_configs1_full_batch_properties(workload, monkeypatch, tmp_path):
     from badread_amd.engine import HipEngine, RS_EMPTY
     bench, wl = workload
     eng = bench.configure(HipEngine(0, scratch_bytes=30 << 30), wl)
@@ -79,14 +119,8 @@ def test_configs1_full_batch_properties(workload, monkeypatch):
     ident = st['n_match'][live] / st['n_cols'][live]
     assert 0.93 < float(np.mean(ident)) < 0.97 and float(ident.max()) <= 1.0
 
-    # ---- oracle spot checks
-    orc = bench.configure(H.oracle_engine(), wl)
-    picks = list(range(0, N, N // 24))[:24] + [int(np.argmax(st['seq_len']))]
-    for r in picks:
-        o, so = orc.simulate_batch(SEED, r, 1)
-        mine = raw[int(st['rec_off'][r]): int(st['rec_off'][r]) + int(st['rec_len'][r])]
-        assert bytes(o) == mine, f'read {r} differs from the oracle'
-        assert int(so['n_cols'][0]) == int(st['n_cols'][r]) and int(so['n_match'][0]) == int(st['n_match'][r])
+    # ---- every read against the oracle
+    compare_with_oracle_slices('kpn', None, N, st, raw, tmp_path, ALL_FIELDS)
     eng.close()
 
     # ---- the traceback window does not show in the output
@@ -103,9 +137,9 @@ def test_configs1_full_batch_properties(workload, monkeypatch):
 @pytest.mark.parametrize('wlname', ['human', 'hifi'])
 def test_configs3_and_4_every_read_of_a_full_batch_equals_the_oracle(wlname, tmp_path):
     """BASELINE.json configs[3] (GRCh38-like 3.09 Gb, nanopore2023) and configs[4] (pacbio2021, --identity 30,3) at the
-    bench's batch size: ALL 16384 reads of the first device batch, HIP path vs the CPU oracle (one oracle process per
-    usable host core on disjoint slices of the batch), FASTQ bytes and every per-read statistic.  The batch is known
-    (oracle plan probes, read indices 0..16383 under seed 42) to hold reads that overlap N runs -- whose windows carry
+    SHIPPED launch geometry (49152 reads per device batch, the bench's scratch arena, default environment): ALL reads of the
+    first device batch, HIP path vs the CPU oracle (one oracle process per usable host core on disjoint slices of the batch),
+    FASTQ bytes and every per-read statistic.  The batch is known (oracle plan probes under seed 42) to hold reads that overlap N runs -- whose windows carry
     non-ACGT symbols and saturated edit bounds -- and reads clipped at the end of a linear contig
     (simulate.py:231-246); both are asserted from the GPU's own output."""
     import os
@@ -119,37 +153,16 @@ def test_configs3_and_4_every_read_of_a_full_batch_equals_the_oracle(wlname, tmp
     pref = wl[0]
     assert pref.n_bases == 3088269832 and len(pref.names) == 24
     assert len(pref.exceptions) == 25 + 3        # the end run of one contig and the start run of the next are one run in packed coordinates
-    eng = bench.configure(HipEngine(0, scratch_bytes=34 << 30), wl)
-    out, st = eng.simulate_batch(SEED, 0, N)
+    n = SHIPPED_BATCH
+    scratch_gb = bench.SCRATCH_GB_DEFAULT
+    eng = bench.configure(HipEngine(0, scratch_bytes=int(scratch_gb * (1 << 30))), wl)
+    out, st = eng.simulate_batch(SEED, 0, n)
     out, st = out.copy(), st.copy()
+    assert getattr(eng, 'retries', 0) == 0, 'the shipped arena must hold a shipped batch without a retry'
     eng.close()
     assert (st['status'] & ~np.uint32(RS_EMPTY) == 0).all()
-
-    cores = max(1, min(bench.usable_cores(), 32))
-    per = -(-N // cores)
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='')
-    procs = []
-    for i in range(cores):
-        first, count = i * per, max(0, min(per, N - i * per))
-        if count == 0:
-            continue
-        path = str(tmp_path / f'slice{i}.npz')
-        procs.append((first, count, path, subprocess.Popen([sys.executable, os.path.join(here, 'oracle_slice_worker.py'), wlname, ref_dir,
-                                                            str(SEED), str(first), str(count), path], env=env,
-                                                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
     raw = out.tobytes()
-    for first, count, path, pr in procs:
-        _, err = pr.communicate(timeout=900)
-        assert pr.returncode == 0, err.decode()[-2000:]
-        z = np.load(path)
-        so = z['stats']
-        lo = int(st['rec_off'][first])
-        hi = int(st['rec_off'][first + count - 1] + st['rec_len'][first + count - 1])
-        assert z['data'].tobytes() == raw[lo:hi], f'{wlname}: reads {first}..{first + count - 1} differ from the oracle'
-        for f in ('status', 'frag_len', 'seq_len', 'n_cols', 'n_match', 'padded_len', 'loop_count', 'change_count', 'n_alignments',
-                  'rec_len', 'target_identity', 'qerr_sum'):
-            assert (so[f] == st[f][first:first + count]).all(), (wlname, f, first)
+    compare_with_oracle_slices(wlname, ref_dir, n, st, raw, tmp_path, ALL_FIELDS)
 
     # the batch really exercises the non-ACGT path and the clipping of linear contigs
     lengths = dict(synth_refs.GRCH38_LENGTHS)
