@@ -70,7 +70,7 @@ SIMULATE_OPTIONS = [
     ]),
     ('MI355X', 'Device options (additive; no effect on the simulated reads)', [
         ('--gpu-batch', dict(type=int, default=None, dest='gpu_batch',
-                             help='Maximum reads per device batch and GPU (default: 49152)')),
+                             help='Maximum reads per device batch and GPU (default: 65536)')),
         ('--gzip', dict(type=int, default=None, dest='gzip_level', metavar='LEVEL',
                         help='Write gzip-compressed FASTQ to stdout, compressed on all host cores (level 0-9); '
                              'default: plain text, as the reference')),

@@ -25,6 +25,21 @@ def hipcc():
     return 'hipcc'
 
 
+def source_hash():
+    """First 16 hex digits of the SHA-256 over the kernel sources (csrc/*.h, *.hip, include/*.h): measurements that depend on
+    the kernels (profiles/valu_per_base.json) record it, and bench.py flags them as stale when the tree has moved on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
+    inc = os.path.join(HERE, '..', 'include')
+    files += sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith('.h'))
+    for path in files:
+        h.update(os.path.basename(path).encode() + b'\0')
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

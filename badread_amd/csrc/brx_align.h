@@ -50,6 +50,9 @@
              __hip_atomic_store((prog) + 8 * blockIdx.x + (slot), (uint32_t)(val), __ATOMIC_RELAXED,  \
                                 __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
 
+#ifndef BRX_K1
+#define BRX_K1 8       /* columns per loop trip of the one-word-per-lane forward pass (4 or 8; 8 measured faster) */
+#endif
 struct BrxGeom {
     int Q, T;          /* query rows, target columns                              */
     int dlo, dhi;      /* band of diagonals i-j                                   */
@@ -57,8 +60,8 @@ struct BrxGeom {
     int NS, NW;        /* superblocks, 32-row words                               */
     int WSp;           /* band slots per time step in the traceback store         */
     int K;             /* time skew between neighbouring superblocks: superblock s handles column j at
-                          time j + K*s.  K = 4 for G = 1 (four columns per loop trip), else 1            */
-    int t_end;         /* last traceback row = T (K = 4: rounded up to a multiple of 4) + K*(NS - 1) */
+                          time j + K*s.  K = BRX_K1 for G = 1 (that many columns per loop trip), else 1     */
+    int t_end;         /* last traceback row = T (G = 1: rounded up to a multiple of K) + K*(NS - 1) */
     int H;             /* windowed traceback store: only superblocks within H rows of the straight line
                           row = column * Q / T are written (BRX_H_ALL: every superblock of the band)    */
     uint32_t slope;    /* Q / T with 20 fractional bits (0 when the store is not windowed)               */
@@ -104,8 +107,8 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul =
     g.WSp = (bw + g.R - 2) / (g.R + 1) + 2;
     if (g.WSp > g.NS) g.WSp = g.NS;
     if (g.WSp < 1) g.WSp = 1;
-    g.K = G == 1 ? 4 : 1;
-    g.t_end = (G == 1 ? (T + 3) / 4 * 4 : T) + g.K * (g.NS - 1);   /* K = 4: whole trips, the last one may run past column T */
+    g.K = G == 1 ? BRX_K1 : 1;
+    g.t_end = (T + g.K - 1) / g.K * g.K + g.K * (g.NS - 1);        /* whole trips: the last one may run past column T */
     g.H = BRX_H_ALL; g.slope = 0;
     if (hmul != 0 && G <= 16 && T > 0 && (uint64_t)Q < ((uint64_t)T << 11)) {
         const int H = hmul > 0 ? hmul * (int)brx_isqrt((uint32_t)k) + 24 : 8;
@@ -116,7 +119,7 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul =
 }
 
 /* Is superblock s written for the column group represented by column jrep?  (jrep = the column itself when
- * K = 1; the third column of the four-column trip when K = 4: brx_jrep.)  For a fixed store row the rows
+ * K = 1; the column in the middle of its trip otherwise: brx_jrep.)  For a fixed store row the rows
  * R*s - c(jrep) grow by at least R per superblock, so at most (2H + R - 1)/R + 1 consecutive superblocks
  * pass -- they land in distinct slots s % WSp. */
 __host__ __device__ __forceinline__ bool brx_stored(const BrxGeom &g, int s, int jrep) {
@@ -124,7 +127,7 @@ __host__ __device__ __forceinline__ bool brx_stored(const BrxGeom &g, int s, int
     const int a = g.R * s + g.H + g.R - 1 - c;
     return (uint32_t)a <= (uint32_t)(2 * g.H + g.R - 1);
 }
-__host__ __device__ __forceinline__ int brx_jrep(const BrxGeom &g, int j) { return g.K == 4 ? (((j - 1) & ~3) + 2) : j; }
+__host__ __device__ __forceinline__ int brx_jrep(const BrxGeom &g, int j) { return g.K > 1 ? (((j - 1) & ~(g.K - 1)) + g.K / 2) : j; }
 
 /* 8-byte units of traceback storage an alignment needs */
 __host__ __device__ inline uint64_t brx_tb_units(const BrxGeom &g) {
@@ -181,7 +184,7 @@ __device__ __forceinline__ int brx_from_lane_above(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
 }
 
-#define BRX_RING_BYTES 1024         /* per-wave LDS window of target bytes (four 256-byte chunks)  */
+#define BRX_RING_BYTES 2048         /* per-wave LDS window of target bytes (eight 256-byte chunks; the one-column-per-trip passes use two) */
 /* One wave per workgroup, so one window per workgroup.  File scope keeps the LDS address space
  * visible to the compiler (ds_read_u8 / ds_write_b32); a generic or volatile pointer to it turns
  * every access into a flat load that waits on vmcnt -- exactly what the window is there to avoid. */
@@ -544,15 +547,18 @@ __device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32
 }
 
 /* ---------------------------------------------------------------------------------------------
- * forward pass for G = 1, FOUR columns per loop trip (g.K = 4): superblock s handles columns
- * 4(tau - s) + 1 .. 4(tau - s) + 4 in trip tau, so the lane above has finished exactly these four
- * columns one trip earlier and hands its four carries over in one DPP word.  The loop bookkeeping
- * (time tests, ring refill, lane hops, pointer arithmetic: ~40 of the ~85 instructions of a
- * one-column trip) is paid once per four columns.  Traceback row of column j of superblock s is
- * j + 4s = 4 tau + c + 1: the same for every lane of a trip, so the stores stay slot-contiguous.
+ * forward pass for G = 1, K = g.K columns per loop trip (K = 4 or 8): superblock s handles columns
+ * K (tau - s) + 1 .. K (tau - s) + K in trip tau, so the lane above has finished exactly these K
+ * columns one trip earlier and hands its K carries over in one DPP word.  The loop bookkeeping
+ * (time tests, ring refill, lane hops, pointer arithmetic, activity and window tests: ~32 vector and as
+ * many scalar instructions) is paid once per K columns of ~19 vector instructions each: 27 per column at
+ * K = 4 (round 2), 23 at K = 8.  Traceback row of column j of superblock s is j + K s = K tau + c + 1:
+ * the same for every lane of a trip, so the stores stay slot-contiguous.
  * ------------------------------------------------------------------------------------------- */
-__device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
+template <int K>
+__device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                             const BrxGeom g, uint2 *__restrict__ tb) {
+    static_assert(K == 4 || K == 8, "four or eight columns per trip");
     const int lane = threadIdx.x & 63;
     uint32_t *const ring32 = brx_ring32;
     /* the store base is the same in every lane: say so (and that it is global memory), and the traceback stores take the
@@ -560,9 +566,8 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
     const uint64_t tb_addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)tb >> 32)) << 32) |
                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)tb);
     constexpr int NEVER = 0x7FFFFFFF;
-    constexpr int K = 4;
     /* A superblock works in WHOLE trips: trips tf .. tl, i.e. columns 4 (tf - s) + 1 .. 4 (tl - s) + 4 -- its band window
-       [jf, jl] widened to trip boundaries (up to three columns on either side, the last trip possibly past column T: those
+       [jf, jl] widened to trip boundaries (up to K - 1 columns on either side, the last trip possibly past column T: those
        bytes are padding and nothing reads their cells).  Computing more than the Ukkonen band is harmless (cells outside it
        are upper bounds either way, cells inside are exact), and one activity test, one store predicate and one select of
        the running Pv / Mv per trip replace four of each. */
@@ -571,7 +576,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
     int tf = NEVER, tl = NEVER;                     /* first / last loop trip of the lane's superblock: trip tau is computed
                                                        iff (uint32_t)(tau - tf) <= tspan                                  */
     uint32_t tspan = 0;
-    /* windowed traceback store (brx_stored), incrementally: acc = slope * (third column of the trip), exact in 64 bits;
+    /* windowed traceback store (brx_stored), incrementally: acc = slope * (middle column of the trip: brx_jrep), exact in 64 bits;
        superblock s is written iff (uint32_t)(keep_base - (acc >> 20)) <= keep_lim */
     const uint32_t keep_lim = (uint32_t)(2 * g.H + g.R - 1);
     int keep_base = 0;
@@ -586,12 +591,13 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
             if (jl >= jf) { tf = s + (jf - 1) / K; tspan = (uint32_t)(tl - tf); }   /* empty window: never active, but it still hops at tl */
         }
         keep_base = g.R * s + g.H + g.R - 1;
-        acc = (int64_t)(K * (tau_now - s) + 2) * (int64_t)g.slope;
+        acc = (int64_t)(K * (tau_now - s) + K / 2) * (int64_t)g.slope;
     };
     window(0);
     uint32_t Pv = 0xFFFFFFFFu, Mv = 0;
     BrxQPlanes qp = {0u, 0u, 0u, 0u};
-    uint32_t carry = 0xF0u;                         /* bits 7..4: hout of columns 0..3 is +1; bits 3..0: it is -1.  An idle lane
+    constexpr uint32_t IDLE = ((1u << K) - 1u) << K;
+    uint32_t carry = IDLE;                          /* bits 2K-1..K: hout of columns 0..K-1 is +1; bits K-1..0: it is -1.  An idle lane
                                                        hands on +1 (the cells above the band grow by one per column) */
 
     auto fetch_chunk = [&](int c) -> uint32_t {
@@ -607,9 +613,9 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
     };
     uint32_t odd = 0, pending = 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {                   /* chunks 0..2; chunk c lives in ring quarter c & 3 */
+    for (int c = 0; c < 3; ++c) {                   /* chunks 0..2; chunk c lives in ring slot c & 7 */
         pending = fetch_chunk(c);
-        ring32[(c & 3) * 64 + lane] = pending;
+        ring32[(c & 7) * 64 + lane] = pending;
         odd |= chunk_odd(c, pending) << c;
     }
     int s_top = 0;                                  /* first superblock still inside the band (uniform) */
@@ -619,23 +625,27 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
     const size_t wsp = (size_t)g.WSp;
     /* traceback rows 4 tau + 1 .. 4 tau + 4 (uniform addresses); a lane writes at byte slot8 of each */
     BRX_GLOBAL char *row0 = (BRX_GLOBAL char *)((BRX_GLOBAL uint64_t *)tb_addr + wsp);
-    BRX_GLOBAL char *row1 = row0 + 8 * wsp, *row2 = row0 + 16 * wsp, *row3 = row0 + 24 * wsp;
+    const size_t row_bytes = 8 * wsp;
     const size_t trip_bytes = 8 * (size_t)K * wsp;
-    uint32_t wnext = ring32[((uint32_t)(K * (0 - s)) >> 2) & (BRX_RING_BYTES / 4 - 1)];
-    for (int tau = 0; tau <= tau_end; ++tau, row0 += trip_bytes, row1 += trip_bytes, row2 += trip_bytes, row3 += trip_bytes, acc += acc_step) {
+    constexpr int KW = K / 4;                        /* ring words per trip */
+    uint32_t wnext[KW];
+#pragma unroll
+    for (int x = 0; x < KW; ++x) wnext[x] = ring32[(((uint32_t)(K * (0 - s)) >> 2) + (uint32_t)x) & (BRX_RING_BYTES / 4 - 1)];
+    for (int tau = 0; tau <= tau_end; ++tau, row0 += trip_bytes, acc += acc_step) {
         /* ---- refill of the target window, keyed on the newest byte in use (scalar code) ---- */
         while (__builtin_expect(s_top < g.NS - 1 && tau > tl_top, 0)) { s_top += 1; tl_top = s_top + (brx_jlast(g, s_top) - 1) / K; }
-        const int fq = (tau - s_top);               /* newest column group in use: bytes 4 fq .. 4 fq + 3 */
-        if (__builtin_expect((fq & 15) == 0 && fq > 0, 0)) {
-            /* The band spans fewer than 62 superblocks, so the oldest byte still read is 4 (fq - 61):
-               when the front enters chunk m (fq = 64 m) chunk m - 2 is dead and chunk m + 2 takes its
-               quarter of the ring; its load was issued a quarter chunk earlier. */
-            const int ph = (fq >> 4) & 3;
-            if (ph == 3) pending = fetch_chunk((fq >> 6) + 3);
+        const int fq = (tau - s_top);               /* newest column group in use: bytes K fq .. K fq + K - 1 */
+        if (__builtin_expect((fq & (64 / K - 1)) == 0 && fq > 0, 0)) {
+            /* The band spans fewer than 62 superblocks, so the oldest byte still read is K (fq - 61), at most 488 bytes
+               behind the front: when the front enters chunk m, chunks m - 2 .. m + 1 are live or about to be and chunk
+               m + 2 takes the slot of the long dead chunk m - 6; its load was issued a quarter chunk earlier. */
+            const int fb = K * fq;                  /* front byte: a multiple of 64 here */
+            const int ph = (fb >> 6) & 3;
+            if (ph == 3) pending = fetch_chunk((fb >> 8) + 3);
             else if (ph == 0) {
-                const int c = (fq >> 6) + 2;
-                ring32[(c & 3) * 64 + lane] = pending;
-                odd = (odd & ~(1u << (c & 3))) | (chunk_odd(c, pending) << (c & 3));
+                const int c = (fb >> 8) + 2;
+                ring32[(c & 7) * 64 + lane] = pending;
+                odd = (odd & ~(1u << (c & 7))) | (chunk_odd(c, pending) << (c & 7));
             }
         }
 
@@ -648,26 +658,28 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
             next_entry = brx_wave_min(tf > tau ? tf : NEVER);
         }
 
-        /* ---- four column updates, straight-line ---- */
+        /* ---- K column updates, straight-line ---- */
         const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
-        const uint32_t w = wnext;
+        uint32_t w[KW];
+#pragma unroll
+        for (int x = 0; x < KW; ++x) w[x] = wnext[x];
         const bool act = (uint32_t)(tau - tf) <= tspan;
         const bool keep = (uint32_t)(keep_base - (int)(uint32_t)((uint64_t)acc >> 20)) <= keep_lim;   /* one test per trip */
         bool rare = false;
         if (__builtin_expect(odd != 0u, 0)) {
             bool lr = false;
 #pragma unroll
-            for (int c = 0; c < K; ++c) lr |= ((w >> (8 * c)) & 0xFFu) > 3u;
+            for (int c = 0; c < K; ++c) lr |= ((w[c >> 2] >> (8 * (c & 3))) & 0xFFu) > 3u;
             rare = __ballot(lr && act) != 0ull;
         }
         uint32_t P = Pv, M = Mv, accP = 0, accM = 0;
         uint32_t pvs[K], phs[K];
         /* one column.  ANY = the trip holds an N or an IUPAC symbol in some active lane (out-of-line masks) */
         auto column = [&](const int c, auto any_tag) {
-            const uint32_t hm = (nb >> (3 - c)) & 1u, hp = (nb >> (7 - c)) & 1u;
+            const uint32_t hm = (nb >> (K - 1 - c)) & 1u, hp = (nb >> (2 * K - 1 - c)) & 1u;
             uint32_t Eq;
             if constexpr (decltype(any_tag)::value) {
-                const uint32_t ch = (w >> (8 * c)) & 0xFFu;
+                const uint32_t ch = (w[c >> 2] >> (8 * (c & 3))) & 0xFFu;
                 Eq = brx_eq_acgt(qp, 0u - (ch & 1u), 0u - ((ch >> 1) & 1u));
                 if (ch == 4u) Eq = qp.n;
                 if (act && ch > 4u) {                              /* inline, rolled: a call would impose the callee's registers */
@@ -677,7 +689,7 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
                     Eq = mq;
                 }
             } else {
-                Eq = brx_eq_acgt(qp, brx_bit_mask(w, 8 * c), brx_bit_mask(w, 8 * c + 1));
+                Eq = brx_eq_acgt(qp, brx_bit_mask(w[c >> 2], 8 * (c & 3)), brx_bit_mask(w[c >> 2], 8 * (c & 3) + 1));
             }
             const uint32_t Xv = Eq | M;
             const uint32_t Eq2 = Eq | hm;
@@ -696,8 +708,8 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
             /* rolled: the loop index is a run-time value, so the bit positions are computed */
 #pragma unroll 1
             for (int c = 0; c < K; ++c) {
-                const uint32_t hm = (nb >> (3 - c)) & 1u, hp = (nb >> (7 - c)) & 1u;
-                const uint32_t ch = (w >> (8 * c)) & 0xFFu;
+                const uint32_t hm = (nb >> (K - 1 - c)) & 1u, hp = (nb >> (2 * K - 1 - c)) & 1u;
+                const uint32_t ch = ((c < 4 ? w[0] : w[KW - 1]) >> (8 * (c & 3))) & 0xFFu;
                 uint32_t Eq = brx_eq_acgt(qp, 0u - (ch & 1u), 0u - ((ch >> 1) & 1u));
                 if (ch == 4u) Eq = qp.n;
                 if (act && ch > 4u) {
@@ -715,22 +727,21 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
                 const uint32_t MhS = (Mh << 1) | hm;
                 P = MhS | ~(Xv | PhS);
                 M = PhS & Xv;
-                if (act && keep) *(BRX_GLOBAL uint64_t *)(row0 + 8 * (size_t)c * wsp + slot8) = ((uint64_t)Ph << 32) | (uint64_t)P;
+                if (act && keep) *(BRX_GLOBAL uint64_t *)(row0 + (size_t)c * row_bytes + slot8) = ((uint64_t)Ph << 32) | (uint64_t)P;
                 accP = (accP << 1) | (Ph >> 31);
                 accM = (accM << 1) | (Mh >> 31);
             }
         } else {
             column(0, std::false_type{}); column(1, std::false_type{}); column(2, std::false_type{}); column(3, std::false_type{});
-            if (act && keep) {                                     /* uint2 {pv, Ph} per column */
-                *(BRX_GLOBAL uint64_t *)(row0 + slot8) = ((uint64_t)phs[0] << 32) | (uint64_t)pvs[0];
-                *(BRX_GLOBAL uint64_t *)(row1 + slot8) = ((uint64_t)phs[1] << 32) | (uint64_t)pvs[1];
-                *(BRX_GLOBAL uint64_t *)(row2 + slot8) = ((uint64_t)phs[2] << 32) | (uint64_t)pvs[2];
-                *(BRX_GLOBAL uint64_t *)(row3 + slot8) = ((uint64_t)phs[3] << 32) | (uint64_t)pvs[3];
+            if constexpr (K == 8) { column(4, std::false_type{}); column(5, std::false_type{}); column(6, std::false_type{}); column(7, std::false_type{}); }
+            if (act && keep) {                                     /* uint2 {pv, Ph} per column: K stores with scalar row bases */
+#pragma unroll
+                for (int c = 0; c < K; ++c) *(BRX_GLOBAL uint64_t *)(row0 + (size_t)c * row_bytes + slot8) = ((uint64_t)phs[c] << 32) | (uint64_t)pvs[c];
             }
         }
         Pv = act ? P : Pv;
         Mv = act ? M : Mv;
-        carry = act ? ((accP << 4) | accM) : 0xF0u;
+        carry = act ? ((accP << K) | accM) : IDLE;
 
         /* ---- a superblock leaves the band: its lane takes superblock s + 64 ---- */
         if (__builtin_expect(tau == next_hop, 0)) {
@@ -738,7 +749,8 @@ __device__ inline void brx_align_forward_k4(const uint8_t *__restrict__ Qs, cons
             next_hop = brx_wave_min(tl);
             next_entry = brx_wave_min(tf > tau ? tf : NEVER);
         }
-        wnext = ring32[((uint32_t)(K * (tau + 1 - s)) >> 2) & (BRX_RING_BYTES / 4 - 1)];   /* bytes of the next trip */
+#pragma unroll
+        for (int x = 0; x < KW; ++x) wnext[x] = ring32[(((uint32_t)(K * (tau + 1 - s)) >> 2) + (uint32_t)x) & (BRX_RING_BYTES / 4 - 1)];   /* bytes of the next trip */
     }
 }
 
@@ -758,7 +770,7 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
         brx_align_forward_wide(Qs, Ts, g, tb, peq, st);
         return;
     }
-    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_k4(Qs, Ts, g, tb); return; } }
+    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_kn<BRX_K1>(Qs, Ts, g, tb); return; } }
     if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, prog); return; } }
     if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, prog); return; } }
     if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, prog); return; } }

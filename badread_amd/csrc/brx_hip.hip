@@ -45,6 +45,7 @@ struct brx_ctx {
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
+    uint32_t lane_waves;         /* BRX_LANE_WAVES: most waves of one k_win_lane launch */
     uint32_t fin_head_reads;     /* BRX_FIN_HEAD_READS: the longest reads of a batch form the head set of the final stage (side streams) */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
     int wide_stream;             /* BRX_WIDE_STREAM: the head set's widest band class aligns on a third stream */
@@ -169,6 +170,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 0xFFFFFFFFu; }   /* unset: a twelfth of the batch, at least 1024 */
     { const char *sw = getenv("BRX_SEG_WAVES_PER_CU"); c->seg_waves_per_cu = sw && atoi(sw) > 0 ? (uint32_t)atoi(sw) : 8u; }
     { const char *lt = getenv("BRX_LANE_THRESHOLD"); c->lane_threshold = lt ? (uint32_t)atoi(lt) : 3000u; }
+    { const char *v = getenv("BRX_LANE_WAVES"); c->lane_waves = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 512u; }
     c->err[0] = 0;
     *out = c;
     return BRX_OK;
@@ -369,7 +371,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint8_t *Fbuf = (uint8_t *)A.take((size_t)f_bytes + 64);
     uint32_t *repl = (uint32_t *)A.take(((size_t)f_bytes + 64) * 4);
     const uint32_t side_waves = std::min<uint32_t>(n_reads, 4096u);                 /* wave-level window aligner / legacy */
-    const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, 512u);      /* lane-level window aligner          */
+    const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, c->lane_waves);   /* lane-level window aligner: one 6.4 MB store of move codes per wave */
     uint8_t *win = (uint8_t *)A.take((size_t)(side_waves + 1) * c->win_bytes);      /* one slot per wave */
     MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
     uint32_t *mctr = (uint32_t *)A.take(8 * MC_WORDS * sizeof(uint32_t));   /* pass counters 0/1, 2 first bulk input, 3 bulk legacy, 4 head input, 5 head legacy, 6 head pass */

@@ -806,8 +806,11 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
    (brx_hip.hip, launch_final_phase): low half = list position, high half = waves that have started.  A wave's first pop adds
    to both halves at once -- its ticket t is then at most the position it popped -- and slab t (slabs[t] .. slabs[t + 1], in
    8-byte units from slab_base) holds the traceback store of every read the wave will ever pop. */
+#ifndef BRX_FIN4_WAVES
+#define BRX_FIN4_WAVES 4         /* waves per SIMD the four-word class is compiled for (4: 128 VGPRs and 8 spilled words; 3: 147 VGPRs) */
+#endif
 template <int MAXG, int GLO, int GHI>
-__global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *list, uint32_t n_list,
+__global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : MAXG == 2 ? 4 : MAXG == 4 ? BRX_FIN4_WAVES : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *list, uint32_t n_list,
                                                    unsigned long long *ctr, const uint64_t *slabs, uint32_t *retries, int phase, const uint8_t *Fbuf,
                                                    uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *slab_base, uint64_t *clk) {
     const int lane = lane_id();

@@ -39,7 +39,7 @@ from .version import __version__
 NOFRAG_MESSAGE = ('Error: failed to generate any sequence fragments - are your read lengths '
                   'incompatible with your reference contig lengths?')
 ADJUST_SAMPLES = 100000
-DEFAULT_MAX_BATCH = 49152
+DEFAULT_MAX_BATCH = 65536
 DEFAULT_IN_FLIGHT = 6          # super-batches in flight per GPU (--gpu-streams): what bench.py measures
 
 

@@ -19,10 +19,10 @@ are loaded through the native packer brx_fasta_pack + its sidecar, like a user's
   kpn    configs[1]: 5.5 Mb K. pneumoniae-like reference (3 circular contigs, numpy default_rng(1)), defaults (round 1's line)
 
 A "step" is ONE pass of the whole hot path (plan -> fragments -> mutate -> align -> qscores -> FASTQ bytes) over
-one batch of `--reads-per-step` read indices per GPU (default 294912 reads x 15 kb ~ 4.4 Gbases; the 30x job is 21 such
-steps on one GPU).  The batch goes through the C-ABI as `--streams` device batches (brx_simulate_batch, 6 x 49152
-reads by default: measured best on the MI355X among 4..16 batches of 16384..65536 reads -- bigger launches, and
-6 x 42 GB of scratch still fit the 288 GB) that are in flight together, one context + HIP stream + host thread each; device batches of
+one batch of `--reads-per-step` read indices per GPU (default 393216 reads x 15 kb ~ 5.9 Gbases; the 30x job is 16 such
+steps on one GPU).  The batch goes through the C-ABI as `--streams` device batches (brx_simulate_batch, 6 x 65536
+reads by default: measured best on the MI355X among 4..8 batches of 49152..98304 reads -- round 3's slab traceback stores
+made the bigger batch fit a SMALLER arena, 6 x 40 GB) that are in flight together, one context + HIP stream + host thread each; device batches of
 consecutive steps follow each other without a barrier, exactly as the CLI driver runs them
 (badread_amd.simulate.run_batches).  Inputs (packed reference, model tables) are resident in HBM before the timed
 region; the FASTQ bytes stay in HBM (`--d2h` adds the PCIe-inclusive rate as `value_incl_d2h`).  Weak scaling: every
@@ -56,7 +56,7 @@ for _p in (REPO, os.path.join(REPO, 'tools')):
 
 ALGO_BYTES_PER_BASE = 2.26          # 0.25 B packed reference read + 2 B FASTQ written + header share
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
-SCRATCH_GB_DEFAULT = 42.0           # scratch arena per in-flight device batch (tests/test_gpu_fullsize.py runs the shipped geometry with it)
+SCRATCH_GB_DEFAULT = 40.0           # scratch arena per in-flight device batch (tests/test_gpu_fullsize.py runs the shipped geometry with it)
 VALU_PEAK_PER_S = 6.56e11           # wave64 32-bit integer VALU instructions/s, chip-wide, MEASURED (profiles/valu_rate.json, tools/native/valu_bench.hip):
                                     # 4 cycles per instruction per SIMD -- half of what the 2-cycle v_fma_f32 rate of MI355X_MICROARCH.md would give
 SEED = 42
@@ -223,6 +223,23 @@ def cpu_baseline(first_read, budget_s, workload, ref_dir):
     return result
 
 
+def aligner_lane_model(stats):
+    """Share of the final aligner's lane-words that hold band cells, from the geometry of every read of a batch (a model, not a
+    counter): a column of a read costs one trip-slot on all 64 lanes x G words, of which (band width) / 32 words are inside
+    the Ukkonen band.  Band width ~ distance of the alignment + 1 (the kernels use the proven bound, a few percent more);
+    G = words per lane of the band class (1 up to 56 x 32 diagonals, then doubling).  Returns (useful, issued) word-columns."""
+    n = stats['frag_len'].astype(np.float64) + 14.0
+    d = np.maximum(stats['n_cols'].astype(np.float64) - stats['n_match'], 0.0)
+    live = stats['n_cols'] > 0
+    bw = np.maximum(d + 1.0, np.abs(stats['padded_len'].astype(np.float64) - n) + 1.0)
+    g = np.ones_like(bw)
+    for _ in range(12):
+        g = np.where(bw > 56.0 * 32.0 * g, g * 2.0, g)
+    useful = float((n * bw / 32.0)[live].sum())
+    issued = float((n * 64.0 * g)[live].sum())
+    return useful, issued
+
+
 def valu_per_base(workload):
     """SQ_INSTS_VALU per simulated base of this workload from the committed counter pass (profiles/), or None."""
     path = os.path.join(REPO, 'profiles', 'valu_per_base.json')
@@ -254,7 +271,7 @@ def main():
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='human', choices=sorted(WORKLOADS))
-    ap.add_argument('--reads-per-step', type=int, default=294912,
+    ap.add_argument('--reads-per-step', type=int, default=393216,
                     help='read indices per GPU per step; split into --streams device batches')
     ap.add_argument('--scratch-gb', type=float, default=SCRATCH_GB_DEFAULT, help='scratch arena per in-flight batch')
     ap.add_argument('--streams', type=int, default=6,
@@ -347,7 +364,7 @@ def main():
         """The device batches of steps `step_indices`, C in flight: worker i owns context i / stream i and takes
         every C-th device batch; batch b of step k covers read indices ((k*C + b)*world + rank)*R ..."""
         indices = [k * C + b for k in step_indices for b in range(C)]
-        acc = [{'bases': 0, 'passes': 0, 'stages': {}, 'kernels': {}, 'final_launches': 0, 'misses': 0, 'bad': 0, 'host_ms': 0.0, 'error': None} for _ in range(C)]
+        acc = [{'bases': 0, 'passes': 0, 'stages': {}, 'kernels': {}, 'final_launches': 0, 'misses': 0, 'bad': 0, 'host_ms': 0.0, 'error': None, 'lane_useful': 0.0, 'lane_issued': 0.0} for _ in range(C)]
 
         def worker(i):
             try:
@@ -361,6 +378,8 @@ def main():
                         acc[i]['host_ms'] += 1000.0 * (time.perf_counter() - t_call)
                         acc[i]['bases'] += int(stats['seq_len'].sum())
                         acc[i]['bad'] += int((stats['status'] & 0xE).astype(bool).sum())     # RS_TOO_MANY_SEGS | RS_BAND | RS_QMISS
+                        useful, issued = aligner_lane_model(stats)
+                        acc[i]['lane_useful'] += useful; acc[i]['lane_issued'] += issued
                         if dry:
                             continue
                         acc[i]['passes'] += engines[i].mutate_passes()
@@ -421,7 +440,7 @@ def main():
         for name, level in (('devnull_cold', None), ('devnull', None), ('gzip_device', 'device'), ('gzip1', 1)):   # cold: includes mapping the clones' scratch
             print(f'[bench --d2h] {name} ...', file=sys.stderr, flush=True)
             gc.collect()
-            torch.cuda.empty_cache()                 # the legs run at the edge of the 288 GB (6 x 42 GB of scratch): give back what the last one cached
+            torch.cuda.empty_cache()                 # the legs run at the edge of the 288 GB (6 x 40 GB of scratch): give back what the last one cached
             raw = open(os.devnull, 'wb')
             sink = raw if level in (None, 'device') else GzipSink(raw, level)
             counter = {'bytes': 0}
@@ -509,8 +528,22 @@ def main():
     vpb = valu_per_base(args.workload)
     if vpb:
         rate = vpb['valu_per_base'] * value / world
-        result['roofline_alu'] = {'bound': 'valu-issue', 'achieved': rate, 'peak': VALU_PEAK_PER_S, 'peak_source': 'profiles/valu_rate.json (measured integer VALU issue rate)', 'unit': 'wave-instructions/s',
-                                  'frac': rate / VALU_PEAK_PER_S, 'valu_per_base': vpb['valu_per_base'], 'source': vpb.get('source')}
+        from badread_amd.build import source_hash
+        tree = source_hash()
+        lane_useful, lane_issued = sum(a['lane_useful'] for a in acc), sum(a['lane_issued'] for a in acc)
+        result['roofline_alu'] = {'bound': 'valu-issue', 'achieved': rate, 'peak': VALU_PEAK_PER_S, 'peak_source': 'profiles/valu_rate.json (measured integer VALU issue rate: 4 cycles per wave64 instruction per SIMD)',
+                                  'unit': 'wave-instructions/s', 'frac': rate / VALU_PEAK_PER_S,
+                                  'peak_guide': 2.0 * VALU_PEAK_PER_S, 'frac_of_guide_peak': rate / (2.0 * VALU_PEAK_PER_S),
+                                  'peak_note': 'MI355X_MICROARCH.md quotes a 2-cycle issue for 32-bit VALU ops; tools/native/valu_bench.hip measures 4 cycles for the '
+                                               'integer ops of this path AND for its v_fma_f32 control (profiles/valu_rate.json): both fractions are given',
+                                  'valu_per_base': vpb['valu_per_base'], 'source': vpb.get('source'),
+                                  'counted_on_tree': vpb.get('csrc_sha16'), 'this_tree': tree,
+                                  'stale': vpb.get('csrc_sha16') != tree,        # the instruction count was taken on other kernel sources: repeat tools/profile_round.sh
+                                  'exec_lane_frac': vpb.get('exec_lane_frac'),
+                                  'useful_lane_frac_aligner_model': (lane_useful / lane_issued) if lane_issued else None,
+                                  'lane_note': 'issued instructions are not useful lane-operations: exec_lane_frac = lanes the EXEC mask leaves on (PMC), '
+                                               'useful_lane_frac_aligner_model = band words / (64 lanes x words per lane) of the final alignments of THIS run '
+                                               '(the kernels that issue more than half of the instructions)'}
     result['stage_ms_per_device_batch'] = stages
     result['host_ms_per_device_batch'] = sum(a['host_ms'] for a in acc) / n_batches        # wall time of one brx_simulate_batch call
     result['scratch_or_output_retries'] = sum(getattr(e, 'retries', 0) for e in engines)

@@ -12,7 +12,7 @@ checked through properties that do not need the oracle at that size, and against
   * ALL 16384 reads: the oracle (one process per host core) reproduces every record and every statistic.
 
 configs[3] and configs[4] (the 3.09 Gb reference) run at the SHIPPED launch geometry -- the bench's and the CLI's device batch
-of 49152 reads with the bench's scratch arena and the default environment -- and every read of that batch is compared with
+of 65536 reads with the bench's scratch arena and the default environment -- and every read of that batch is compared with
 the oracle.
 """
 import io
@@ -26,7 +26,7 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 N = 16384
-SHIPPED_BATCH = 49152          # bench.py / CLI device batch (--reads-per-step 294912 as --streams 6)
+SHIPPED_BATCH = 65536          # bench.py / CLI device batch (--reads-per-step 393216 as --streams 6)
 SEED = 42
 HEADER = re.compile(rb'length=(\d+) error-free_length=(\d+) read_identity=([0-9.]+)%$')
 
@@ -137,7 +137,7 @@ def test_configs1_full_batch_properties(workload, monkeypatch, tmp_path):
 @pytest.mark.parametrize('wlname', ['human', 'hifi'])
 def test_configs3_and_4_every_read_of_a_full_batch_equals_the_oracle(wlname, tmp_path):
     """BASELINE.json configs[3] (GRCh38-like 3.09 Gb, nanopore2023) and configs[4] (pacbio2021, --identity 30,3) at the
-    SHIPPED launch geometry (49152 reads per device batch, the bench's scratch arena, default environment): ALL reads of the
+    SHIPPED launch geometry (65536 reads per device batch, the bench's scratch arena, default environment): ALL reads of the
     first device batch, HIP path vs the CPU oracle (one oracle process per usable host core on disjoint slices of the batch),
     FASTQ bytes and every per-read statistic.  The batch is known (oracle plan probes under seed 42) to hold reads that overlap N runs -- whose windows carry
     non-ACGT symbols and saturated edit bounds -- and reads clipped at the end of a linear contig

@@ -17,7 +17,7 @@ i=0
 for ctrs in "${@:3}"; do
   i=$((i + 1))
   timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$out/${tag}_pmc$i" -o p -- \
-      python "$root/bench.py" --workload $wl --steps 1 --warmup 1 --streams 1 --reads-per-step 49152 --cpu-seconds 0 > "$out/${tag}_pmc$i.json" 2> "$out/${tag}_pmc$i.err"
+      python "$root/bench.py" --workload $wl --steps 1 --warmup 1 --streams 1 --reads-per-step 65536 --cpu-seconds 0 > "$out/${tag}_pmc$i.json" 2> "$out/${tag}_pmc$i.err"
 done
 if [ $i -gt 0 ]; then
   python "$root/tools/pmc_summary.py" "$out/${tag}"_pmc*/*counter_collection.csv > "$out/${tag}_pmc_per_kernel.csv" 2>> "$out/${tag}_trace.err"
