@@ -54,6 +54,8 @@ struct brx_ctx {
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
                                     three wide classes: a stream per class measured 30 % slower, r01d) */
     hipEvent_t ev_fork, ev_join;
+    hipEvent_t ev_wait;          /* blocking-sync event: the host thread SLEEPS in wait_stream instead of spinning (BRX_SPIN_WAIT=1: spin) */
+    int spin_wait;
     uint64_t *d_clk, *d_phase; uint32_t clk_reads;
     /* per-kernel launch timing (brx_set_kernel_timing / brx_last_kernel_stats): event pairs around every launch */
     int ktiming;
@@ -113,6 +115,7 @@ static void release(brx_ctx *c) {
     for (int i = 0; i < 2; ++i) { if (c->ev_fork2[i]) (void)hipEventDestroy(c->ev_fork2[i]); if (c->ev_join2[i]) (void)hipEventDestroy(c->ev_join2[i]); }
     if (c->ev_head_mut) (void)hipEventDestroy(c->ev_head_mut);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     free(c);
 }
@@ -162,6 +165,8 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
     /* a context owns exactly three streams besides the caller's: every stream of a context takes a hardware queue, and two idle
        extra streams per context (6 contexts) cost 24 % of the rate (round 2, A/B on one box: 2.97 -> 2.27 Gbases/s) */
+    if ((e = hipEventCreateWithFlags(&c->ev_wait, hipEventDisableTiming | hipEventBlockingSync)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    { const char *v = getenv("BRX_SPIN_WAIT"); c->spin_wait = v ? atoi(v) : 0; }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
@@ -215,7 +220,19 @@ extern "C" int brx_last_stage_ms(const brx_ctx *c, float ms[BRX_STAGE_COUNT]) {
 /* wait for the stream; with BRX_DEBUG set, poll instead and on a stall print the kernel's progress
  * words and leave the process (a hung kernel must not take the GPU box down with it) */
 static int wait_stream(brx_ctx *c, hipStream_t st, const char *what) {
-    if (!brx_debug()) { HIPCHK(c, hipStreamSynchronize(st)); return BRX_OK; }
+    if (!brx_debug()) {
+        /* A batch waits ~25 times for its stream, and a rank keeps six batches in flight on six host threads: hipStreamSynchronize
+           spins, i.e. six busy cores per GPU -- 48 on an 8-GPU node whose container has 16.  The thread polls an event every 40 us
+           instead (tens of microseconds later per wait, against ~1.7 s per batch). */
+        if (c->spin_wait) { HIPCHK(c, hipStreamSynchronize(st)); return BRX_OK; }
+        HIPCHK(c, hipEventRecord(c->ev_wait, st));
+        for (;;) {                                   /* hipEventSynchronize spins even on a blocking-sync event (measured: 6.1 busy cores per rank) */
+            const hipError_t q = hipEventQuery(c->ev_wait);
+            if (q == hipSuccess) return BRX_OK;
+            if (q != hipErrorNotReady) return fail(c, BRX_E_HIP, "%s: %s", what, hipGetErrorString(q));
+            usleep(40);
+        }
+    }
     const char *w = getenv("BRX_WATCHDOG_S");
     int limit_ms = (w ? atoi(w) : 15) * 1000;
     for (int ms = 0;; ms += 20) {
@@ -551,7 +568,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             HIPCHK(c, hipMemcpyAsync(set_tboff + S.b, h_tboff.data() + S.b, (size_t)ns * 8, hipMemcpyHostToDevice, S.st));
             hipLaunchKernelGGL(k_set_tboff, dim3((ns + 63) / 64), dim3(64), 0, S.st, ns, rs, order + S.b, set_tboff + S.b, (uint64_t *)nullptr);
         }
-        HIPCHK(c, hipStreamSynchronize(S.st));                      /* the host vectors above go out of scope */
+        { int rcw_ = wait_stream(c, S.st, "final stage tables"); if (rcw_) return rcw_; }     /* the host vectors above go out of scope */
         const uint32_t b = S.b, e = S.e;
         const uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
         uint32_t *cq = counters + 16 + 16 * (((size_t)S.id * 2 + (size_t)phase));      /* queue heads of this set and phase: [0..7] four 64-bit class counters, [8], [9] qscore */
@@ -664,7 +681,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         c->window_misses += misses;
         if (!misses) return BRX_OK;
         HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, S.st));
-        HIPCHK(c, hipStreamSynchronize(S.st));
+        { int rcw_ = wait_stream(c, S.st, "final stage, misses"); if (rcw_) return rcw_; }
         int rcp = launch_final_phase(S, 1);
         if (rcp) return rcp;
         return wait_stream(c, S.st, "final stage, second phase");
@@ -680,7 +697,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         h_ctr[MC_WORDS + MC_OUT] = n_mh;           /* block 4 (copied below): the head launch's input count */
         HIPCHK(c, hipMemcpyAsync(mctr + 2 * MC_WORDS, h_ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(mctr + 4 * MC_WORDS, h_ctr + MC_WORDS, MC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        { int rcw_ = wait_stream(c, st, "mutate counters"); if (rcw_) return rcw_; }
     }
     const uint32_t lane_threshold = c->lane_threshold;   /* fewer active reads than this: one wave per window (lower latency) */
     /* reads taken to completion in ONE launch (the head set from the start; the last BRX_TAIL_READS of the bulk set):
@@ -874,7 +891,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     /* a read that exhausted its 1000 tries is fatal in the reference (simulate.py:164) */
     if (!raw) {
         HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        { int rcw_ = wait_stream(c, st, "read status"); if (rcw_) return rcw_; }
         for (uint32_t i = 0; i < n_reads; ++i) if (h_rs[i].status & BRX_RS_NOFRAG) {
             snprintf(c->err, sizeof(c->err), "read %llu failed to generate a sequence fragment", (unsigned long long)(first_read + i));
             return BRX_E_NOFRAG;

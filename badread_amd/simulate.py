@@ -447,6 +447,9 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         print_progress(count, total, target_size, output)
     timing = run_batches.last_timing = collections.Counter()     # seconds of the consumer thread per activity (bench.py --d2h)
     t0 = time.perf_counter()
+    if hasattr(engine, 'presize'):               # the arena of the first engine (the clones copy its size) for the batches this job will issue
+        first_batch = plan_batch(target_size, expected_mean, shard.world, max_batch) // shard.world
+        engine.presize(first_batch, expected_mean)
     pool = _BatchPool(engine, max(1, int(in_flight)))
     timing['create_engines'] = time.perf_counter() - t0
     ring = None

@@ -279,6 +279,7 @@ def main():
                          'read of one device batch overlaps the bulk of the others')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='seconds each host core runs the cpu_baseline leg (0 = skip)')
     ap.add_argument('--d2h', action='store_true', help='also run the same amount of work through the CLI driver (PCIe + host output stage): value_incl_d2h, value_incl_gzip')
+    ap.add_argument('--d2h-legs', default='devnull_cold,devnull,gzip_device,gzip1', help='which --d2h legs to run (comma separated)')
     ap.add_argument('--ref-dir', default=default_ref_dir(), help='where the synthetic reference FASTA and its packed sidecar live')
     ap.add_argument('--ref-scale', type=float, default=1.0, help='shrink the GRCh38-like reference (tests, dry runs); 1.0 = the metric\'s 3.09 Gb')
     ap.add_argument('--cpu-engine', action='store_true',
@@ -408,9 +409,11 @@ def main():
     run_steps(list(range(args.warmup)) if args.warmup else [])
     barrier()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     acc = run_steps([args.warmup + k for k in range(args.steps)])
     barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - cpu0           # CPU seconds of this rank (all its threads) inside the timed region
     bases = sum(a['bases'] for a in acc)
     bad = sum(a['bad'] for a in acc)
 
@@ -437,7 +440,10 @@ def main():
         torch.cuda.empty_cache()
         target = int(sum(a['bases'] for a in acc))           # what this rank simulated in the timed region
         d2h = {}
+        legs = [x for x in args.d2h_legs.split(',') if x]
         for name, level in (('devnull_cold', None), ('devnull', None), ('gzip_device', 'device'), ('gzip1', 1)):   # cold: includes mapping the clones' scratch
+            if name not in legs:
+                continue
             print(f'[bench --d2h] {name} ...', file=sys.stderr, flush=True)
             gc.collect()
             torch.cuda.empty_cache()                 # the legs run at the edge of the 288 GB (6 x 40 GB of scratch): give back what the last one cached
@@ -546,14 +552,16 @@ def main():
                                                '(the kernels that issue more than half of the instructions)'}
     result['stage_ms_per_device_batch'] = stages
     result['host_ms_per_device_batch'] = sum(a['host_ms'] for a in acc) / n_batches        # wall time of one brx_simulate_batch call
+    result['host_cpu'] = {'cpu_seconds_per_device_batch': host_cpu_s / n_batches, 'busy_cores_of_this_rank': host_cpu_s / elapsed, 'usable_cores': usable_cores(),
+                          'note': 'process CPU time of rank 0 (six batch threads + main) over the timed region: busy_cores x 8 ranks must fit the usable cores of an 8-GPU node'}
     result['scratch_or_output_retries'] = sum(getattr(e, 'retries', 0) for e in engines)
     result['retry_log'] = [m for e in engines for m in getattr(e, 'retry_log', [])][:8]
     result['mutate_passes_per_device_batch'] = sum(a['passes'] for a in acc) / n_batches
     result['traceback_window_misses_per_step'] = sum(a['misses'] for a in acc) / args.steps
     if d2h is not None:
-        result['value_incl_d2h'] = d2h['devnull']['bases_per_s']
-        result['value_incl_gzip'] = d2h['gzip1']['bases_per_s']
-        result['value_incl_gzip_device'] = d2h['gzip_device']['bases_per_s']
+        for key, leg in (('value_incl_d2h', 'devnull'), ('value_incl_d2h_cold', 'devnull_cold'), ('value_incl_gzip', 'gzip1'), ('value_incl_gzip_device', 'gzip_device')):
+            if leg in d2h:
+                result[key] = d2h[leg]['bases_per_s']
         result['driver_end_to_end'] = dict(d2h, note='badread_amd.simulate.run_batches (the CLI driver: stop rule, D2H through a ring of pinned '
                                                       'buffers, writer thread) over the same number of bases, FASTQ to /dev/null and through '
                                                       '--gzip 1 on all host cores; includes the start-up of its engine clones')

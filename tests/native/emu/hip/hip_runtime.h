@@ -278,7 +278,7 @@ enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorInvalidValue = 1 };
 typedef struct emu_stream { int id; } *hipStream_t;
 typedef struct emu_event { double ms; } *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocMapped = 2, hipHostMallocDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventBlockingSync = 1, hipHostMallocMapped = 2, hipHostMallocDefault = 0 };
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
 
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "emulated HIP error"; }
@@ -299,6 +299,7 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
     e->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     return hipSuccess;
 }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->ms - a->ms); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }

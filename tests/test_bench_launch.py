@@ -46,3 +46,16 @@ def test_gpus_2_spawns_two_ranks_and_aggregates(tmp_path):
 def test_world_size_that_contradicts_gpus_is_refused(tmp_path):
     r = run(COMMON + ['--gpus', '2'], env={'WORLD_SIZE': '3', 'RANK': '0', 'LOCAL_RANK': '0'}, tmp=tmp_path)
     assert r.returncode != 0 and 'refusing' in (r.stderr + r.stdout)
+
+
+def test_gpus_8_dry_run_over_gloo(tmp_path):
+    """The launch the driver uses for its scaling curve (--gpus 8), on the CPU checker engine over gloo: eight ranks start,
+    shard the read-index space, reduce their three scalars and rank 0 prints one line whose bases are the sum of all ranks."""
+    r = run(['--cpu-engine', '--steps', '1', '--warmup', '0', '--reads-per-step', '16', '--streams', '1', '--workload', 'human',
+             '--ref-scale', '0.002', '--gpus', '8'], tmp=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = last_json(r.stdout)
+    assert line['n_gpus'] == 8 and 'INVALID' in line and line['scaling'] == 'weak'
+    total = line['value'] * line['ms_per_step'] * 1e-3 * line['steps']
+    rank0 = line['config']['bases_per_step_per_gpu'] * line['steps']
+    assert total > 3.0 * rank0, (total, rank0)          # 16 reads of 15 +- 13 kb per rank: eight ranks in the sum
