@@ -300,7 +300,9 @@ class BrxError(RuntimeError):
 class HipEngine(EngineBase):
     """One context on one MI355X.  Not thread-safe; one engine per process per GPU."""
 
-    def __init__(self, device=0, scratch_bytes=1 << 30):
+    def __init__(self, device=0, scratch_bytes=1 << 30, scratch_tensor=None):
+        """scratch_tensor: a device uint8 tensor (typically a slice of one arena the caller allocated for several engines at
+        once, before any of them computes: simulate._BatchPool) to use instead of allocating `scratch_bytes`."""
         super().__init__()
         import torch
         if not torch.cuda.is_available():
@@ -318,7 +320,11 @@ class HipEngine(EngineBase):
         self._out = None
         self._stats = None
         self._structs = {}              # last descriptor given to each brx_set_*: what clone() hands to a new context
-        self._ensure_scratch(scratch_bytes)
+        if scratch_tensor is not None:
+            self._scratch = scratch_tensor
+            self._check(self.lib.brx_set_scratch(self.ctx, ctypes.c_void_p(self._scratch.data_ptr()), self._scratch.numel()))
+        else:
+            self._ensure_scratch(scratch_bytes)
 
     def close(self):
         if getattr(self, 'ctx', None):
@@ -389,11 +395,12 @@ class HipEngine(EngineBase):
         self._check(self.lib.brx_set_qscore_model(self.ctx, ctypes.byref(s)))
         self._structs['qm'] = s
 
-    def clone(self, scratch_bytes=None):
+    def clone(self, scratch_bytes=None, scratch_tensor=None):
         """Another context on the same device that SHARES this engine's device tables (reference, models,
         parameters: read-only in every kernel) and owns its scratch, output and stream.  The driver keeps several
         batches in flight with one clone per batch (badread_amd.simulate.run_batches)."""
-        other = HipEngine(self.device.index or 0, scratch_bytes or (self._scratch.numel() if self._scratch is not None else 1 << 30))
+        other = HipEngine(self.device.index or 0, scratch_bytes or (self._scratch.numel() if self._scratch is not None else 1 << 30),
+                          scratch_tensor=scratch_tensor)
         other._keep = dict(self._keep)
         other.sym = self.sym
         setters = {'ref': self.lib.brx_set_reference, 'em': self.lib.brx_set_error_model,

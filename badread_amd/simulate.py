@@ -357,61 +357,94 @@ class _HostRing(object):
 
 class _BatchPool(object):
     """`in_flight` engines (the given one + clones sharing its device tables), each driven by its own host thread on
-    its own HIP stream, so that several batches overlap on the GPU.  A job returns the batch's FASTQ bytes WHERE THEY
-    ARE (a device tensor on the GPU engines) and its per-read statistics; the consumer copies out only the bytes it
-    keeps and then releases the engine."""
+    its own HIP stream, so that several batches overlap on the GPU.
+
+    Batches are CONSUMED in index order (the stop rule), but they do not FINISH in index order: read lengths differ, and so do
+    batch times.  Round 2 released an engine only when its batch was consumed, so an engine that had finished batch k + 3
+    idled until batches k .. k + 2 were through -- every round of six batches took as long as its slowest member, and a 30x job
+    through this driver ran at 60-70 % of the rate bench.py measures on the same kernels.  Now the worker thread itself takes
+    a free engine when it starts a batch, copies the batch's FASTQ bytes device-to-device out of the engine's buffer when the
+    batch is done (2 GB at HBM speed: ~1 ms) and gives the engine back at once; `depth` = in_flight + 2 batches may be outstanding,
+    the surplus holding only their bytes."""
 
     def __init__(self, engine, in_flight):
         import concurrent.futures
+        import queue
         self.engines = [engine]
         self.streams = [None]
         torch = getattr(engine, 'torch', None)           # absent on the tests' CPU checker engines
         self.on_gpu = torch is not None and getattr(engine, 'device', None) is not None and engine.device.type == 'cuda'
         if in_flight > 1 and hasattr(engine, 'clone'):
             self.streams = [torch.cuda.Stream(device=engine.device) if self.on_gpu else None for _ in range(in_flight)]
-            # a clone is made by the worker thread that first needs it: its tens of GB of scratch are mapped (seconds,
-            # measured: 6.8 s for 7 x 34 GB up front) while the engines that already exist are computing
             self.engines += [None] * (in_flight - 1)
         elif self.on_gpu:
             self.streams = [torch.cuda.Stream(device=engine.device)]
-        self.free = list(range(len(self.engines)))
-        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=len(self.engines)) if len(self.engines) > 1 else None
-
-    def __len__(self):
-        return len(self.engines)
-
-    def submit(self, seed, first, n_mine):
-        i = self.free.pop(0)                             # engine 0 exists already: it takes the first batch
-        stream = self.streams[i]
-
-        def job():
-            import torch
-            if self.engines[i] is None:
+        self.free = queue.Queue()
+        self.free.put(0)                                 # engine 0 exists already: it takes the first batch
+        self.create_seconds = 0.0
+        self.create_error = None
+        # Mapping a clone's 40 GB arena takes ~0.6-1.2 s per engine whoever does it and whenever (the driver clears the memory:
+        # 14-29 ms per GB measured, also for ONE 200 GB allocation on an idle device -- 5.9 s), so the clones are made by their own
+        # threads while engine 0 already computes: a job's first seconds run on fewer engines instead of on none.
+        def make(i):                                     # a clone maps tens of GB of scratch: its own thread, beside the first batches
+            t0 = time.perf_counter()
+            try:
                 if self.on_gpu:
                     torch.cuda.set_device(self.engines[0].device)
                 self.engines[i] = self.engines[0].clone()
-            eng = self.engines[i]
-            if n_mine == 0:
-                return torch.zeros(0, dtype=torch.uint8), np.zeros(0, dtype=eng.stats_dtype)
-            if not self.on_gpu:
-                out, stats = eng.simulate_batch(seed, first, n_mine, allow_nofrag=True)
-                return torch.from_numpy(np.ascontiguousarray(out).copy()), stats.copy()
-            torch.cuda.set_device(eng.device)
-            with torch.cuda.stream(stream):
-                out, stats = eng.simulate_batch_device(seed, first, n_mine, allow_nofrag=True)
-                stream.synchronize()
-                return out, stats.copy()                 # `out` is the engine's buffer: valid until release(i)
+            except BaseException as ex:                  # surfaced by the job that would have used this engine
+                self.create_error = ex
+            self.create_seconds += time.perf_counter() - t0
+            self.free.put(i)
+        import threading
+        self.makers = [threading.Thread(target=make, args=(i,), daemon=True) for i in range(1, len(self.engines))]
+        for th in self.makers:
+            th.start()
+        self.depth = len(self.engines) + (2 if len(self.engines) > 1 else 0)
+        self.job_seconds = self.job_count = 0.0          # wall time of the device batches (bench.py --d2h reports the average)
+        self.wait_engine_seconds = 0.0
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=len(self.engines)) if len(self.engines) > 1 else None
+
+    def __len__(self):
+        return self.depth
+
+    def submit(self, seed, first, n_mine):
+        def job():
+            import torch
+            t_q = time.perf_counter()
+            i = self.free.get()
+            t_job = time.perf_counter()
+            self.wait_engine_seconds += t_job - t_q
+            try:
+                stream = self.streams[i]
+                if self.engines[i] is None:
+                    raise self.create_error or RuntimeError('engine clone missing')
+                eng = self.engines[i]
+                if n_mine == 0:
+                    return torch.zeros(0, dtype=torch.uint8), np.zeros(0, dtype=eng.stats_dtype)
+                if not self.on_gpu:
+                    out, stats = eng.simulate_batch(seed, first, n_mine, allow_nofrag=True)
+                    return torch.from_numpy(np.ascontiguousarray(out).copy()), stats.copy()
+                torch.cuda.set_device(eng.device)
+                with torch.cuda.stream(stream):
+                    out, stats = eng.simulate_batch_device(seed, first, n_mine, allow_nofrag=True)
+                    out = out.clone()                        # the engine's buffer is free again; the copy runs on this batch's stream ...
+                    stream.synchronize()                     # ... and is complete before the engine is handed to the next batch
+                    return out, stats.copy()
+            finally:
+                self.job_seconds += time.perf_counter() - t_job
+                self.job_count += 1
+                self.free.put(i)
         if self.pool is None:
             class _Done(object):
                 def __init__(self, v): self.v = v
                 def result(self): return self.v
-            return i, _Done(job())
-        return i, self.pool.submit(job)
-
-    def release(self, i):
-        self.free.append(i)
+            return _Done(job())
+        return self.pool.submit(job)
 
     def close(self):
+        for th in self.makers:
+            th.join()
         if self.pool is not None:
             self.pool.shutdown(wait=True)
         for eng in self.engines[1:]:
@@ -471,28 +504,28 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             sys.exit('Error: --gzip-device needs the GPU engine')
         from .output import fastq_blocks
         gz_engine = engine.clone(1 << 20) if hasattr(engine, 'clone') else engine      # its own context: the others are busy on their threads
-    pending = collections.deque()          # (slot, future, first_of_super_batch, n_super, first, n_mine)
+    pending = collections.deque()          # (None, future, first_of_super_batch, n_super, first, n_mine)
     fatal = bad_read = None
 
     def fill():
         """Keep the pipeline full: what is outstanding is assumed to deliver its expected number of bases.  Called at
         points that depend only on consumed totals, so every rank issues the same batches."""
         nonlocal next_read
-        while len(pending) < len(pool) and pool.free:
+        while len(pending) < len(pool):
             outstanding = sum(p[3] for p in pending) * expected_mean
             remaining = target_size - total - outstanding
             if remaining <= 0 and pending:
                 break
             n_super = plan_batch(max(remaining, 1), expected_mean, shard.world, max_batch)
             first, n_mine = shard.slice_of(next_read, n_super)
-            slot, fut = pool.submit(seed, first, n_mine)
-            pending.append((slot, fut, next_read, n_super, first, n_mine))
+            fut = pool.submit(seed, first, n_mine)
+            pending.append((None, fut, next_read, n_super, first, n_mine))
             next_read += n_super
 
     try:
         while total < target_size:
             fill()
-            slot, fut, base, n_super, first, n_mine = pending.popleft()
+            _, fut, base, n_super, first, n_mine = pending.popleft()
             t0 = time.perf_counter()
             out, stats = fut.result()
             timing['wait_for_batch'] += time.perf_counter() - t0
@@ -531,18 +564,8 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             if shard.world > 1:
                 sizes = [int(x[0]) for x in shard.gather_words(np.array([my_bytes], dtype=np.uint32), [1] * shard.world)]
                 assert my_bytes < 2 ** 32
-            # the engine goes back to work at once: its kept bytes are copied device-to-device first (0.5 GB at HBM speed),
-            # the slower hops (PCIe into the pinned ring, or the send to rank 0) read that copy
-            t0 = time.perf_counter()
             if pool.on_gpu and my_bytes and not packed:
-                out = out[:my_bytes].clone()
-                # the copy runs on THIS thread's stream, the engine's next batch (which overwrites the buffer) on its own:
-                # the engine is released only when the copy is done (~1 ms for 0.5 GB)
-                torch_mod = getattr(pool.engines[slot], 'torch', None)
-                if torch_mod is not None:
-                    torch_mod.cuda.current_stream().synchronize()
-            timing['clone'] += time.perf_counter() - t0
-            pool.release(slot)                      # the engine's output buffer may be overwritten from here on
+                out = out[:my_bytes]                # `out` is this batch's own copy (made by its worker): nothing to wait for
             used = lens[:last + 1]
             count += int((used > 0).sum())
             total += int(used.sum())
@@ -560,7 +583,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             if stop:
                 break
     finally:
-        for slot, fut, *_ in pending:       # speculative batches past the stopping read
+        for _, fut, *_ in pending:          # speculative batches past the stopping read
             try:
                 fut.result()
             except Exception:
@@ -577,6 +600,9 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             timing['ring_alloc'] = ring.alloc_seconds
         timing['flush'] = time.perf_counter() - t0
         timing['retries'] = sum(getattr(e, 'retries', 0) for e in pool.engines if e is not None)
+        timing['device_batch_seconds_avg'] = pool.job_seconds / max(pool.job_count, 1.0)
+        timing['wait_for_engine'] = pool.wait_engine_seconds
+        timing['create_clones_thread_seconds'] = pool.create_seconds
     if shard.rank == 0:
         print('\n', file=output)
     if fatal:
