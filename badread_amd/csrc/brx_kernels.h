@@ -521,7 +521,6 @@ __device__ inline bool dev_choose_alt(const brx_error_model &em, const uint8_t *
 }
 
 __device__ __forceinline__ uint32_t rep_len(uint32_t w) { return w ? ((w >> 24) & 0x7Fu) : 1u; }
-__device__ __forceinline__ uint32_t rep_cost(uint32_t w) { uint32_t l = (w >> 24) & 0x7Fu; return w ? (l ? l : 1u) : 0u; }
 
 __device__ inline uint8_t rep_char(const brx_error_model &em, uint32_t w, uint32_t x) {
     uint32_t off = w & 0x00FFFFFFu;
@@ -530,9 +529,22 @@ __device__ inline uint8_t rep_char(const brx_error_model &em, uint32_t w, uint32
     return em.d_pool[off + x];
 }
 
+/* Proven bound on the edits one position contributes: the distance between the one-base string `orig` and its replacement of
+   `len` characters -- 1 for a deletion or a substitution, len - 1 for a string that still holds the base (an insertion beside
+   it), len for one that does not.  (Round 2 charged `len` for every string: a third of nanopore2023's alternatives are the base
+   plus one inserted character, so the bound -- the band width of every alignment of the read -- ran ~30 % above the distance.) */
+__device__ inline uint32_t rep_cost(const brx_error_model &em, uint32_t w, uint32_t orig) {
+    if (!w) return 0u;
+    const uint32_t l = (w >> 24) & 0x7Fu;
+    if (l < 2u) return 1u;
+    bool has = false;
+    for (uint32_t x = 0; x < l; ++x) has |= (uint32_t)rep_char(em, w, x) == orig;
+    return l - (has ? 1u : 0u);
+}
+
 /* join(new_fragment_bases[a:b]) by the whole wave: writes the characters to out (may be null for
  * sizing), returns the total length; *cost receives an upper bound on the edit distance between
- * F[a:b] and the joined string (1 per substitution/deletion, len per insertion string). */
+ * F[a:b] and the joined string (rep_cost per changed position). */
 __device__ inline uint32_t wave_join(const brx_error_model &em, const uint8_t *F, const uint32_t *repl,
                                      uint32_t a, uint32_t b, uint8_t *out, uint32_t *cost) {
     const int lane = lane_id();
@@ -540,7 +552,7 @@ __device__ inline uint32_t wave_join(const brx_error_model &em, const uint8_t *F
     for (uint32_t base = a; base < b; base += 64) {
         uint32_t p = base + lane;
         uint32_t w = 0, len = 0;
-        if (p < b) { w = repl[p]; len = rep_len(w); c += rep_cost(w); }
+        if (p < b) { w = repl[p]; len = rep_len(w); if (w) c += rep_cost(em, w, F[p]); }
         uint32_t inc = wave_incl_scan(len);
         if (out && p < b) {
             uint32_t o = run + inc - len;

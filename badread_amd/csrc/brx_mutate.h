@@ -67,7 +67,7 @@ __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F
         const bool valid = p < b;
         uint32_t w = 0, len = 0;
         uint8_t fb = 0xFF;
-        if (valid) { fb = F[p]; w = repl[p]; len = rep_len(w); c += rep_cost(w); qb[p - a] = fb; o_ |= fb > 3; }
+        if (valid) { fb = F[p]; w = repl[p]; len = rep_len(w); c += rep_cost(em, w, fb); qb[p - a] = fb; o_ |= fb > 3; }
         const uint32_t inc = wave_incl_scan(len);
         if (valid) {
             const uint32_t o = run + inc - len;
