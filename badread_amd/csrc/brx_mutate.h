@@ -56,32 +56,59 @@ enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WOR
 
 /* Park a window in ONE pass: qb[0, b-a) = F[a:b] (+16 bytes 0xFF), tbuf[0, tl) = join(new_fragment_bases[a:b]) clipped
  * to `tmax` bytes (+16 bytes 0xFE when it fits), *cost = edit bound of the pair, *odd = a symbol outside ACGT on either
- * side (wave-uniform).  Returns the joined length tl (may exceed tmax: the caller hands the read to k_mutate). */
+ * side (wave-uniform).  Returns the joined length tl (may exceed tmax: the caller hands the read to k_mutate).
+ *
+ * PLANES: the pair also as 2-bit planes behind the bytes (pl: query lo[32] hi[32], target lo[48] hi[48]) for the lane
+ * kernel, in the same pass: the query planes are ballots on the fragment bytes the lanes hold anyway; the target bytes --
+ * whose positions depend on the insertions and deletions before them -- go to a per-wave LDS window as well, and the target
+ * planes are ballots on that.  (Round 2 read both byte strings back from global memory: two more chains of dependent round
+ * trips in a wave that has nothing else to do -- parking was 92 of the ~300 kcycles of a mutate cycle.) */
+#define BRX_PARK_LDS BRX_LANE_TMAX
+__shared__ uint8_t brx_park_lds[BRX_PARK_LDS + 64];
+template <bool PLANES>
 __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F, const uint32_t *repl, uint32_t a, uint32_t b,
-                                     uint8_t *qb, uint8_t *tbuf, uint32_t tmax, uint32_t *cost, bool *odd) {
+                                     uint8_t *qb, uint8_t *tbuf, uint32_t tmax, uint32_t *cost, bool *odd, uint32_t *pl = nullptr) {
     const int lane = lane_id();
-    uint32_t run = 0, c = 0;
+    uint32_t run = 0, c = 0, it = 0;
     bool o_ = false;
-    for (uint32_t base = a; base < b; base += 64) {
+    for (uint32_t base = a; base < b; base += 64, ++it) {
         const uint32_t p = base + lane;
         const bool valid = p < b;
         uint32_t w = 0, len = 0;
         uint8_t fb = 0xFF;
         if (valid) { fb = F[p]; w = repl[p]; len = rep_len(w); c += rep_cost(em, w, fb); qb[p - a] = fb; o_ |= fb > 3; }
+        if constexpr (PLANES) {
+            const unsigned long long lo = __ballot(valid && (fb & 1u)), hi = __ballot(valid && (fb & 2u));
+            if (lane < 2 && it < 16u) { pl[2 * it + lane] = (uint32_t)(lo >> (32 * lane)); pl[32 + 2 * it + lane] = (uint32_t)(hi >> (32 * lane)); }
+        }
         const uint32_t inc = wave_incl_scan(len);
         if (valid) {
             const uint32_t o = run + inc - len;
-            if (!w) { if (o < tmax) tbuf[o] = fb; }
-            else for (uint32_t x = 0; x < len; ++x) {
+            if (!w) {
+                if (o < tmax) tbuf[o] = fb;
+                if constexpr (PLANES) { if (o < BRX_PARK_LDS) brx_park_lds[o] = fb; }
+            } else for (uint32_t x = 0; x < len; ++x) {
                 const uint8_t ch = rep_char(em, w, x);
                 o_ |= ch > 3;
                 if (o + x < tmax) tbuf[o + x] = ch;
+                if constexpr (PLANES) { if (o + x < BRX_PARK_LDS) brx_park_lds[o + x] = ch; }
             }
         }
         run += wave_bcast_u32(inc, 63);
     }
     const uint32_t ql = b - a;
     for (uint32_t x = lane; x < 16; x += 64) { qb[ql + x] = 0xFF; if (run <= tmax) tbuf[run + x] = 0xFE; }
+    if constexpr (PLANES) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);                       /* the LDS bytes of every lane are in place */
+        const uint32_t tl = run < BRX_PARK_LDS ? run : BRX_PARK_LDS;
+        for (uint32_t t = 0; 64u * t < tl; ++t) {
+            const uint32_t x = 64u * t + (uint32_t)lane;
+            const uint32_t ch = x < tl ? brx_park_lds[x] : 0u;
+            const unsigned long long lo = __ballot(ch & 1u), hi = __ballot(ch & 2u);
+            if (lane < 2) { pl[64 + 2 * t + lane] = (uint32_t)(lo >> (32 * lane)); pl[64 + BRX_LANE_TMAX / 32 + 2 * t + lane] = (uint32_t)(hi >> (32 * lane)); }
+        }
+    }
     *cost = wave_sum(c);
     *odd = __ballot(o_) != 0ull;
     return run;
@@ -237,12 +264,15 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
                         uint32_t cost = 0;
                         uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
                         bool odd = false;
-                        const uint32_t tl = wave_park(em, F, rp, a, b, qb, tbuf, BRX_WIN_TMAX, &cost, &odd);
+                        const uint32_t tl = wave_park<!INLINE>(em, F, rp, a, b, qb, tbuf, BRX_WIN_TMAX, &cost, &odd,
+                                                               reinterpret_cast<uint32_t *>(qb + BRX_WIN_PLANES));
                         const uint32_t ql = b - a;
                         uint32_t klass = MC_LEGACY;
                         if (tl <= BRX_WIN_TMAX) {
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                            __builtin_amdgcn_s_waitcnt(0);
+                            if constexpr (INLINE) {                    /* the in-place aligner below reads the bytes back */
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                __builtin_amdgcn_s_waitcnt(0);
+                            }
                             const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
                             const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
                             /* "easy" windows go to a throughput kernel: one window per LANE while the pass is large, eight
@@ -250,21 +280,6 @@ __global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv,
                             const bool easy = !INLINE && !odd && g.G == 1 && tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 &&
                                               (n_in > lane_threshold ? band_blocks <= BRX_LANE_W : brx_pack_eligible(ql, tl, cost, odd));
                             klass = easy ? MC_EASY : MC_HARD;
-                            if (easy) {         /* may go to k_win_lane (the host picks by its own, older count): the pair as bit planes */
-                                uint32_t *pl = reinterpret_cast<uint32_t *>(qb + BRX_WIN_PLANES);
-                                for (uint32_t it = 0; 64u * it < ql; ++it) {
-                                    const uint32_t x = 64u * it + (uint32_t)lane;
-                                    const uint32_t c = x < ql ? qb[x] : 0u;
-                                    const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
-                                    if (lane < 2) { pl[2 * it + lane] = (uint32_t)(lo >> (32 * lane)); pl[32 + 2 * it + lane] = (uint32_t)(hi >> (32 * lane)); }
-                                }
-                                for (uint32_t it = 0; 64u * it < tl; ++it) {
-                                    const uint32_t x = 64u * it + (uint32_t)lane;
-                                    const uint32_t c = x < tl ? tbuf[x] : 0u;
-                                    const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
-                                    if (lane < 2) { pl[64 + 2 * it + lane] = (uint32_t)(lo >> (32 * lane)); pl[64 + BRX_LANE_TMAX / 32 + 2 * it + lane] = (uint32_t)(hi >> (32 * lane)); }
-                                }
-                            }
                         }
                         {
                             MS o = ms;
