@@ -361,6 +361,10 @@ class HipEngine(EngineBase):
             self._check(self.lib.brx_set_scratch(self.ctx, ctypes.c_void_p(self._scratch.data_ptr()),
                                                  self._scratch.numel()))
 
+    def scratch_bytes(self):
+        """Size of this engine's scratch arena (a clone maps the same amount)."""
+        return int(self._scratch.numel()) if self._scratch is not None else 0
+
     def _ensure_out(self, nbytes, n_reads):
         if self._out is None or self._out.numel() < nbytes:
             self._out = None

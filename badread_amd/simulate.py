@@ -408,6 +408,23 @@ class _BatchPool(object):
     def __len__(self):
         return self.depth
 
+    @staticmethod
+    def engines_that_fit(torch, engine, in_flight, out_bytes):
+        """How many engines the device's FREE memory holds: every clone maps an arena as large as the first engine's, every engine
+        owns an output buffer, and in_flight + 2 copies of a batch's bytes may wait for the consumer.  A reserve stays free for what
+        the runtime allocates on its own: the private segments of the planning kernels (1.6 KB per lane, per hardware queue: ~0.9 GB
+        each over the ~20 queues of a six-engine job), the gzip stage, other ranks' records on rank 0.  A job that asks for more
+        engines than fit runs on fewer (a 96-batch job of six 65536-read engines with 40 GB arenas died with
+        HSA_STATUS_ERROR_OUT_OF_RESOURCES at the edge of the 288 GB, where no allocation of ours failed)."""
+        torch.cuda.empty_cache()
+        free, total = torch.cuda.mem_get_info(engine.device)
+        reserve = int(float(os.environ.get('BRX_DRIVER_RESERVE_GB', '24')) * (1 << 30))
+        scratch = engine.scratch_bytes() if hasattr(engine, 'scratch_bytes') else 0
+        n = in_flight
+        while n > 1 and (n - 1) * scratch + (2 * n + 2) * int(out_bytes) + reserve > free:
+            n -= 1
+        return n
+
     def submit(self, seed, first, n_mine):
         def job():
             import torch
@@ -483,7 +500,17 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     if hasattr(engine, 'presize'):               # the arena of the first engine (the clones copy its size) for the batches this job will issue
         first_batch = plan_batch(target_size, expected_mean, shard.world, max_batch) // shard.world
         engine.presize(first_batch, expected_mean)
-    pool = _BatchPool(engine, max(1, int(in_flight)))
+        out_bytes = int(first_batch * (2.1 * expected_mean + 400.0))
+    else:
+        out_bytes = 0
+    asked = fit = max(1, int(in_flight))
+    if fit > 1 and hasattr(engine, 'scratch_bytes') and getattr(getattr(engine, 'device', None), 'type', '') == 'cuda':
+        fit = _BatchPool.engines_that_fit(engine.torch, engine, fit, out_bytes)
+    if shard.world > 1:                          # the issue schedule depends on the depth of the pipeline: the same on every rank
+        fit = min(int(x[0]) for x in shard.gather_words(np.array([fit], dtype=np.uint32), [1] * shard.world))
+    if fit < asked and shard.rank == 0:
+        print(f'  {fit} of the {asked} batches in flight asked for fit into the free device memory', file=output)
+    pool = _BatchPool(engine, fit)
     timing['create_engines'] = time.perf_counter() - t0
     ring = None
     if shard.rank == 0:
@@ -602,6 +629,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         timing['retries'] = sum(getattr(e, 'retries', 0) for e in pool.engines if e is not None)
         timing['device_batch_seconds_avg'] = pool.job_seconds / max(pool.job_count, 1.0)
         timing['wait_for_engine'] = pool.wait_engine_seconds
+        timing['engines'] = len(pool.engines)
         timing['create_clones_thread_seconds'] = pool.create_seconds
     if shard.rank == 0:
         print('\n', file=output)
