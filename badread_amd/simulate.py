@@ -497,6 +497,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         print_progress(count, total, target_size, output)
     timing = run_batches.last_timing = collections.Counter()     # seconds of the consumer thread per activity (bench.py --d2h)
     t0 = time.perf_counter()
+    t_job = t0
     if hasattr(engine, 'presize'):               # the arena of the first engine (the clones copy its size) for the batches this job will issue
         first_batch = plan_batch(target_size, expected_mean, shard.world, max_batch) // shard.world
         engine.presize(first_batch, expected_mean)
@@ -630,6 +631,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         timing['device_batch_seconds_avg'] = pool.job_seconds / max(pool.job_count, 1.0)
         timing['wait_for_engine'] = pool.wait_engine_seconds
         timing['engines'] = len(pool.engines)
+        timing['run_batches_seconds'] = time.perf_counter() - t_job
         timing['create_clones_thread_seconds'] = pool.create_seconds
     if shard.rank == 0:
         print('\n', file=output)
@@ -698,6 +700,10 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
                          in_flight=getattr(args, 'gpu_streams', None) or DEFAULT_IN_FLIGHT, device_gzip=device_gzip)
     if sink is not None and hasattr(sink, 'flush'):
         sink.flush()
+    if os.environ.get('BRX_DRIVER_TIMING') and shard.rank == 0:      # seconds of the consumer thread per activity + rate, for tools/cli_30x.sh
+        t = dict(run_batches.last_timing)
+        t['bases'], t['reads'] = result[1], result[0]
+        print('driver_timing ' + repr({k: round(float(v), 3) for k, v in t.items()}), file=sys.stderr)
     return result
 
 

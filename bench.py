@@ -540,8 +540,9 @@ def main():
         result['roofline_alu'] = {'bound': 'valu-issue', 'achieved': rate, 'peak': VALU_PEAK_PER_S, 'peak_source': 'profiles/valu_rate.json (measured integer VALU issue rate: 4 cycles per wave64 instruction per SIMD)',
                                   'unit': 'wave-instructions/s', 'frac': rate / VALU_PEAK_PER_S,
                                   'peak_guide': 2.0 * VALU_PEAK_PER_S, 'frac_of_guide_peak': rate / (2.0 * VALU_PEAK_PER_S),
-                                  'peak_note': 'MI355X_MICROARCH.md quotes a 2-cycle issue for 32-bit VALU ops; tools/native/valu_bench.hip measures 4 cycles for the '
-                                               'integer ops of this path AND for its v_fma_f32 control (profiles/valu_rate.json): both fractions are given',
+                                  'peak_note': 'MI355X_MICROARCH.md quotes a 2-cycle issue for 32-bit VALU ops; tools/native/valu_bench.hip reaches that rate only with fp32 FMA '
+                                               '(control kernel: 1.07e12 FMA/s, issued as 5.3e11 v_pk_fma_f32/s) and measures 3.75 cycles for the integer ops of this path '
+                                               '(v_and / v_add / v_bitop3 / v_alignbit; profiles/valu_rate.json): both fractions are given',
                                   'valu_per_base': vpb['valu_per_base'], 'source': vpb.get('source'),
                                   'counted_on_tree': vpb.get('csrc_sha16'), 'this_tree': tree,
                                   'stale': vpb.get('csrc_sha16') != tree,        # the instruction count was taken on other kernel sources: repeat tools/profile_round.sh

@@ -1,7 +1,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}; out=gpurun_out
 timeout 420 python bench.py --d2h --steps 16 --d2h-legs devnull_cold,devnull,gzip_device --cpu-seconds 0 > $out/r03_bench_d2h.json 2> $out/r03_bench_d2h.err
 echo rc=$?
-timeout 330 python bench.py --d2h --steps 16 --reads-per-step 294912 --d2h-legs devnull_cold,devnull --cpu-seconds 0 > $out/r03_bench_d2h_49152.json 2> $out/r03_bench_d2h_49152.err
+timeout 330 python bench.py --d2h --steps 16 --reads-per-step 294912 --scratch-gb 36 --d2h-legs devnull_cold,devnull --cpu-seconds 0 > $out/r03_bench_d2h_49152.json 2> $out/r03_bench_d2h_49152.err
 echo rc=$?
 for f in r03_bench_d2h r03_bench_d2h_49152; do python - <<PY
 import json
