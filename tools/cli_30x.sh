@@ -1,23 +1,23 @@
 #!/bin/bash
 # The product command on BASELINE.json configs[3] as a user runs it: `badread simulate --reference GRCh38-like.fa --quantity 30x`
 # in a fresh process, FASTQ to /dev/null; wall time of the whole command and of the read loop (run_batches).
-cd ${GRAFT_REPO_ROOT:-/root/repo}; out=gpurun_out; q=${1:-30x}
+cd ${GRAFT_REPO_ROOT:-/root/repo}; out=gpurun_out; q=${1:-30x}; extra=${2:-}; tag=${q}${extra//[^a-z]/}
 fa=$(python -c "import sys; sys.path.insert(0,'tools'); import bench; print(bench.reference_fasta('human', bench.default_ref_dir()))")
 python -m badread_amd simulate --reference $fa --quantity 1x --seed 1 > /dev/null 2> $out/cli_warm.err      # packs the FASTA (sidecar), builds nothing else
 t0=$(date +%s.%N)
-BRX_DRIVER_TIMING=1 timeout 400 python -m badread_amd simulate --reference $fa --quantity $q --seed 42 > /dev/null 2> $out/cli_${q}.err
+BRX_DRIVER_TIMING=1 timeout 400 python -m badread_amd simulate --reference $fa --quantity $q --seed 42 $extra > /dev/null 2> $out/cli_${tag}.err
 rc=$?
 t1=$(date +%s.%N)
-grep -a driver_timing $out/cli_${q}.err | tail -1 > $out/cli_${q}.timing
+grep -a driver_timing $out/cli_${tag}.err | tail -1 > $out/cli_${tag}.timing
 python - <<PY
 import ast, json
-line = open('$out/cli_${q}.timing').read().strip()
+line = open('$out/cli_${tag}.timing').read().strip()
 t = ast.literal_eval(line.split(' ', 1)[1]) if line else {}
 wall = $t1 - $t0
-res = {'command': 'python -m badread_amd simulate --reference grch38_like.fa --quantity $q --seed 42 > /dev/null', 'rc': $rc, 'wall_seconds': round(wall, 2),
+res = {'command': 'python -m badread_amd simulate --reference grch38_like.fa --quantity $q --seed 42 $extra > /dev/null', 'rc': $rc, 'wall_seconds': round(wall, 2),
        'bases': t.get('bases'), 'reads': t.get('reads'), 'gbases_per_s_whole_command': round(t.get('bases', 0) / wall / 1e9, 3),
        'gbases_per_s_read_loop': round(t.get('bases', 0) / max(t.get('run_batches_seconds', 1e9), 1e-9) / 1e9, 3), 'driver_timing': t}
 print(json.dumps(res))
-open('$out/r03_cli_${q}.json', 'w').write(json.dumps(res, indent=1))
+open('$out/r03_cli_${tag}.json', 'w').write(json.dumps(res, indent=1))
 PY
-tail -c 400 $out/cli_${q}.err | tr '\r' '\n' | tail -4
+tail -c 400 $out/cli_${tag}.err | tr '\r' '\n' | tail -4
