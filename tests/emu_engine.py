@@ -24,8 +24,7 @@ _variants = {}
 
 
 def build(defines=()):
-    """The interpreted library; `defines` selects a build variant of the kernels (e.g. ('-DBRX_SEG_WAVES=8',
-    '-DBRX_SEG_THR_ROWS=16384'): pass kernels as 8-wave workgroups with the self thresholds in LDS)."""
+    """The interpreted library; `defines` selects a build variant of the kernels (-D macros for the product sources)."""
     global _lib
     key = tuple(defines)
     if key in _variants:

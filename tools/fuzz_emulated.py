@@ -21,7 +21,8 @@ MODELS = ['random', 'nanopore2018', 'nanopore2020', 'nanopore2023', 'pacbio2016'
 QMODELS = ['random', 'ideal', 'nanopore2018', 'nanopore2020', 'nanopore2023', 'pacbio2016', 'pacbio2021']
 ROUTES = [{}, {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '0'}, {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '1000000'},
           {'BRX_TB_WINDOW': '-1'}, {'BRX_TB_WINDOW': '0'}, {'BRX_TB_WINDOW': '1'}, {'BRX_MUTATE_INLINE': '1'},
-          {'BRX_TAIL_READS': '3'}, {'BRX_FIN_BALANCE': '0'}]
+          {'BRX_TAIL_READS': '3'}, {'BRX_WAVES_PER_CU': '1'}, {'BRX_WAVES_PER_CU': '2', 'BRX_TB_WINDOW': '-1'},      # few slabs per band class
+          {'BRX_LANE_WAVES': '1', 'BRX_TAIL_READS': '0', 'BRX_HEAD_READS': '0', 'BRX_LANE_THRESHOLD': '0'}]
 
 
 def draw_case(rng):
