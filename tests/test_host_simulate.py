@@ -181,3 +181,38 @@ def test_batches_in_flight_do_not_change_the_output(monkeypatch):
     for streams, mb in ((3, 16), (4, 5), (2, 4096)):
         got, _, c2, t2 = run(Args(quantity='40x', gpu_streams=streams), max_batch=mb, monkeypatch=monkeypatch)
         assert got == base and (c2, t2) == (count, total), (streams, mb)
+
+
+def test_batches_in_flight_follow_the_free_device_memory(monkeypatch):
+    """_BatchPool.engines_that_fit: clones map an arena as large as the first engine's, every engine owns an output buffer,
+    in_flight + 2 copies of a batch may wait for the consumer, and a reserve stays free for the runtime's own allocations."""
+    GB = 1 << 30
+
+    class FakeCuda(object):
+        def __init__(self, free):
+            self.free = free
+        def empty_cache(self):
+            pass
+        def mem_get_info(self, device):
+            return self.free, 288 * GB
+
+    class FakeTorch(object):
+        pass
+
+    class FakeEngine(object):
+        device = 'cuda:0'
+        def scratch_bytes(self):
+            return 40 * GB
+
+    t = FakeTorch()
+    monkeypatch.delenv('BRX_DRIVER_RESERVE_GB', raising=False)
+    fit = S._BatchPool.engines_that_fit
+    t.cuda = FakeCuda(247 * GB)          # a fresh process after the first 40 GB arena and the reference: five clones + 14 buffers of 2 GB + 24 GB
+    assert fit(t, FakeEngine(), 6, 2 * GB) == 5
+    t.cuda = FakeCuda(260 * GB)
+    assert fit(t, FakeEngine(), 6, 2 * GB) == 6
+    t.cuda = FakeCuda(10 * GB)           # never below one engine: the first one exists already
+    assert fit(t, FakeEngine(), 6, 2 * GB) == 1
+    monkeypatch.setenv('BRX_DRIVER_RESERVE_GB', '0')
+    t.cuda = FakeCuda(229 * GB)
+    assert fit(t, FakeEngine(), 6, 2 * GB) == 6
