@@ -510,17 +510,18 @@ def main():
     bases_per_launch = kb / n_l
     algo_bytes = ALGO_BYTES_PER_BASE * bases_per_launch
     achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
-    traffic = None
+    traffic = traffic_tree = None
     tfile = os.path.join(REPO, 'profiles', 'pmc_traffic.json')
     if os.path.isfile(tfile):
         try:
             rec = json.load(open(tfile))
             if rec.get('reads_per_step') == R and rec.get('kernel') == top and rec.get('workload', 'kpn') == args.workload:
                 traffic = rec.get('hbm_bytes_per_launch')
+                traffic_tree = rec.get('csrc_sha16')
         except (OSError, ValueError):
             pass
     result['roofline'] = {'bound': 'hbm', 'kernel': top, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_counted_on_tree': traffic_tree,
                           'algorithmic_bytes_per_launch': algo_bytes, 'bases_per_launch': bases_per_launch,
                           'launch_ms': launch_ms, 'launches_per_device_batch': n_l / n_batches,
                           'whole_path_frac': value / world * ALGO_BYTES_PER_BASE / 1e9 / HBM_PEAK_GBS,

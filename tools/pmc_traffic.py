@@ -8,7 +8,10 @@ WRITE_SIZE is taken as reported.  The correction was calibrated there on wide st
 are narrow (target bytes, traceback words), so the read half is an upper estimate."""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
@@ -26,7 +29,8 @@ def main():
     fetch, nf = vals['FETCH_SIZE']
     write, nw = vals['WRITE_SIZE']
     fetch, write = fetch / (full or nf), write / (full or nw)
-    json.dump({'kernel': label, 'rocprof_name': kernel, 'workload': workload, 'reads_per_step': reads,
+    from badread_amd.build import source_hash          # run on the tree the counters were collected on (tools/profile_round.sh does)
+    json.dump({'kernel': label, 'rocprof_name': kernel, 'workload': workload, 'reads_per_step': reads, 'csrc_sha16': source_hash(),
                'FETCH_SIZE_KB_per_launch': fetch, 'WRITE_SIZE_KB_per_launch': write,
                'hbm_bytes_per_launch': (2.0 * fetch + write) * 1024.0,
                'note': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh: bench.py --steps 1 '
