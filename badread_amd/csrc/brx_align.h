@@ -106,7 +106,7 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul =
     if (g.WSp > g.NS) g.WSp = g.NS;
     if (g.WSp < 1) g.WSp = 1;
     g.K = 1;
-    g.U = G == 1 ? BRX_U1 : 1;
+    g.U = G == 1 ? BRX_U1 : G == 2 ? 4 : G == 4 ? 2 : 1;           /* G * U = 8 words of {Pv, Ph} per lane and trip */
     g.t_end = (T + g.NS - 1 + g.U - 1) / g.U * g.U;                 /* whole trips: the last one may run past time T + NS - 1 */
     g.H = BRX_H_ALL; g.slope = 0;
     if (hmul != 0 && G <= 16 && T > 0 && (uint64_t)Q < ((uint64_t)T << 11)) {
@@ -584,10 +584,12 @@ __device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32
 __device__ __forceinline__ uint32_t brx_funnel_bytes(uint32_t hi, uint32_t lo, uint32_t nbytes) {   /* v_alignbyte_b32 */
     return (uint32_t)((((uint64_t)hi << 32) | (uint64_t)lo) >> (8u * (nbytes & 3u)));
 }
-template <int U>
+template <int U, int G>
 __device__ inline void brx_align_forward_u(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
                                            const BrxGeom g, uint2 *__restrict__ tb, const uint2 *__restrict__ planes) {
-    static_assert(U == 8, "eight columns per trip");
+    static_assert(U == 8 || U == 4 || U == 2, "columns per trip");
+    static_assert(G * U <= 8, "G words per lane, U columns per trip");
+    constexpr int LU = U == 8 ? 3 : U == 4 ? 2 : 1;  /* log2 U */
     const int lane = threadIdx.x & 63;
     uint32_t *const ring32 = brx_ring32;
     /* the store base is the same in every lane: say so (and that it is global memory), and the traceback stores take the
@@ -603,22 +605,24 @@ __device__ inline void brx_align_forward_u(const uint8_t *__restrict__ Qs, const
                                                        iff (uint32_t)(tau - tf) <= tspan                                  */
     uint32_t tspan = 0;
     /* windowed traceback store (brx_stored): superblock s is written in trip tau iff
-       (uint32_t)(keep_base - ((slope * brx_jrep) >> 20)) <= keep_lim, brx_jrep = max(8 tau + 4 - s, 0) */
+       (uint32_t)(keep_base - ((slope * brx_jrep) >> 20)) <= keep_lim, brx_jrep = max(U tau + U / 2 - s, 0) */
     const uint32_t keep_lim = (uint32_t)(2 * g.H + g.R - 1);
     int keep_base = 0;
     auto window = [&]() {                            /* everything that depends on s */
         tf = NEVER; tl = NEVER; tspan = 0;
         if (s < g.NS) {
             const int jf = brx_jfirst(g, s), jl = brx_jlast(g, s);
-            slot8 = 8u * (uint32_t)slot;
-            tl = (jl + s - 1) >> 3;
-            if (jl >= jf) { tf = (jf + s - 1) >> 3; tspan = (uint32_t)(tl - tf); }   /* empty window: never active, but it still hops at tl */
+            slot8 = 8u * (uint32_t)G * (uint32_t)slot;
+            tl = (jl + s - 1) >> LU;
+            if (jl >= jf) { tf = (jf + s - 1) >> LU; tspan = (uint32_t)(tl - tf); }   /* empty window: never active, but it still hops at tl */
         }
         keep_base = g.R * s + g.H + g.R - 1;
     };
     window();
-    uint32_t Pv = 0xFFFFFFFFu, Mv = 0;
-    BrxQPlanes qp = {0u, 0u, 0u, 0u};
+    uint32_t Pv[G], Mv[G];
+    BrxQPlanes qp[G];
+#pragma unroll
+    for (int x = 0; x < G; ++x) { Pv[x] = 0xFFFFFFFFu; Mv[x] = 0; qp[x] = BrxQPlanes{0u, 0u, 0u, 0u}; }
     constexpr uint32_t IDLE = 0x80000000u;          /* carry word: bit 31 = hout is +1, bit 0 = hout is -1.  An idle lane hands on +1
                                                        (the cells above the band grow by one per column) */
     uint32_t carry = IDLE;
@@ -642,34 +646,35 @@ __device__ inline void brx_align_forward_u(const uint8_t *__restrict__ Qs, const
         odd |= chunk_odd(c, pending) << c;
     }
     int s_top = 0;                                  /* first superblock still inside the band (uniform) */
-    int tl_top = (brx_jlast(g, 0) + 0 - 1) >> 3;    /* its last trip                                     */
+    int tl_top = (brx_jlast(g, 0) + 0 - 1) >> LU;   /* its last trip                                     */
     int next_mark = 64;                             /* next multiple of 64 the front byte crosses: refill events */
     /* entries and exits happen in superblock order: scalar bookkeeping.  Near the corners several superblocks can enter or
        leave in one trip (their windows are clamped to column 1 / column T and their times differ by one column) */
-    auto tf_of = [&](int x) { return (brx_jfirst(g, x) + x - 1) >> 3; };
-    auto tl_of = [&](int x) { return (brx_jlast(g, x) + x - 1) >> 3; };
+    auto tf_of = [&](int x) { return (brx_jfirst(g, x) + x - 1) >> LU; };
+    auto tl_of = [&](int x) { return (brx_jlast(g, x) + x - 1) >> LU; };
     int e_s = 0, h_s = 0;
     while (e_s < g.NS && brx_jlast(g, e_s) < brx_jfirst(g, e_s)) ++e_s;
     int next_entry = e_s < g.NS ? tf_of(e_s) : NEVER;
     int next_hop = g.NS > 0 ? tl_of(0) : NEVER;
-    const int tau_end = (g.T + g.NS - 1 - 1) >> 3;
+    const int tau_end = (g.T + g.NS - 1 - 1) >> LU;
     /* trips in which a lane of the first 64 superblocks would compute columns left of column 1 */
-    int sv = (g.dhi + 6) / 32;
+    int sv = (g.dhi + U - 2) / g.R;
     if (sv > g.NS - 1) sv = g.NS - 1;
     if (sv > 63) sv = 63;
     const int tau_pro = sv >= 1 ? tf_of(sv) : -1;
     const size_t wsp = (size_t)g.WSp;
-    /* traceback rows 8 tau + 1 .. 8 tau + 8 (uniform addresses); a lane writes at byte slot8 of each */
-    BRX_GLOBAL char *row0 = (BRX_GLOBAL char *)((BRX_GLOBAL uint64_t *)tb_addr + wsp);
-    const size_t row_bytes = 8 * wsp;
-    const size_t trip_bytes = 8 * (size_t)U * wsp;
-    /* the lane's eight target bytes of a trip: ring bytes 8 tau - s .. 8 tau - s + 7, an unaligned window of three words */
+    /* traceback rows U tau + 1 .. U tau + U (uniform addresses); a lane writes G words at byte slot8 of each */
+    BRX_GLOBAL char *row0 = (BRX_GLOBAL char *)((BRX_GLOBAL uint64_t *)tb_addr + wsp * (size_t)G);
+    const size_t row_bytes = 8 * wsp * (size_t)G;
+    const size_t trip_bytes = (size_t)U * row_bytes;
+    /* the lane's U target bytes of a trip: ring bytes U tau - s .. U tau - s + U - 1, an unaligned window of two or three words */
     auto ring_bytes = [&](int tau_, uint32_t *x0, uint32_t *x1) {
         const uint32_t b0 = (uint32_t)(U * tau_ - s);
         const uint32_t d = b0 >> 2;
-        const uint32_t w0 = ring32[d & (BRX_RING_BYTES / 4 - 1)], w1 = ring32[(d + 1) & (BRX_RING_BYTES / 4 - 1)],
-                       w2 = ring32[(d + 2) & (BRX_RING_BYTES / 4 - 1)];
-        *x0 = brx_funnel_bytes(w1, w0, b0); *x1 = brx_funnel_bytes(w2, w1, b0);
+        const uint32_t w0 = ring32[d & (BRX_RING_BYTES / 4 - 1)], w1 = ring32[(d + 1) & (BRX_RING_BYTES / 4 - 1)];
+        *x0 = brx_funnel_bytes(w1, w0, b0);
+        if constexpr (U == 8) { const uint32_t w2 = ring32[(d + 2) & (BRX_RING_BYTES / 4 - 1)]; *x1 = brx_funnel_bytes(w2, w1, b0); }
+        else *x1 = 0u;
     };
     uint32_t xn0, xn1;
     ring_bytes(0, &xn0, &xn1);
@@ -695,14 +700,18 @@ __device__ inline void brx_align_forward_u(const uint8_t *__restrict__ Qs, const
         /* ---- superblocks enter the band: read their query planes ---- */
         if (__builtin_expect(tau == next_entry, 0)) {
             if (tau == tf) {
-                Pv = 0xFFFFFFFFu; Mv = 0;                         /* cells below the band grow by +1 per row */
-                qp = brx_load_planes(planes, s);
+#pragma unroll
+                for (int x = 0; x < G; ++x) {
+                    Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;               /* cells below the band grow by +1 per row */
+                    const int w = s * G + x;
+                    qp[x] = w < g.NW ? brx_load_planes(planes, w) : BrxQPlanes{0u, 0u, 0u, 0u};
+                }
             }
             do { ++e_s; } while (e_s < g.NS && (brx_jlast(g, e_s) < brx_jfirst(g, e_s) || tf_of(e_s) <= tau));
             next_entry = e_s < g.NS ? tf_of(e_s) : NEVER;
         }
 
-        /* ---- eight column updates, straight-line ---- */
+        /* ---- U column updates, straight-line ---- */
         const uint32_t x0 = xn0, x1 = xn1;
         const bool act = (uint32_t)(tau - tf) <= tspan;
         int jr = U * tau + U / 2 - s;
@@ -715,7 +724,9 @@ __device__ inline void brx_align_forward_u(const uint8_t *__restrict__ Qs, const
             for (int c = 0; c < U; ++c) lr |= (((c < 4 ? x0 : x1) >> (8 * (c & 3))) & 0xFFu) > 3u;
             rare = rare || __ballot(lr && act) != 0ull;
         }
-        uint32_t P = Pv, M = Mv;
+        uint32_t P[G], M[G];
+#pragma unroll
+        for (int x = 0; x < G; ++x) { P[x] = Pv[x]; M[x] = Mv[x]; }
         if (__builtin_expect(rare, 0)) {
             /* rolled: symbols outside A/C/G/T, and the corner trips whose columns may lie left of column 1 */
 #pragma unroll 1
@@ -723,55 +734,71 @@ __device__ inline void brx_align_forward_u(const uint8_t *__restrict__ Qs, const
                 const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
                 const int j = U * tau + c + 1 - s;
                 const bool real = act && j >= 1;
-                const uint32_t hm = nb & 1u, hp = nb >> 31;
+                uint32_t hm = nb & 1u, hp = nb >> 31;
                 const uint32_t ch = ((c < 4 ? x0 : x1) >> (8 * (c & 3))) & 0xFFu;
-                uint32_t Eq = brx_eq_acgt(qp, 0u - (ch & 1u), 0u - ((ch >> 1) & 1u));
-                if (ch == 4u) Eq = qp.n;
-                if (real && ch > 4u) {                            /* inline, rolled: a call would impose the callee's registers */
-                    uint32_t mq = 0;
+                BRX_GLOBAL uint64_t *dst = (BRX_GLOBAL uint64_t *)(row0 + (size_t)c * row_bytes + slot8);
+#pragma unroll
+                for (int x = 0; x < G; ++x) {
+                    uint32_t Eq = brx_eq_acgt(qp[x], 0u - (ch & 1u), 0u - ((ch >> 1) & 1u));
+                    if (ch == 4u) Eq = qp[x].n;
+                    if (real && ch > 4u && s * G + x < g.NW) {    /* inline, rolled: a call would impose the callee's registers */
+                        uint32_t mq = 0;
 #pragma unroll 1
-                    for (int rr = 0; rr < 32; ++rr) { const int qi = 32 * s + rr; if (qi < g.Q && Qs[qi] == ch) mq |= 1u << rr; }
-                    Eq = mq;
+                        for (int rr = 0; rr < 32; ++rr) { const int qi = 32 * (s * G + x) + rr; if (qi < g.Q && Qs[qi] == ch) mq |= 1u << rr; }
+                        Eq = mq;
+                    }
+                    const uint32_t Xv = Eq | M[x];
+                    const uint32_t Eq2 = Eq | hm;
+                    const uint32_t Xh = (((Eq2 & P[x]) + P[x]) ^ P[x]) | Eq2;
+                    const uint32_t Ph = M[x] | ~(Xh | P[x]);
+                    const uint32_t Mh = P[x] & Xh;
+                    const uint32_t PhS = (Ph << 1) | hp;
+                    const uint32_t MhS = (Mh << 1) | hm;
+                    const uint32_t Pn = MhS | ~(Xv | PhS), Mn = PhS & Xv;
+                    if (real) { P[x] = Pn; M[x] = Mn; }
+                    if (real && keep) dst[x] = ((uint64_t)Ph << 32) | (uint64_t)Pn;
+                    hp = Ph >> 31; hm = Mh >> 31;
                 }
-                const uint32_t Xv = Eq | M;
-                const uint32_t Eq2 = Eq | hm;
-                const uint32_t Xh = (((Eq2 & P) + P) ^ P) | Eq2;
-                const uint32_t Ph = M | ~(Xh | P);
-                const uint32_t Mh = P & Xh;
-                const uint32_t PhS = (Ph << 1) | hp;
-                const uint32_t MhS = (Mh << 1) | hm;
-                const uint32_t Pn = MhS | ~(Xv | PhS), Mn = PhS & Xv;
-                if (real) { P = Pn; M = Mn; }
-                if (real && keep) *(BRX_GLOBAL uint64_t *)(row0 + (size_t)c * row_bytes + slot8) = ((uint64_t)Ph << 32) | (uint64_t)Pn;
-                carry = real ? ((Ph & 0x80000000u) | (Mh >> 31)) : IDLE;
+                carry = real ? ((hp << 31) | hm) : IDLE;
             }
         } else {
-            uint32_t pvs[U], phs[U];
+            uint32_t pvs[U][G], phs[U][G];
 #pragma unroll
             for (int c = 0; c < U; ++c) {
                 const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
                 const uint32_t w = c < 4 ? x0 : x1;
-                const uint32_t Eq = brx_eq_acgt(qp, brx_bit_mask(w, 8 * (c & 3)), brx_bit_mask(w, 8 * (c & 3) + 1));
-                const uint32_t hm = nb & 1u;
-                const uint32_t Xv = Eq | M;
-                const uint32_t Eq2 = Eq | hm;
-                const uint32_t Xh = (((Eq2 & P) + P) ^ P) | Eq2;
-                const uint32_t Ph = M | ~(Xh | P);
-                const uint32_t Mh = P & Xh;
-                const uint32_t PhS = __builtin_amdgcn_alignbit(Ph, nb, 31);     /* Ph << 1 | hp */
-                const uint32_t MhS = (Mh << 1) | hm;
-                P = MhS | ~(Xv | PhS);
-                M = PhS & Xv;
-                pvs[c] = P; phs[c] = Ph;
+                const uint32_t k0 = brx_bit_mask(w, 8 * (c & 3)), k1 = brx_bit_mask(w, 8 * (c & 3) + 1);
+                uint32_t hm = nb & 1u;
+                uint32_t hpw = nb;                                 /* hp in bit 31 */
+                uint32_t Ph = 0, Mh = 0;
+#pragma unroll
+                for (int x = 0; x < G; ++x) {
+                    const uint32_t Eq = brx_eq_acgt(qp[x], k0, k1);
+                    const uint32_t Xv = Eq | M[x];
+                    const uint32_t Eq2 = Eq | hm;
+                    const uint32_t Xh = (((Eq2 & P[x]) + P[x]) ^ P[x]) | Eq2;
+                    Ph = M[x] | ~(Xh | P[x]);
+                    Mh = P[x] & Xh;
+                    const uint32_t PhS = __builtin_amdgcn_alignbit(Ph, hpw, 31);     /* Ph << 1 | hp */
+                    const uint32_t MhS = (Mh << 1) | hm;
+                    P[x] = MhS | ~(Xv | PhS);
+                    M[x] = PhS & Xv;
+                    pvs[c][x] = P[x]; phs[c][x] = Ph;
+                    hpw = Ph; hm = Mh >> 31;
+                }
                 carry = act ? ((Ph & 0x80000000u) | (Mh >> 31)) : IDLE;
             }
-            if (act && keep) {                                     /* uint2 {pv, Ph} per column: U stores with scalar row bases */
+            if (act && keep) {                                     /* uint2 {pv, Ph} per word and column: stores with scalar row bases */
 #pragma unroll
-                for (int c = 0; c < U; ++c) *(BRX_GLOBAL uint64_t *)(row0 + (size_t)c * row_bytes + slot8) = ((uint64_t)phs[c] << 32) | (uint64_t)pvs[c];
+                for (int c = 0; c < U; ++c) {
+                    BRX_GLOBAL uint64_t *dst = (BRX_GLOBAL uint64_t *)(row0 + (size_t)c * row_bytes + slot8);
+#pragma unroll
+                    for (int x = 0; x < G; ++x) dst[x] = ((uint64_t)phs[c][x] << 32) | (uint64_t)pvs[c][x];
+                }
             }
         }
-        Pv = act ? P : Pv;
-        Mv = act ? M : Mv;
+#pragma unroll
+        for (int x = 0; x < G; ++x) { Pv[x] = act ? P[x] : Pv[x]; Mv[x] = act ? M[x] : Mv[x]; }
 
         /* ---- superblocks leave the band: their lanes take superblock s + 64 ---- */
         if (__builtin_expect(tau == next_hop, 0)) {
@@ -806,9 +833,9 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
     brx_build_planes(Qs, g, planes);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);                    /* the table is read back by other lanes of this wave */
-    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_u<BRX_U1>(Qs, Ts, g, tb, planes); return; } }
-    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, planes, prog); return; } }
-    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, planes, prog); return; } }
+    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_u<BRX_U1, 1>(Qs, Ts, g, tb, planes); return; } }
+    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward_u<4, 2>(Qs, Ts, g, tb, planes); return; } }
+    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward_u<2, 4>(Qs, Ts, g, tb, planes); return; } }
     if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, planes, prog); return; } }
     if constexpr (MAXG >= 16 && MING <= 16) { if (g.G == 16) { brx_align_forward<16>(Qs, Ts, g, tb, planes, prog); return; } }
 }
