@@ -50,18 +50,16 @@
              __hip_atomic_store((prog) + 8 * blockIdx.x + (slot), (uint32_t)(val), __ATOMIC_RELAXED,  \
                                 __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
 
-#ifndef BRX_K1
-#define BRX_K1 8       /* columns per loop trip of the one-word-per-lane forward pass (4 or 8; 8 measured faster) */
-#endif
+#define BRX_U1 8       /* columns per loop trip of the one-word-per-lane forward pass */
 struct BrxGeom {
     int Q, T;          /* query rows, target columns                              */
     int dlo, dhi;      /* band of diagonals i-j                                   */
     int G, R;          /* words per lane, rows per superblock (32*G)              */
     int NS, NW;        /* superblocks, 32-row words                               */
     int WSp;           /* band slots per time step in the traceback store         */
-    int K;             /* time skew between neighbouring superblocks: superblock s handles column j at
-                          time j + K*s.  K = BRX_K1 for G = 1 (that many columns per loop trip), else 1     */
-    int t_end;         /* last traceback row = T (G = 1: rounded up to a multiple of K) + K*(NS - 1) */
+    int K;             /* time skew between neighbouring superblocks: superblock s handles column j at time j + K*s (1) */
+    int U;             /* columns per loop trip of the forward pass (BRX_U1 for G = 1, else 1): the windowed store is decided per trip */
+    int t_end;         /* last traceback row = T + NS - 1 (G = 1: rounded up to whole trips) */
     int H;             /* windowed traceback store: only superblocks within H rows of the straight line
                           row = column * Q / T are written (BRX_H_ALL: every superblock of the band)    */
     uint32_t slope;    /* Q / T with 20 fractional bits (0 when the store is not windowed)               */
@@ -100,15 +98,16 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul =
     int bw = g.dhi - g.dlo + 1;
     int G = 1;
     while (G <= BRX_GEOM_MAXG && (long long)bw > 56ll * 32ll * G) G *= 2;
-    if (G > BRX_GEOM_MAXG) { g.G = 0; g.R = 0; g.NS = 0; g.NW = 0; g.WSp = 0; g.K = 1; g.t_end = 0; return g; }
+    if (G > BRX_GEOM_MAXG) { g.G = 0; g.R = 0; g.NS = 0; g.NW = 0; g.WSp = 0; g.K = 1; g.U = 1; g.t_end = 0; return g; }
     g.G = G; g.R = 32 * G;
     g.NW = (Q + 31) / 32;
     g.NS = (Q + g.R - 1) / g.R;
     g.WSp = (bw + g.R - 2) / (g.R + 1) + 2;
     if (g.WSp > g.NS) g.WSp = g.NS;
     if (g.WSp < 1) g.WSp = 1;
-    g.K = G == 1 ? BRX_K1 : 1;
-    g.t_end = (T + g.K - 1) / g.K * g.K + g.K * (g.NS - 1);        /* whole trips: the last one may run past column T */
+    g.K = 1;
+    g.U = G == 1 ? BRX_U1 : G == 2 ? 4 : G == 4 ? 2 : 1;           /* G * U = 8 words of {Pv, Ph} per lane and trip */
+    g.t_end = (T + g.NS - 1 + g.U - 1) / g.U * g.U;                 /* whole trips: the last one may run past time T + NS - 1 */
     g.H = BRX_H_ALL; g.slope = 0;
     if (hmul != 0 && G <= 16 && T > 0 && (uint64_t)Q < ((uint64_t)T << 11)) {
         const int H = hmul > 0 ? hmul * (int)brx_isqrt((uint32_t)k) + 24 : 8;
@@ -127,7 +126,13 @@ __host__ __device__ __forceinline__ bool brx_stored(const BrxGeom &g, int s, int
     const int a = g.R * s + g.H + g.R - 1 - c;
     return (uint32_t)a <= (uint32_t)(2 * g.H + g.R - 1);
 }
-__host__ __device__ __forceinline__ int brx_jrep(const BrxGeom &g, int j) { return g.K > 1 ? (((j - 1) & ~(g.K - 1)) + g.K / 2) : j; }
+/* the column that stands for column j of superblock s in the windowed-store test: the middle one of the loop trip that
+   computes it (time j + s), never below 0 */
+__host__ __device__ __forceinline__ int brx_jrep(const BrxGeom &g, int s, int j) {
+    if (g.U == 1) return j;
+    const int jr = ((j + s - 1) & ~(g.U - 1)) + g.U / 2 - s;
+    return jr > 0 ? jr : 0;
+}
 
 /* 8-byte units of traceback storage an alignment needs */
 __host__ __device__ inline uint64_t brx_tb_units(const BrxGeom &g) {
@@ -181,7 +186,7 @@ __device__ __noinline__ uint32_t brx_eq_rare(const uint8_t *Qs, int Q, int w, ui
 
 /* lane i receives the value of lane (i - 1) mod 64: DPP wave_ror:1, two VALU cycles, no LDS traffic */
 __device__ __forceinline__ int brx_from_lane_above(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);     /* every lane is written: no old value to preserve (update_dpp costs a move for it) */
 }
 
 #define BRX_RING_BYTES 2048         /* per-wave LDS window of target bytes (eight 256-byte chunks; the one-column-per-trip passes use two) */
@@ -424,7 +429,7 @@ __device__ inline bool brx_align_traceback(const uint8_t *__restrict__ Qs, const
             const int ci = I0 - lane, cj = J0 - lane;
             if (ci >= 1 && cj >= 1) {
                 const int s = (ci - 1) >> shiftR;
-                if (cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s) && brx_stored(g, s, brx_jrep(g, cj))) {
+                if (cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s) && brx_stored(g, s, brx_jrep(g, s, cj))) {
                     const int x = ((ci - 1) & (g.R - 1)) >> 5;
                     const uint2 v = tb[((size_t)(cj + g.K * s) * (size_t)g.WSp + (size_t)(s % g.WSp)) * (size_t)g.G + (size_t)x];
                     w_pv = v.x; w_ph = v.y; tag_word = (ci - 1) >> 5; tag_col = cj;
@@ -440,7 +445,7 @@ __device__ inline bool brx_align_traceback(const uint8_t *__restrict__ Qs, const
             bool cell = false;                                     /* inside the band and the stored window */
             if (mine) {
                 const int s = (ci - 1) >> shiftR;
-                cell = cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s) && brx_stored(g, s, brx_jrep(g, cj));
+                cell = cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s) && brx_stored(g, s, brx_jrep(g, s, cj));
             }
             const bool inhand = cell && tag_word == ((ci - 1) >> 5) && tag_col == cj && q_row == ci;
             const int bit = (ci - 1) & 31;
@@ -561,18 +566,30 @@ __device__ inline void brx_build_peq(const uint8_t *Qs, const BrxGeom &g, uint32
 }
 
 /* ---------------------------------------------------------------------------------------------
- * forward pass for G = 1, K = g.K columns per loop trip (K = 4 or 8): superblock s handles columns
- * K (tau - s) + 1 .. K (tau - s) + K in trip tau, so the lane above has finished exactly these K
- * columns one trip earlier and hands its K carries over in one DPP word.  The loop bookkeeping
- * (time tests, ring refill, lane hops, pointer arithmetic, activity and window tests: ~32 vector and as
- * many scalar instructions) is paid once per K columns of ~19 vector instructions each: 27 per column at
- * K = 4 (round 2), 23 at K = 8.  Traceback row of column j of superblock s is j + K s = K tau + c + 1:
- * the same for every lane of a trip, so the stores stay slot-contiguous.
+ * forward pass for G = 1: a lag of ONE column between neighbouring superblocks, U = 8 columns per loop trip.
+ *
+ * Superblock s handles column j at time t = j + s (K = 1), so the lane above has finished this very column one
+ * micro-step earlier and its carry comes over by DPP in every micro-step.  A loop trip is eight micro-steps, t = 8 tau + 1
+ * .. 8 tau + 8: the loop bookkeeping (time tests, ring refill, lane hops, pointer arithmetic, activity and window tests) is
+ * paid once per eight columns as before, but a read of T columns and NS superblocks takes (T + NS - 1) / 8 trips instead of
+ * T / 8 + NS - 1 -- the round-3 schedule (a lag of one TRIP, the eight carries in one word) spent a quarter of its trips on
+ * fill and drain.  Traceback row of column j of superblock s is its time j + s = 8 tau + c + 1: the same for every lane of a
+ * micro-step, so the stores stay slot-contiguous.
+ *
+ * Lanes work in WHOLE trips, and a trip's columns 8 tau + c + 1 - s differ from lane to lane.  Widening a band window to trip
+ * boundaries computes up to seven columns more than the Ukkonen band on either side (harmless: upper bounds), but at the
+ * top-left corner the extra columns of superblocks 1 .. (dhi + 6) / 32 would lie left of column 1: the first trips
+ * (tau <= tau_pro, at most eight) take the rolled path, which skips columns below 1.
  * ------------------------------------------------------------------------------------------- */
-template <int K>
-__device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
-                                            const BrxGeom g, uint2 *__restrict__ tb, const uint2 *__restrict__ planes) {
-    static_assert(K == 4 || K == 8, "four or eight columns per trip");
+__device__ __forceinline__ uint32_t brx_funnel_bytes(uint32_t hi, uint32_t lo, uint32_t nbytes) {   /* v_alignbyte_b32 */
+    return (uint32_t)((((uint64_t)hi << 32) | (uint64_t)lo) >> (8u * (nbytes & 3u)));
+}
+template <int U, int G>
+__device__ inline void brx_align_forward_u(const uint8_t *__restrict__ Qs, const uint8_t *__restrict__ Ts,
+                                           const BrxGeom g, uint2 *__restrict__ tb, const uint2 *__restrict__ planes) {
+    static_assert(U == 8 || U == 4 || U == 2, "columns per trip");
+    static_assert(G * U <= 8, "G words per lane, U columns per trip");
+    constexpr int LU = U == 8 ? 3 : U == 4 ? 2 : 1;  /* log2 U */
     const int lane = threadIdx.x & 63;
     uint32_t *const ring32 = brx_ring32;
     /* the store base is the same in every lane: say so (and that it is global memory), and the traceback stores take the
@@ -580,11 +597,6 @@ __device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, cons
     const uint64_t tb_addr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)tb >> 32)) << 32) |
                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint64_t)tb);
     constexpr int NEVER = 0x7FFFFFFF;
-    /* A superblock works in WHOLE trips: trips tf .. tl, i.e. columns 4 (tf - s) + 1 .. 4 (tl - s) + 4 -- its band window
-       [jf, jl] widened to trip boundaries (up to K - 1 columns on either side, the last trip possibly past column T: those
-       bytes are padding and nothing reads their cells).  Computing more than the Ukkonen band is harmless (cells outside it
-       are upper bounds either way, cells inside are exact), and one activity test, one store predicate and one select of
-       the running Pv / Mv per trip replace four of each. */
     int s = lane;
     int slot = lane % g.WSp;                         /* s % WSp, kept incrementally: s moves by 64 */
     const int slot_step = 64 % g.WSp;
@@ -592,29 +604,28 @@ __device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, cons
     int tf = NEVER, tl = NEVER;                     /* first / last loop trip of the lane's superblock: trip tau is computed
                                                        iff (uint32_t)(tau - tf) <= tspan                                  */
     uint32_t tspan = 0;
-    /* windowed traceback store (brx_stored), incrementally: acc = slope * (middle column of the trip: brx_jrep), exact in 64 bits;
-       superblock s is written iff (uint32_t)(keep_base - (acc >> 20)) <= keep_lim */
+    /* windowed traceback store (brx_stored): superblock s is written in trip tau iff
+       (uint32_t)(keep_base - ((slope * brx_jrep) >> 20)) <= keep_lim, brx_jrep = max(U tau + U / 2 - s, 0) */
     const uint32_t keep_lim = (uint32_t)(2 * g.H + g.R - 1);
     int keep_base = 0;
-    int64_t acc = 0;
-    const int64_t acc_step = (int64_t)K * (int64_t)g.slope;
-    auto window = [&](int tau_now) {                 /* everything that depends on s; tau_now: the trip the loop is in */
+    auto window = [&]() {                            /* everything that depends on s */
         tf = NEVER; tl = NEVER; tspan = 0;
         if (s < g.NS) {
             const int jf = brx_jfirst(g, s), jl = brx_jlast(g, s);
-            slot8 = 8u * (uint32_t)slot;
-            tl = s + (jl - 1) / K;
-            if (jl >= jf) { tf = s + (jf - 1) / K; tspan = (uint32_t)(tl - tf); }   /* empty window: never active, but it still hops at tl */
+            slot8 = 8u * (uint32_t)G * (uint32_t)slot;
+            tl = (jl + s - 1) >> LU;
+            if (jl >= jf) { tf = (jf + s - 1) >> LU; tspan = (uint32_t)(tl - tf); }   /* empty window: never active, but it still hops at tl */
         }
         keep_base = g.R * s + g.H + g.R - 1;
-        acc = (int64_t)(K * (tau_now - s) + K / 2) * (int64_t)g.slope;
     };
-    window(0);
-    uint32_t Pv = 0xFFFFFFFFu, Mv = 0;
-    BrxQPlanes qp = {0u, 0u, 0u, 0u};
-    constexpr uint32_t IDLE = ((1u << K) - 1u) << K;
-    uint32_t carry = IDLE;                          /* bits 2K-1..K: hout of columns 0..K-1 is +1; bits K-1..0: it is -1.  An idle lane
-                                                       hands on +1 (the cells above the band grow by one per column) */
+    window();
+    uint32_t Pv[G], Mv[G];
+    BrxQPlanes qp[G];
+#pragma unroll
+    for (int x = 0; x < G; ++x) { Pv[x] = 0xFFFFFFFFu; Mv[x] = 0; qp[x] = BrxQPlanes{0u, 0u, 0u, 0u}; }
+    constexpr uint32_t IDLE = 0x80000000u;          /* carry word: bit 31 = hout is +1, bit 0 = hout is -1.  An idle lane hands on +1
+                                                       (the cells above the band grow by one per column) */
+    uint32_t carry = IDLE;
 
     auto fetch_chunk = [&](int c) -> uint32_t {
         const int idx = 256 * c + 4 * lane;
@@ -635,146 +646,170 @@ __device__ inline void brx_align_forward_kn(const uint8_t *__restrict__ Qs, cons
         odd |= chunk_odd(c, pending) << c;
     }
     int s_top = 0;                                  /* first superblock still inside the band (uniform) */
-    int tl_top = (brx_jlast(g, 0) - 1) / K;         /* its last trip                                     */
-    /* entries and exits happen in superblock order: scalar bookkeeping (see brx_align_forward) */
+    int tl_top = (brx_jlast(g, 0) + 0 - 1) >> LU;   /* its last trip                                     */
+    int next_mark = 64;                             /* next multiple of 64 the front byte crosses: refill events */
+    /* entries and exits happen in superblock order: scalar bookkeeping.  Near the corners several superblocks can enter or
+       leave in one trip (their windows are clamped to column 1 / column T and their times differ by one column) */
+    auto tf_of = [&](int x) { return (brx_jfirst(g, x) + x - 1) >> LU; };
+    auto tl_of = [&](int x) { return (brx_jlast(g, x) + x - 1) >> LU; };
     int e_s = 0, h_s = 0;
     while (e_s < g.NS && brx_jlast(g, e_s) < brx_jfirst(g, e_s)) ++e_s;
-    int next_entry = e_s < g.NS ? e_s + (brx_jfirst(g, e_s) - 1) / K : NEVER;
-    int next_hop = g.NS > 0 ? (brx_jlast(g, 0) - 1) / K : NEVER;
-    const int tau_end = (g.NS - 1) + (g.T - 1) / K;
+    int next_entry = e_s < g.NS ? tf_of(e_s) : NEVER;
+    int next_hop = g.NS > 0 ? tl_of(0) : NEVER;
+    const int tau_end = (g.T + g.NS - 1 - 1) >> LU;
+    /* trips in which a lane of the first 64 superblocks would compute columns left of column 1 */
+    int sv = (g.dhi + U - 2) / g.R;
+    if (sv > g.NS - 1) sv = g.NS - 1;
+    if (sv > 63) sv = 63;
+    const int tau_pro = sv >= 1 ? tf_of(sv) : -1;
     const size_t wsp = (size_t)g.WSp;
-    /* traceback rows 4 tau + 1 .. 4 tau + 4 (uniform addresses); a lane writes at byte slot8 of each */
-    BRX_GLOBAL char *row0 = (BRX_GLOBAL char *)((BRX_GLOBAL uint64_t *)tb_addr + wsp);
-    const size_t row_bytes = 8 * wsp;
-    const size_t trip_bytes = 8 * (size_t)K * wsp;
-    constexpr int KW = K / 4;                        /* ring words per trip */
-    uint32_t wnext[KW];
-#pragma unroll
-    for (int x = 0; x < KW; ++x) wnext[x] = ring32[(((uint32_t)(K * (0 - s)) >> 2) + (uint32_t)x) & (BRX_RING_BYTES / 4 - 1)];
-    for (int tau = 0; tau <= tau_end; ++tau, row0 += trip_bytes, acc += acc_step) {
+    /* traceback rows U tau + 1 .. U tau + U (uniform addresses); a lane writes G words at byte slot8 of each */
+    BRX_GLOBAL char *row0 = (BRX_GLOBAL char *)((BRX_GLOBAL uint64_t *)tb_addr + wsp * (size_t)G);
+    const size_t row_bytes = 8 * wsp * (size_t)G;
+    const size_t trip_bytes = (size_t)U * row_bytes;
+    /* the lane's U target bytes of a trip: ring bytes U tau - s .. U tau - s + U - 1, an unaligned window of two or three words */
+    auto ring_bytes = [&](int tau_, uint32_t *x0, uint32_t *x1) {
+        const uint32_t b0 = (uint32_t)(U * tau_ - s);
+        const uint32_t d = b0 >> 2;
+        const uint32_t w0 = ring32[d & (BRX_RING_BYTES / 4 - 1)], w1 = ring32[(d + 1) & (BRX_RING_BYTES / 4 - 1)];
+        *x0 = brx_funnel_bytes(w1, w0, b0);
+        if constexpr (U == 8) { const uint32_t w2 = ring32[(d + 2) & (BRX_RING_BYTES / 4 - 1)]; *x1 = brx_funnel_bytes(w2, w1, b0); }
+        else *x1 = 0u;
+    };
+    uint32_t xn0, xn1;
+    ring_bytes(0, &xn0, &xn1);
+    for (int tau = 0; tau <= tau_end; ++tau, row0 += trip_bytes) {
         /* ---- refill of the target window, keyed on the newest byte in use (scalar code) ---- */
-        while (__builtin_expect(s_top < g.NS - 1 && tau > tl_top, 0)) { s_top += 1; tl_top = s_top + (brx_jlast(g, s_top) - 1) / K; }
-        const int fq = (tau - s_top);               /* newest column group in use: bytes K fq .. K fq + K - 1 */
-        if (__builtin_expect((fq & (64 / K - 1)) == 0 && fq > 0, 0)) {
-            /* The band spans fewer than 62 superblocks, so the oldest byte still read is K (fq - 61), at most 488 bytes
-               behind the front: when the front enters chunk m, chunks m - 2 .. m + 1 are live or about to be and chunk
-               m + 2 takes the slot of the long dead chunk m - 6; its load was issued a quarter chunk earlier. */
-            const int fb = K * fq;                  /* front byte: a multiple of 64 here */
-            const int ph = (fb >> 6) & 3;
-            if (ph == 3) pending = fetch_chunk((fb >> 8) + 3);
+        while (__builtin_expect(s_top < g.NS - 1 && tau > tl_top, 0)) { s_top += 1; tl_top = tl_of(s_top); }
+        const int fb = U * tau + U - s_top;         /* one past the newest byte this trip reads */
+        if (__builtin_expect(fb >= next_mark, 0)) {
+            /* The band spans fewer than 62 superblocks, so the oldest byte still read is less than 80 bytes behind the
+               front: when the front enters chunk m, chunk m + 2 takes the slot of the long dead chunk m - 6; its load was
+               issued a quarter chunk earlier. */
+            const int mark = next_mark;
+            next_mark += 64;
+            const int ph = (mark >> 6) & 3;
+            if (ph == 3) pending = fetch_chunk((mark >> 8) + 3);
             else if (ph == 0) {
-                const int c = (fb >> 8) + 2;
+                const int c = (mark >> 8) + 2;
                 ring32[(c & 7) * 64 + lane] = pending;
                 odd = (odd & ~(1u << (c & 7))) | (chunk_odd(c, pending) << (c & 7));
             }
         }
 
-        /* ---- a superblock enters the band: read its query rows ---- */
+        /* ---- superblocks enter the band: read their query planes ---- */
         if (__builtin_expect(tau == next_entry, 0)) {
             if (tau == tf) {
-                Pv = 0xFFFFFFFFu; Mv = 0;                         /* cells below the band grow by +1 per row */
-                qp = brx_load_planes(planes, s);
+#pragma unroll
+                for (int x = 0; x < G; ++x) {
+                    Pv[x] = 0xFFFFFFFFu; Mv[x] = 0;               /* cells below the band grow by +1 per row */
+                    const int w = s * G + x;
+                    qp[x] = w < g.NW ? brx_load_planes(planes, w) : BrxQPlanes{0u, 0u, 0u, 0u};
+                }
             }
-            do { ++e_s; } while (e_s < g.NS && brx_jlast(g, e_s) < brx_jfirst(g, e_s));
-            next_entry = e_s < g.NS ? e_s + (brx_jfirst(g, e_s) - 1) / K : NEVER;
+            do { ++e_s; } while (e_s < g.NS && (brx_jlast(g, e_s) < brx_jfirst(g, e_s) || tf_of(e_s) <= tau));
+            next_entry = e_s < g.NS ? tf_of(e_s) : NEVER;
         }
 
-        /* ---- K column updates, straight-line ---- */
-        const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
-        uint32_t w[KW];
-#pragma unroll
-        for (int x = 0; x < KW; ++x) w[x] = wnext[x];
+        /* ---- U column updates, straight-line ---- */
+        const uint32_t x0 = xn0, x1 = xn1;
         const bool act = (uint32_t)(tau - tf) <= tspan;
-        const bool keep = (uint32_t)(keep_base - (int)(uint32_t)((uint64_t)acc >> 20)) <= keep_lim;   /* one test per trip */
-        bool rare = false;
+        int jr = U * tau + U / 2 - s;
+        if (jr < 0) jr = 0;
+        const bool keep = (uint32_t)(keep_base - (int)(uint32_t)(((uint64_t)(uint32_t)jr * (uint64_t)g.slope) >> 20)) <= keep_lim;   /* one test per trip */
+        bool rare = tau <= tau_pro;
         if (__builtin_expect(odd != 0u, 0)) {
             bool lr = false;
 #pragma unroll
-            for (int c = 0; c < K; ++c) lr |= ((w[c >> 2] >> (8 * (c & 3))) & 0xFFu) > 3u;
-            rare = __ballot(lr && act) != 0ull;
+            for (int c = 0; c < U; ++c) lr |= (((c < 4 ? x0 : x1) >> (8 * (c & 3))) & 0xFFu) > 3u;
+            rare = rare || __ballot(lr && act) != 0ull;
         }
-        uint32_t P = Pv, M = Mv, accP = 0, accM = 0;
-        uint32_t pvs[K], phs[K];
-        /* one column.  ANY = the trip holds an N or an IUPAC symbol in some active lane (out-of-line masks) */
-        auto column = [&](const int c, auto any_tag) {
-            const uint32_t hm = (nb >> (K - 1 - c)) & 1u, hp = (nb >> (2 * K - 1 - c)) & 1u;
-            uint32_t Eq;
-            if constexpr (decltype(any_tag)::value) {
-                const uint32_t ch = (w[c >> 2] >> (8 * (c & 3))) & 0xFFu;
-                Eq = brx_eq_acgt(qp, 0u - (ch & 1u), 0u - ((ch >> 1) & 1u));
-                if (ch == 4u) Eq = qp.n;
-                if (act && ch > 4u) {                              /* inline, rolled: a call would impose the callee's registers */
-                    uint32_t mq = 0;
-#pragma unroll 1
-                    for (int rr = 0; rr < 32; ++rr) { const int qi = 32 * s + rr; if (qi < g.Q && Qs[qi] == ch) mq |= 1u << rr; }
-                    Eq = mq;
-                }
-            } else {
-                Eq = brx_eq_acgt(qp, brx_bit_mask(w[c >> 2], 8 * (c & 3)), brx_bit_mask(w[c >> 2], 8 * (c & 3) + 1));
-            }
-            const uint32_t Xv = Eq | M;
-            const uint32_t Eq2 = Eq | hm;
-            const uint32_t Xh = (((Eq2 & P) + P) ^ P) | Eq2;
-            const uint32_t Ph = M | ~(Xh | P);
-            const uint32_t Mh = P & Xh;
-            const uint32_t PhS = (Ph << 1) | hp;
-            const uint32_t MhS = (Mh << 1) | hm;
-            P = MhS | ~(Xv | PhS);
-            M = PhS & Xv;
-            pvs[c] = P; phs[c] = Ph;
-            accP = __builtin_amdgcn_alignbit(accP, Ph, 31);        /* accP << 1 | Ph >> 31 */
-            accM = __builtin_amdgcn_alignbit(accM, Mh, 31);
-        };
+        uint32_t P[G], M[G];
+#pragma unroll
+        for (int x = 0; x < G; ++x) { P[x] = Pv[x]; M[x] = Mv[x]; }
         if (__builtin_expect(rare, 0)) {
-            /* rolled: the loop index is a run-time value, so the bit positions are computed */
+            /* rolled: symbols outside A/C/G/T, and the corner trips whose columns may lie left of column 1 */
 #pragma unroll 1
-            for (int c = 0; c < K; ++c) {
-                const uint32_t hm = (nb >> (K - 1 - c)) & 1u, hp = (nb >> (2 * K - 1 - c)) & 1u;
-                const uint32_t ch = ((c < 4 ? w[0] : w[KW - 1]) >> (8 * (c & 3))) & 0xFFu;
-                uint32_t Eq = brx_eq_acgt(qp, 0u - (ch & 1u), 0u - ((ch >> 1) & 1u));
-                if (ch == 4u) Eq = qp.n;
-                if (act && ch > 4u) {
-                    uint32_t mq = 0;
+            for (int c = 0; c < U; ++c) {
+                const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
+                const int j = U * tau + c + 1 - s;
+                const bool real = act && j >= 1;
+                uint32_t hm = nb & 1u, hp = nb >> 31;
+                const uint32_t ch = ((c < 4 ? x0 : x1) >> (8 * (c & 3))) & 0xFFu;
+                BRX_GLOBAL uint64_t *dst = (BRX_GLOBAL uint64_t *)(row0 + (size_t)c * row_bytes + slot8);
+#pragma unroll
+                for (int x = 0; x < G; ++x) {
+                    uint32_t Eq = brx_eq_acgt(qp[x], 0u - (ch & 1u), 0u - ((ch >> 1) & 1u));
+                    if (ch == 4u) Eq = qp[x].n;
+                    if (real && ch > 4u && s * G + x < g.NW) {    /* inline, rolled: a call would impose the callee's registers */
+                        uint32_t mq = 0;
 #pragma unroll 1
-                    for (int rr = 0; rr < 32; ++rr) { const int qi = 32 * s + rr; if (qi < g.Q && Qs[qi] == ch) mq |= 1u << rr; }
-                    Eq = mq;
+                        for (int rr = 0; rr < 32; ++rr) { const int qi = 32 * (s * G + x) + rr; if (qi < g.Q && Qs[qi] == ch) mq |= 1u << rr; }
+                        Eq = mq;
+                    }
+                    const uint32_t Xv = Eq | M[x];
+                    const uint32_t Eq2 = Eq | hm;
+                    const uint32_t Xh = (((Eq2 & P[x]) + P[x]) ^ P[x]) | Eq2;
+                    const uint32_t Ph = M[x] | ~(Xh | P[x]);
+                    const uint32_t Mh = P[x] & Xh;
+                    const uint32_t PhS = (Ph << 1) | hp;
+                    const uint32_t MhS = (Mh << 1) | hm;
+                    const uint32_t Pn = MhS | ~(Xv | PhS), Mn = PhS & Xv;
+                    if (real) { P[x] = Pn; M[x] = Mn; }
+                    if (real && keep) dst[x] = ((uint64_t)Ph << 32) | (uint64_t)Pn;
+                    hp = Ph >> 31; hm = Mh >> 31;
                 }
-                const uint32_t Xv = Eq | M;
-                const uint32_t Eq2 = Eq | hm;
-                const uint32_t Xh = (((Eq2 & P) + P) ^ P) | Eq2;
-                const uint32_t Ph = M | ~(Xh | P);
-                const uint32_t Mh = P & Xh;
-                const uint32_t PhS = (Ph << 1) | hp;
-                const uint32_t MhS = (Mh << 1) | hm;
-                P = MhS | ~(Xv | PhS);
-                M = PhS & Xv;
-                if (act && keep) *(BRX_GLOBAL uint64_t *)(row0 + (size_t)c * row_bytes + slot8) = ((uint64_t)Ph << 32) | (uint64_t)P;
-                accP = (accP << 1) | (Ph >> 31);
-                accM = (accM << 1) | (Mh >> 31);
+                carry = real ? ((hp << 31) | hm) : IDLE;
             }
         } else {
-            column(0, std::false_type{}); column(1, std::false_type{}); column(2, std::false_type{}); column(3, std::false_type{});
-            if constexpr (K == 8) { column(4, std::false_type{}); column(5, std::false_type{}); column(6, std::false_type{}); column(7, std::false_type{}); }
-            if (act && keep) {                                     /* uint2 {pv, Ph} per column: K stores with scalar row bases */
+            uint32_t pvs[U][G], phs[U][G];
 #pragma unroll
-                for (int c = 0; c < K; ++c) *(BRX_GLOBAL uint64_t *)(row0 + (size_t)c * row_bytes + slot8) = ((uint64_t)phs[c] << 32) | (uint64_t)pvs[c];
+            for (int c = 0; c < U; ++c) {
+                const uint32_t nb = (uint32_t)brx_from_lane_above((int)carry);
+                const uint32_t w = c < 4 ? x0 : x1;
+                const uint32_t k0 = brx_bit_mask(w, 8 * (c & 3)), k1 = brx_bit_mask(w, 8 * (c & 3) + 1);
+                uint32_t hm = nb & 1u;
+                uint32_t hpw = nb;                                 /* hp in bit 31 */
+                uint32_t Ph = 0, Mh = 0;
+#pragma unroll
+                for (int x = 0; x < G; ++x) {
+                    const uint32_t Eq = brx_eq_acgt(qp[x], k0, k1);
+                    const uint32_t Xv = Eq | M[x];
+                    const uint32_t Eq2 = Eq | hm;
+                    const uint32_t Xh = (((Eq2 & P[x]) + P[x]) ^ P[x]) | Eq2;
+                    Ph = M[x] | ~(Xh | P[x]);
+                    Mh = P[x] & Xh;
+                    const uint32_t PhS = __builtin_amdgcn_alignbit(Ph, hpw, 31);     /* Ph << 1 | hp */
+                    const uint32_t MhS = (Mh << 1) | hm;
+                    P[x] = MhS | ~(Xv | PhS);
+                    M[x] = PhS & Xv;
+                    pvs[c][x] = P[x]; phs[c][x] = Ph;
+                    hpw = Ph; hm = Mh >> 31;
+                }
+                carry = act ? ((Ph & 0x80000000u) | (Mh >> 31)) : IDLE;
+            }
+            if (act && keep) {                                     /* uint2 {pv, Ph} per word and column: stores with scalar row bases */
+#pragma unroll
+                for (int c = 0; c < U; ++c) {
+                    BRX_GLOBAL uint64_t *dst = (BRX_GLOBAL uint64_t *)(row0 + (size_t)c * row_bytes + slot8);
+#pragma unroll
+                    for (int x = 0; x < G; ++x) dst[x] = ((uint64_t)phs[c][x] << 32) | (uint64_t)pvs[c][x];
+                }
             }
         }
-        Pv = act ? P : Pv;
-        Mv = act ? M : Mv;
-        carry = act ? ((accP << K) | accM) : IDLE;
+#pragma unroll
+        for (int x = 0; x < G; ++x) { Pv[x] = act ? P[x] : Pv[x]; Mv[x] = act ? M[x] : Mv[x]; }
 
-        /* ---- a superblock leaves the band: its lane takes superblock s + 64 ---- */
+        /* ---- superblocks leave the band: their lanes take superblock s + 64 ---- */
         if (__builtin_expect(tau == next_hop, 0)) {
-            if (tau >= tl) {                                     /* acc: the loop header adds one step before the next trip */
+            if (tau >= tl) {
                 s += 64; slot += slot_step; if (slot >= g.WSp) slot -= g.WSp;
-                window(tau);
+                window();
             }
-            ++h_s;
-            next_hop = h_s < g.NS ? h_s + (brx_jlast(g, h_s) - 1) / K : NEVER;
+            do { ++h_s; } while (h_s < g.NS && tl_of(h_s) <= tau);
+            next_hop = h_s < g.NS ? tl_of(h_s) : NEVER;
         }
-#pragma unroll
-        for (int x = 0; x < KW; ++x) wnext[x] = ring32[(((uint32_t)(K * (tau + 1 - s)) >> 2) + (uint32_t)x) & (BRX_RING_BYTES / 4 - 1)];   /* bytes of the next trip */
+        ring_bytes(tau + 1, &xn0, &xn1);                           /* bytes of the next trip */
     }
 }
 
@@ -798,9 +833,9 @@ __device__ inline void brx_align_forward_any(const uint8_t *Qs, const uint8_t *T
     brx_build_planes(Qs, g, planes);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);                    /* the table is read back by other lanes of this wave */
-    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_kn<BRX_K1>(Qs, Ts, g, tb, planes); return; } }
-    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward<2>(Qs, Ts, g, tb, planes, prog); return; } }
-    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward<4>(Qs, Ts, g, tb, planes, prog); return; } }
+    if constexpr (MING <= 1) { if (g.G == 1) { brx_align_forward_u<BRX_U1, 1>(Qs, Ts, g, tb, planes); return; } }
+    if constexpr (MAXG >= 2 && MING <= 2) { if (g.G == 2) { brx_align_forward_u<4, 2>(Qs, Ts, g, tb, planes); return; } }
+    if constexpr (MAXG >= 4 && MING <= 4) { if (g.G == 4) { brx_align_forward_u<2, 4>(Qs, Ts, g, tb, planes); return; } }
     if constexpr (MAXG >= 8 && MING <= 8) { if (g.G == 8) { brx_align_forward<8>(Qs, Ts, g, tb, planes, prog); return; } }
     if constexpr (MAXG >= 16 && MING <= 16) { if (g.G == 16) { brx_align_forward<16>(Qs, Ts, g, tb, planes, prog); return; } }
 }

@@ -245,6 +245,7 @@ inline int readfirstlane(int v) {
 }
 }  // namespace emu
 #define __builtin_amdgcn_update_dpp(old, v, ctrl, row_mask, bank_mask, bound_ctrl) emu::dpp((v), (ctrl))
+#define __builtin_amdgcn_mov_dpp(v, ctrl, row_mask, bank_mask, bound_ctrl) emu::dpp((v), (ctrl))
 #define __builtin_amdgcn_readfirstlane(v) emu::readfirstlane((int)(v))
 #define __builtin_amdgcn_alignbit(hi, lo, sh) ((uint32_t)((((uint64_t)(uint32_t)(hi) << 32) | (uint64_t)(uint32_t)(lo)) >> ((sh) & 31)))   /* v_alignbit_b32 */
 /* s_waitcnt separates "every lane has loaded" from "any lane stores" in lockstep code (the in-place shift of the ops in

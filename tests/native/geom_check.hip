@@ -25,10 +25,10 @@ static int check(int Q, int T, int k, int hmul) {
     std::unordered_set<uint64_t> seen;
     for (int s = 0; s < g.NS; ++s) {
         for (int j = host_jfirst(g, s); j <= host_jlast(g, s); ++j) {
-            const bool st = brx_stored(g, s, brx_jrep(g, j));
+            const bool st = brx_stored(g, s, brx_jrep(g, s, j));
             if (g.H == BRX_H_ALL && !st) { printf("full store drops a band cell: Q=%d T=%d k=%d s=%d j=%d\n", Q, T, k, s, j); return 1; }
             if (g.H != BRX_H_ALL) {
-                const long long c = (long long)(((uint64_t)(uint32_t)brx_jrep(g, j) * (uint64_t)g.slope) >> 20);
+                const long long c = (long long)(((uint64_t)(uint32_t)brx_jrep(g, s, j) * (uint64_t)g.slope) >> 20);
                 const long long lo = (long long)g.R * s, hi = lo + g.R - 1;
                 const bool meets = hi >= c - g.H && lo <= c + g.H;
                 if (meets != st) { printf("window predicate: Q=%d T=%d k=%d s=%d j=%d meets=%d stored=%d\n", Q, T, k, s, j, meets, st); return 1; }
