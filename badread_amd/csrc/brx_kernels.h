@@ -863,11 +863,14 @@ __global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : MAXG == 2 ? 4 : MAXG == 4
 }
 
 #define BRX_QS_HOT_MAX 128
+#define BRX_QS_PEND 128          /* power of two, at least 127: up to 63 windows wait while 64 more arrive */
 __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end,
                                                     uint32_t *queue, int phase, int klo, int khi, uint8_t *seqbuf, const uint8_t *opsbuf,
                                                     uint8_t *tb_base, uint64_t *clk) {
     __shared__ uint32_t qhist[256];
     __shared__ uint32_t hot_thr[BRX_QS_HOT_MAX], hot_score[BRX_QS_HOT_MAX];
+    __shared__ uint32_t pend_sp[BRX_QS_PEND], pend_h[BRX_QS_PEND];          /* windows waiting for the slow path (a ring) */
+    __shared__ uint64_t pend_ops[BRX_QS_PEND], pend_gap[BRX_QS_PEND];
     const int lane = lane_id();
     const brx_qscore_model &qm = d.qm;
     /* The full-width window of matches ('=' x k: 89 % of all lookups with nanopore2023) keeps its row in LDS: no hash
@@ -920,34 +923,14 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
         const uint32_t margin = (uint32_t)(qm.k - 1) / 2;
         const uint32_t maxrun = (1u << qm.gap_bits) - 1u;
         bool qmiss = false;
-        if (ok) for (uint32_t sp = lane; sp < m; sp += 64) {
-            uint32_t h = margin;
-            if (sp < h) h = sp;
-            if (m - 1 - sp < h) h = m - 1 - sp;
-            /* ops and D-runs of the widest window, centre at index `margin` of the local arrays */
-            uint32_t c0 = col_of[sp - h], c1 = col_of[sp + h];
-            uint64_t opsbits = 0;     /* 2 bits per op, op i of the widest window at bits 2i  */
-            uint64_t gapbits = 0;     /* 4 bits per gap (saturated), gap after op i at bits 4i */
-            {
-                uint32_t idx = 0, rn = 0;
-                for (uint32_t cc = c0; cc <= c1; ++cc) {
-                    uint32_t op = ops[cc];
-                    if (op == BRX_OP_D) { rn += 1; continue; }
-                    if (idx > 0) { uint32_t code = rn >= maxrun ? maxrun : rn; gapbits |= (uint64_t)code << (4 * (idx - 1)); }
-                    opsbits |= (uint64_t)op << (2 * idx);
-                    rn = 0; idx += 1;
-                }
-            }
+        /* Two speeds.  89 % of the windows are the full-width all-match window and take the LDS row; the others need the key, the
+           hash probe, a search in global memory and sometimes narrower windows -- ~350 instructions that the wave used to issue in
+           EVERY group of 64 bases for the seven lanes that needed them.  Those lanes now only queue their window (centre, half
+           width, ops and gaps of the widest window: 24 bytes in LDS) and the slow path runs when 64 are waiting: full lanes. */
+        uint32_t q_head = 0, q_tail = 0;                                   /* ring of BRX_QS_PEND entries, wave-uniform */
+        auto slow_lane = [&](uint32_t sp, uint32_t h, uint64_t opsbits, uint64_t gapbits) {
             uint32_t score = 0; bool found = false;
             uint32_t hh = h;
-            if (hot_n && h == margin && opsbits == 0 && gapbits == 0) {        /* all matches, full width: the LDS row */
-                uint32_t w4[4];
-                brx_draw4(d.seed, read, BRX_ST_QS, (uint64_t)(sp >> 2), w4);
-                const uint32_t u = w4[sp & 3];
-                uint32_t e = 0, hi_ = hot_n - 1;
-                while (e < hi_) { const uint32_t mid = (e + hi_) >> 1; if (u < hot_thr[mid]) hi_ = mid; else e = mid + 1; }
-                score = hot_score[e]; found = true;
-            } else
             for (;;) {
                 /* sub-window of 2hh+1 ops centred on op index h of the widest window */
                 uint32_t first = h - hh, cnt = 2 * hh + 1;
@@ -976,7 +959,61 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
             if (!found) qmiss = true;
             qual[sp] = (uint8_t)(score + 33);
             atomicAdd(&qhist[score & 255u], 1u);
+        };
+        auto drain = [&](uint32_t count) {                                 /* the `count` oldest queued windows, one per lane */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if ((uint32_t)lane < count) {
+                const uint32_t e = (q_head + (uint32_t)lane) & (BRX_QS_PEND - 1u);
+                slow_lane(pend_sp[e], pend_h[e], pend_ops[e], pend_gap[e]);
+            }
+            q_head += count;
+            __syncthreads();                                               /* the slots may be written again */
+        };
+        if (ok) for (uint32_t sp0 = 0; sp0 < m; sp0 += 64) {
+            const uint32_t sp = sp0 + (uint32_t)lane;
+            const bool valid = sp < m;
+            uint32_t h = margin;
+            uint64_t opsbits = 0;     /* 2 bits per op, op i of the widest window at bits 2i  */
+            uint64_t gapbits = 0;     /* 4 bits per gap (saturated), gap after op i at bits 4i */
+            if (valid) {
+                if (sp < h) h = sp;
+                if (m - 1 - sp < h) h = m - 1 - sp;
+                /* ops and D-runs of the widest window, centre at index `margin` of the local arrays */
+                uint32_t c0 = col_of[sp - h], c1 = col_of[sp + h];
+                uint32_t idx = 0, rn = 0;
+                for (uint32_t cc = c0; cc <= c1; ++cc) {
+                    uint32_t op = ops[cc];
+                    if (op == BRX_OP_D) { rn += 1; continue; }
+                    if (idx > 0) { uint32_t code = rn >= maxrun ? maxrun : rn; gapbits |= (uint64_t)code << (4 * (idx - 1)); }
+                    opsbits |= (uint64_t)op << (2 * idx);
+                    rn = 0; idx += 1;
+                }
+            }
+            const bool hot = valid && hot_n && h == margin && opsbits == 0 && gapbits == 0;     /* all matches, full width: the LDS row */
+            if (hot) {
+                uint32_t w4[4];
+                brx_draw4(d.seed, read, BRX_ST_QS, (uint64_t)(sp >> 2), w4);
+                const uint32_t u = w4[sp & 3];
+                uint32_t e = 0, hi_ = hot_n - 1;
+                while (e < hi_) { const uint32_t mid = (e + hi_) >> 1; if (u < hot_thr[mid]) hi_ = mid; else e = mid + 1; }
+                const uint32_t score = hot_score[e];
+                qual[sp] = (uint8_t)(score + 33);
+                atomicAdd(&qhist[score & 255u], 1u);
+            }
+            const bool slow = valid && !hot;
+            const unsigned long long sm = __ballot(slow);
+            if (sm) {
+                if (slow) {
+                    const uint32_t e = (q_tail + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))) & (BRX_QS_PEND - 1u);
+                    pend_sp[e] = sp; pend_h[e] = h; pend_ops[e] = opsbits; pend_gap[e] = gapbits;
+                }
+                q_tail += (uint32_t)__popcll(sm);
+                if (q_tail - q_head >= 64u) drain(64u);
+            }
         }
+        if (q_tail != q_head) drain(q_tail - q_head);
         if (__ballot(qmiss)) s.status |= BRX_RS_QMISS;
         __syncthreads();
         if (lane == 0) {
