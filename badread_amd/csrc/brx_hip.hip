@@ -46,6 +46,7 @@ struct brx_ctx {
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
     uint32_t lane_waves;         /* BRX_LANE_WAVES: most waves of one k_win_lane launch */
+    uint32_t run_wps_head, run_wps_tail;   /* BRX_RUN_WPS_HEAD / _TAIL: register budget (waves per SIMD: 2 or 4) of the run-to-completion launches */
     uint32_t fin_head_reads;     /* BRX_FIN_HEAD_READS: the longest reads of a batch form the head set of the final stage (side streams) */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
     int wide_stream;             /* BRX_WIDE_STREAM: the head set's widest band class aligns on a third stream */
@@ -161,6 +162,8 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }
+    { const char *v = getenv("BRX_RUN_WPS_HEAD"); c->run_wps_head = v && atoi(v) == 4 ? 4u : 2u; }
+    { const char *v = getenv("BRX_RUN_WPS_TAIL"); c->run_wps_tail = v && atoi(v) == 2 ? 2u : 4u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
     /* a context owns exactly three streams besides the caller's: every stream of a context takes a hardware queue, and two idle
@@ -705,16 +708,15 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
        taking these windows to a cheaper aligner -- workgroups of 8 reads with packed alignments, 8-wave pass kernels, a
        persistent launch with device queues -- and every one lost to this chain on the batch's critical path: DESIGN.md section 7.) */
     auto launch_run = [&](hipStream_t s, uint32_t count, const uint32_t *act_in, const uint32_t *n_in, uint32_t *act_out, uint32_t *ctr,
-                          uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr) {
+                          uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr, uint32_t wps) {
         KTIMED(BRX_KERN_MUTATE_RUN, s);
-        if (c->profile)
-            hipLaunchKernelGGL((k_mutate_seg<true, true>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
-                               req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                               winscr, (uint64_t)c->win_bytes, counters + 1, phase);
-        else
-            hipLaunchKernelGGL((k_mutate_seg<true, false>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in, act_out, ctr,
-                               req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                               winscr, (uint64_t)c->win_bytes, counters + 1, phase);
+#define BRX_LAUNCH_RUN(PROF, WPS)                                                                                                   \
+        hipLaunchKernelGGL((k_mutate_seg<true, PROF, WPS>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in,   \
+                           act_out, ctr, req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,        \
+                           winscr, (uint64_t)c->win_bytes, counters + 1, phase)
+        if (c->profile) { if (wps == 2) BRX_LAUNCH_RUN(true, 2); else BRX_LAUNCH_RUN(true, 4); }
+        else { if (wps == 2) BRX_LAUNCH_RUN(false, 2); else BRX_LAUNCH_RUN(false, 4); }
+#undef BRX_LAUNCH_RUN
     };
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_MUTATE], st));
     /* ---- head chain: mutate to completion ---- */
@@ -724,7 +726,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
         }
         launch_run(s_head, n_mh, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, req_legacy_head,
-                   mctr + 5 * MC_WORDS, win_head);
+                   mctr + 5 * MC_WORDS, win_head, n_mb ? c->run_wps_head : c->run_wps_tail);
         if (n_mb) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
         c->mutate_passes = 1;
     }
@@ -759,7 +761,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                     HIPCHK(c, hipStreamSynchronize(st));
                     for (uint32_t x : h_act) if (x < n_reads) tail_bases += h_rs[x].n;
                 }
-                launch_run(st, n_up, act_in, n_in, act_out, ctr, req_legacy, legacy_ctr, win);
+                launch_run(st, n_up, act_in, n_in, act_out, ctr, req_legacy, legacy_ctr, win, c->run_wps_tail);
                 rc2 = read_counts(ctr);
                 if (rc2) return rc2;
                 n_up = h_ctr[MC_OUT];                   /* 0 unless a window overflowed its slot (then: legacy list) */

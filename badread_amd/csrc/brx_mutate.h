@@ -135,8 +135,11 @@ __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F
  * kernel that needs 4-8 free wave slots on ONE CU is dispatched late), a workgroup kernel with packed alignments (round 2: 1.57-1.71
  * vs 2.04), a persistent launch with device queues (round 3: 0.65-1.6 vs 2.96).  What the table would save
  * is one 4-byte L2 hit per proposal. */
-template <bool INLINE, bool PROFILE = false>
-__global__ void __launch_bounds__(64, 4) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
+/* WPS = waves per SIMD the register budget is set for.  The run-to-completion instantiation carries the wave aligner's
+ * registers beside the loop state: at four waves per SIMD (128 VGPRs) it keeps 128 B per lane in scratch memory, at two
+ * (197 VGPRs) nothing.  The head chain is 1024 waves -- one per SIMD -- so the four-wave budget bought it nothing. */
+template <bool INLINE, bool PROFILE = false, int WPS = 4>
+__global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
                                                     const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,
                                                     uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
                                                     const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk,
