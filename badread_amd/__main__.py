@@ -78,6 +78,10 @@ SIMULATE_OPTIONS = [
                                help='Write gzip-compressed FASTQ to stdout, compressed on the GPU before the bytes cross PCIe '
                                     '(a Huffman code per sequence line and per quality line, no match search: smaller than '
                                     'gzip -6 on simulated reads, and the host only copies)')),
+        ('--output-shards', dict(type=str, default=None, dest='output_shards', metavar='PREFIX',
+                                 help='Multi-GPU runs: every rank writes the records of ITS reads to PREFIX.<rank>.fastq (.fastq.gz with '
+                                      '--gzip / --gzip-device) and the bytes per batch to PREFIX.<rank>.parts, instead of all records '
+                                      'travelling to rank 0 and through one stdout; the same reads, the same stopping point')),
         ('--gpu-streams', dict(type=int, default=None, dest='gpu_streams',
                                help='Device batches in flight per GPU, each on its own HIP stream (default: 6)')),
     ]),

@@ -46,6 +46,7 @@ struct brx_ctx {
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
     uint32_t lane_threshold;
     uint32_t lane_waves;         /* BRX_LANE_WAVES: most waves of one k_win_lane launch */
+    uint32_t stage_words;        /* BRX_STAGE_WORDS: LDS words of a pass wave's slice that may hold a read (0 = never stage; at most the compiled size) */
     uint32_t run_wps_head, run_wps_tail;   /* BRX_RUN_WPS_HEAD / _TAIL: register budget (waves per SIMD: 2 or 4) of the run-to-completion launches */
     uint32_t fin_head_reads;     /* BRX_FIN_HEAD_READS: the longest reads of a batch form the head set of the final stage (side streams) */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
@@ -162,6 +163,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }
+    { const char *v = getenv("BRX_STAGE_WORDS"); c->stage_words = v ? std::min<uint32_t>((uint32_t)atoi(v), (uint32_t)BRX_STAGE_WORDS) : (uint32_t)BRX_STAGE_WORDS; }
     { const char *v = getenv("BRX_RUN_WPS_HEAD"); c->run_wps_head = v && atoi(v) == 4 ? 4u : 2u; }
     { const char *v = getenv("BRX_RUN_WPS_TAIL"); c->run_wps_tail = v && atoi(v) == 2 ? 2u : 4u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
@@ -390,6 +392,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     PPiece *pieces = (PPiece *)A.take((size_t)(tot_pieces + 1) * sizeof(PPiece));
     uint8_t *Fbuf = (uint8_t *)A.take((size_t)f_bytes + 64);
     uint32_t *repl = (uint32_t *)A.take(((size_t)f_bytes + 64) * 4);
+    uint32_t *F2buf = (uint32_t *)A.take(((size_t)f_bytes / 16 + 16) * 4);       /* the fragments as 2-bit codes: word F_off / 16 (k_build) */
+    uint32_t *Cbuf = (uint32_t *)A.take(((size_t)f_bytes / 16 + 16) * 4);        /* a bit per base: replaced (same index) */
     const uint32_t side_waves = std::min<uint32_t>(n_reads, 4096u);                 /* wave-level window aligner / legacy */
     const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, c->lane_waves);   /* lane-level window aligner: one 6.4 MB store of move codes per wave */
     uint8_t *win = (uint8_t *)A.take((size_t)(side_waves + 1) * c->win_bytes);      /* one slot per wave */
@@ -416,7 +420,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
 
     /* ---- stage: build ---- */
     if (raw) hipLaunchKernelGGL(k_copy_frags, dim3(n_reads), dim3(64), 0, st, dev, rs, d_frags, d_frag_off, Fbuf);
-    { KTIMED(BRX_KERN_BUILD, st); hipLaunchKernelGGL(k_build, dim3(n_reads), dim3(64), 0, st, dev, rs, segs, Fbuf, repl); }
+    { KTIMED(BRX_KERN_BUILD, st); hipLaunchKernelGGL(k_build, dim3(n_reads), dim3(64), 0, st, dev, rs, segs, Fbuf, repl, F2buf, Cbuf); }
     hipLaunchKernelGGL(k_order, dim3(1), dim3(64), 0, st, n_reads, rs, order);
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_BUILD], st));
 
@@ -713,7 +717,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
 #define BRX_LAUNCH_RUN(PROF, WPS)                                                                                                   \
         hipLaunchKernelGGL((k_mutate_seg<true, PROF, WPS>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in,   \
                            act_out, ctr, req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,        \
-                           winscr, (uint64_t)c->win_bytes, counters + 1, phase)
+                           winscr, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words)
         if (c->profile) { if (wps == 2) BRX_LAUNCH_RUN(true, 2); else BRX_LAUNCH_RUN(true, 4); }
         else { if (wps == 2) BRX_LAUNCH_RUN(false, 2); else BRX_LAUNCH_RUN(false, 4); }
 #undef BRX_LAUNCH_RUN
@@ -773,11 +777,11 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 if (c->profile)
                     hipLaunchKernelGGL((k_mutate_seg<false, true>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
                                        ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                                       win, (uint64_t)c->win_bytes, counters + 1, phase);
+                                       win, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words);
                 else
                     hipLaunchKernelGGL((k_mutate_seg<false, false>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
                                        ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                                       win, (uint64_t)c->win_bytes, counters + 1, phase);
+                                       win, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words);
             }
             if (n_up > lane_threshold) {
                 KTIMED(BRX_KERN_WIN_LANE, st);

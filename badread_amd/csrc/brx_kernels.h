@@ -391,7 +391,15 @@ __device__ inline uint32_t ref_code_acgt(const brx_reference &r, const brx_conti
     return strand == 0 ? code : (3u - code);       /* complement of ACGT codes 0..3 */
 }
 
-__global__ void __launch_bounds__(64) k_build(BrxDev d, const RS *rs, const PSeg *segs, uint8_t *Fbuf, uint32_t *repl) {
+/* F2 / changed map (round 4): besides the bytes, the fragment is kept as 2-bit codes, sixteen bases per word, base p of
+ * a read in bits 30 - 2 (p % 16) of word p / 16 (most significant first, so that a k-mer read across two words is a
+ * number whose digits are in the order error_model.py:135-160 indexes its table by), at word F_off / 16 of F2buf; the word
+ * behind the last one says whether the read holds a symbol outside ACGT (then the mutate loop keeps to the bytes).
+ * Cbuf (same index) is a bit per base: set when the position has been replaced (repl[p] != 0).  The proposal rounds of
+ * k_mutate_seg read k-mers and the changed bits from THESE -- staged in LDS for reads that fit (brx_mutate.h) -- instead of
+ * seven byte loads and a 4-byte word at a random position of a 15-60 KB read. */
+__global__ void __launch_bounds__(64) k_build(BrxDev d, const RS *rs, const PSeg *segs, uint8_t *Fbuf, uint32_t *repl,
+                                              uint32_t *F2buf, uint32_t *Cbuf) {
     const uint32_t r = blockIdx.x;
     const int lane = lane_id();
     const RS s = rs[r];
@@ -406,9 +414,8 @@ __global__ void __launch_bounds__(64) k_build(BrxDev d, const RS *rs, const PSeg
         F[lane] = (uint8_t)brx_random_base(d.seed, read, 0, (uint64_t)lane);
         F[n - k + lane] = (uint8_t)brx_random_base(d.seed, read, 1, (uint64_t)lane);
     }
-    if (d.raw_mode) return;                       /* fragment bytes were copied by k_copy_frags */
     uint8_t *dst0 = F + k;
-    for (uint32_t si = 0; si < s.n_segs; ++si) {
+    for (uint32_t si = 0; si < (d.raw_mode ? 0u : s.n_segs); ++si) {     /* raw mode: the fragment bytes were copied by k_copy_frags */
         const PSeg sg = segs[s.seg_off + si];
         const uint32_t type = sg.w0 & 3u, b = (sg.w0 >> 2) & 7u, a = sg.w0 >> 5;
         uint8_t *dst = dst0 + sg.dst;
@@ -445,6 +452,31 @@ __global__ void __launch_bounds__(64) k_build(BrxDev d, const RS *rs, const PSeg
             for (uint32_t x = lane; x < sg.len; x += 64) dst[x] = (uint8_t)((a >> (2 * ((sg.start + x) % b))) & 3u);
         }
     }
+    /* ---- the same fragment as 2-bit codes, and an empty changed map ---- */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                 /* the bytes of every lane are in place */
+    uint32_t *f2 = F2buf + (s.F_off >> 4), *cm = Cbuf + (s.F_off >> 4);
+    const uint32_t nw = (n + 15u) >> 4;
+    bool odd = false;
+    for (uint32_t w = lane; w < nw; w += 64) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(F + 16u * w);       /* F + F_off is 16-byte aligned (k_scan_plan) */
+        const uint32_t v[4] = {q.x, q.y, q.z, q.w};
+        uint32_t word = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            /* bytes beyond n are 0xFF (set above): they count as codes, not as odd symbols */
+            const uint32_t left = n - 16u * w - 4u * (uint32_t)i;      /* bases of the read from this dword on (may wrap: then none) */
+            const uint32_t live = 16u * w + 4u * (uint32_t)i >= n ? 0u : left >= 4u ? 0xFFFFFFFFu : (1u << (8u * left)) - 1u;
+            odd |= (v[i] & live & 0xFCFCFCFCu) != 0u;
+            uint32_t x = v[i] & 0x03030303u;                           /* byte j (bits 8j) -> digit j, first base most significant */
+            x = ((x & 0x3u) << 6) | ((x >> 4) & 0x30u) | ((x >> 14) & 0xCu) | (x >> 24);
+            word |= x << (24 - 8 * i);
+        }
+        f2[w] = word;
+    }
+    const bool any_odd = __ballot(odd) != 0ull;
+    if (lane == 0) f2[nw] = any_odd ? 1u : 0u;
+    for (uint32_t w = lane; w <= nw; w += 64) cm[w] = 0u;
 }
 
 /* sequence_fragments entry: copy caller fragments behind the start pad */
@@ -514,6 +546,35 @@ __device__ inline bool dev_choose_alt(const brx_error_model &em, const uint8_t *
 #pragma unroll
     for (int j = 0; j < 16; ++j) if (j < k) {
         uint32_t len = em.d_pool[o + 2 + (uint32_t)j];
+        rep[j] = ((diff >> j) & 1u) ? (0x80000000u | (len << 24) | coff) : 0u;
+        coff += len;
+    }
+    return true;
+}
+
+/* The same choice for a k-mer of ACGT codes given as its table row (digits most significant first, as read from F2). */
+__device__ inline bool dev_choose_alt_row(const brx_error_model &em, uint32_t row, uint32_t w2, uint32_t w3, uint32_t *rep) {
+    const int k = em.k;
+    uint8_t kmer[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) kmer[j] = j < k ? (uint8_t)((row >> (2 * (k - 1 - j))) & 3u) : (uint8_t)0;
+    if (em.type == 0) { dev_random_change(kmer, k, w3, rep); return true; }
+    if (w2 < em.d_self_thr[row]) return false;
+    const uint32_t a0 = em.d_row_off[row], a1 = em.d_row_off[row + 1];
+    if (a0 == a1) { dev_random_change(kmer, k, w3, rep); return true; }
+    uint32_t a = a0, hi_ = a1;
+    while (a < hi_) { const uint32_t mid = (a + hi_) >> 1; if (w2 < em.d_thr[mid]) hi_ = mid; else a = mid + 1; }
+    if (a == a1) {
+        if (em.d_thr[a1 - 1] == 0xFFFFFFFFu) a = a1 - 1;
+        else { dev_random_change(kmer, k, w3, rep); return true; }
+    }
+    const uint32_t o = em.d_desc[a];
+    const uint32_t diff = (uint32_t)em.d_pool[o] | ((uint32_t)em.d_pool[o + 1] << 8);
+    if (diff == 0) return false;
+    uint32_t coff = o + 2u + (uint32_t)k;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (j < k) {
+        const uint32_t len = em.d_pool[o + 2 + (uint32_t)j];
         rep[j] = ((diff >> j) & 1u) ? (0x80000000u | (len << 24) | coff) : 0u;
         coff += len;
     }

@@ -64,7 +64,19 @@ enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WOR
  * planes are ballots on that.  (Round 2 read both byte strings back from global memory: two more chains of dependent round
  * trips in a wave that has nothing else to do -- parking was 92 of the ~300 kcycles of a mutate cycle.) */
 #define BRX_PARK_LDS BRX_LANE_TMAX
-__shared__ uint8_t brx_park_lds[BRX_PARK_LDS + 64];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BRX_KEEP2(a, b) asm volatile("" : "+v"(a), "+v"(b))       /* the values pass through an opaque point of the instruction stream */
+#else
+#define BRX_KEEP2(a, b) ((void)0)
+#endif
+/* LDS of a pass wave (k_mutate_seg<false>): the read it is working on -- F2 words [0, nw2], then the changed map -- while the
+ * proposal rounds run; the parking pass, which ends the wave's work on the read, reuses the front of it as its byte window. */
+#ifndef BRX_STAGE_WORDS
+#define BRX_STAGE_WORDS 2560                              /* 10 KB: sixteen waves per CU keep their slices; F2 + map of reads up to 27 kb */
+#endif
+__shared__ uint32_t brx_stage_lds[BRX_STAGE_WORDS];
+#define brx_park_lds (reinterpret_cast<uint8_t *>(brx_stage_lds))
+static_assert(BRX_STAGE_WORDS * 4 >= BRX_PARK_LDS + 64, "the parking window lives in the staging slice");
 template <bool PLANES>
 __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F, const uint32_t *repl, uint32_t a, uint32_t b,
                                      uint8_t *qb, uint8_t *tbuf, uint32_t tmax, uint32_t *cost, bool *odd, uint32_t *pl = nullptr) {
@@ -144,7 +156,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                                                     uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
                                                     const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk,
                                                     uint32_t lane_threshold, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags,
-                                                    uint64_t *phase) {
+                                                    uint64_t *phase, const uint32_t *F2buf, uint32_t *Cbuf, uint32_t stage_words) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
@@ -165,6 +177,24 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
         const uint32_t n = s.n;
         const uint8_t *F = Fbuf + s.F_off;
         uint32_t *rp = repl + s.F_off;
+        /* ---- the read as 2-bit codes (k_build): k-mers of the proposal rounds come from these.  A pass wave stages them in
+           its LDS slice together with the changed map when both fit (STAGED); otherwise the codes are read from global memory
+           (3.75 KB per 15 kb read: L2 resident) and the changed test stays on repl[].  A read that holds a symbol outside ACGT
+           keeps to the bytes. ---- */
+        const uint32_t *f2g = F2buf + (s.F_off >> 4);
+        uint32_t *cmg = Cbuf + (s.F_off >> 4);
+        const uint32_t nw2 = (n + 15u) >> 4, nwc = (n + 31u) >> 5;
+        const bool coded = uni(f2g[nw2] == 0u);
+        const uint32_t cm0 = nw2 + 1u;                                   /* first word of the map in the slice */
+        const bool staged = !INLINE && coded && uni(cm0 + nwc <= stage_words);
+        if constexpr (!INLINE) {
+            if (staged) {
+                for (uint32_t x = (uint32_t)lane; x <= nw2; x += 64u) brx_stage_lds[x] = f2g[x];
+                for (uint32_t x = (uint32_t)lane; x < nwc; x += 64u) brx_stage_lds[cm0 + x] = cmg[x];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+        }
         const double target = s.target;
         const double dn = (double)n;
         const uint64_t max_i = (uint64_t)n - 1 - (uint64_t)k;
@@ -213,10 +243,21 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                 uint32_t w[4];
                 brx_draw4(d.seed, read, BRX_ST_MUT, loops + (uint64_t)lane, w);
                 ipos = brx_mulhi64(((uint64_t)w[1] << 32) | w[0], max_i + 1);
-                uint8_t kmer[16];
+                if (coded) {
+                    const uint32_t wi = (uint32_t)(ipos >> 4), sh = 2u * ((uint32_t)ipos & 15u);
+                    uint32_t w0, w1;
+                    /* two loads in two address spaces: the empty asm keeps the compiler from folding the branches into ONE load
+                       through a selected generic pointer (a flat load: DESIGN.md section 5, lessons) */
+                    if (staged) { w0 = brx_stage_lds[wi]; w1 = brx_stage_lds[wi + 1u]; BRX_KEEP2(w0, w1); }
+                    else { w0 = f2g[wi]; w1 = f2g[wi + 1u]; BRX_KEEP2(w0, w1); }
+                    const uint32_t row = (uint32_t)(((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) >> (64 - 2 * k));
+                    live = dev_choose_alt_row(em, row, w[2], w[3], rep);
+                } else {
+                    uint8_t kmer[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) kmer[j] = j < k ? F[ipos + j] : 0;
-                live = dev_choose_alt(em, kmer, w[2], w[3], rep);
+                    for (int j = 0; j < 16; ++j) kmer[j] = j < k ? F[ipos + j] : 0;
+                    live = dev_choose_alt(em, kmer, w[2], w[3], rep);
+                }
             }
             unsigned long long surv = __ballot(live);
             BRX_PHASE(1);
@@ -238,14 +279,25 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                 for (int jj = 0; jj < 16; ++jj) {
                     if (jj < k) { const uint32_t v = wave_bcast_u32(rep[jj], l); wj = (lane == jj) ? v : wj; }
                 }
-                const uint32_t curj = lane < k ? rp[i0 + (uint64_t)lane] : 1u;
+                uint32_t curj = 1u;
+                if (staged) {
+                    const uint32_t pp = (uint32_t)i0 + (uint32_t)lane;
+                    if (lane < k) curj = (brx_stage_lds[cm0 + (pp >> 5)] >> (pp & 31u)) & 1u;
+                } else if (lane < k) curj = rp[i0 + (uint64_t)lane];
                 unsigned long long todo = __ballot(lane < k && wj != 0u && curj == 0u);
                 if (first) todo &= ~((1ull << j0) - 1ull);
                 while (todo) {
                     const int j = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
                     const uint32_t w = wave_bcast_u32(wj, j);
-                    if (lane == j) rp[i0 + (uint64_t)j] = w;
+                    if (lane == j) {
+                        rp[i0 + (uint64_t)j] = w;
+                        if (coded) {          /* the map in global memory is what the next pass stages; the slice is what this one reads */
+                            const uint32_t pp = (uint32_t)i0 + (uint32_t)j;
+                            atomicOr(&cmg[pp >> 5], 1u << (pp & 31u));
+                            if (staged) atomicOr(&brx_stage_lds[cm0 + (pp >> 5)], 1u << (pp & 31u));
+                        }
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     change += 1;
                     const uint32_t len = (w >> 24) & 0x7Fu;

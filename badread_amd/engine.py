@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.realpath(__file__))
-LIB_PATH = os.environ.get('BRX_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libbrx_hip.so')     # BRX_HIP_LIB: A/B builds of the same sources (tools)
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libbrx_hip.so')
 
 c_u8p = ctypes.POINTER(ctypes.c_uint8)
 c_u32p = ctypes.POINTER(ctypes.c_uint32)
@@ -634,12 +634,30 @@ class HipEngine(EngineBase):
 _default_engine = None
 
 
+def rank_device_index(n_devices=None):
+    """The device of this rank, resolved in ONE place for the process group (simulate.Shard.from_env) and the engine
+    (default_engine): BRX_DEVICE when set; else LOCAL_RANK.  More ranks than devices is an error -- RCCL would refuse two
+    ranks on one GPU with a far less helpful message -- unless the exchange is kept on the host (BRX_DIST_BACKEND=gloo: several
+    ranks share a GPU, which is how the tests run the HIP engine under world > 1 on a 1-GPU box)."""
+    if os.environ.get('BRX_DEVICE') is not None:
+        return int(os.environ['BRX_DEVICE'])
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if n_devices is None:
+        import torch
+        n_devices = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_devices and local >= n_devices:
+        if os.environ.get('BRX_DIST_BACKEND') == 'gloo':
+            return local % n_devices
+        raise RuntimeError(f'LOCAL_RANK {local} but only {n_devices} GPU(s) are visible: one rank per GPU '
+                           '(set BRX_DEVICE, or BRX_DIST_BACKEND=gloo to let ranks share a GPU)')
+    return local
+
+
 def default_engine():
-    """Process-wide HipEngine on LOCAL_RANK (or device 0)."""
+    """Process-wide HipEngine on this rank's device (rank_device_index)."""
     global _default_engine
     if _default_engine is None:
-        # BRX_DEVICE: several ranks on one GPU (tests on a 1-GPU box; see simulate.Shard.from_env)
-        _default_engine = HipEngine(int(os.environ.get('BRX_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
+        _default_engine = HipEngine(rank_device_index())
     return _default_engine
 
 

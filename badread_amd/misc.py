@@ -102,25 +102,25 @@ RANDOM_SEQ_DICT = {0: 'A', 1: 'C', 2: 'G', 3: 'T'}
 def load_fastq(filename, output=sys.stderr, dot_interval=1000):
     """{read name: (bases upper-cased, qualities)} with the record rule of the reference's loader (misc.py:97-119): a line
     whose first non-blank byte is '@' opens a record and the three lines behind it belong to it whatever they hold (a
-    quality string may itself start with '@').  The file is read in one piece and walked by line index."""
+    quality string may itself start with '@').  Streamed record by record -- the read sets the model builders take are
+    gigabytes -- and a dot per `dot_interval` RECORDS (a repeated name overwrites its entry but still counts)."""
     if get_sequence_file_type(filename) != 'FASTQ':
         sys.exit('Error: {} is not FASTQ format'.format(filename))
     print('Loading reads', end='', file=output, flush=True)
+    reads, records = {}, 0
     with get_open_func(filename)(filename, 'rb') as handle:
-        lines = handle.read().split(b'\n')
-    reads, at = {}, 0
-    while at < len(lines):
-        head = lines[at].strip()
-        at += 1
-        if head[:1] != b'@':
-            continue
-        if at + 2 >= len(lines):
-            raise EOFError('{}: the last record is cut short'.format(filename))
-        name = head[1:].split()[0].decode()
-        reads[name] = (lines[at].strip().upper().decode(), lines[at + 2].strip().decode())
-        at += 3
-        if len(reads) % dot_interval == 0:
-            print('.', end='', file=output, flush=True)
+        rows = iter(handle)
+        for row in rows:
+            head = row.strip()
+            if head[:1] != b'@':
+                continue
+            body = [next(rows, None) for _ in range(3)]
+            if body[2] is None:
+                raise EOFError('{}: the last record is cut short'.format(filename))
+            reads[head[1:].split()[0].decode()] = (body[0].strip().upper().decode(), body[2].strip().decode())
+            records += 1
+            if records % dot_interval == 0:
+                print('.', end='', file=output, flush=True)
     print('', file=output, flush=True)
     return reads
 

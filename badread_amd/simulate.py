@@ -203,8 +203,19 @@ def sim_params_from_args(args, frag_lengths, identities, start_rate, start_amoun
 class Shard(object):
     """This process's place among the ranks of one node: rank r of world N (torch.distributed or single)."""
 
-    def __init__(self, rank=0, world=1, dist=None):
+    def __init__(self, rank=0, world=1, dist=None, owns_group=False):
         self.rank, self.world, self.dist = rank, world, dist
+        self.owns_group = owns_group          # from_env() created the process group: finish() takes it down again
+
+    def finish(self):
+        """Leave the job together.  Every rank leaves run_batches at the same batch (stop rule, bad read, failed sink alike);
+        a rank that then tears its connections down while a peer is still flushing makes gloo abort the peer, so the ranks
+        meet once more and the group this object created is destroyed in order."""
+        if self.world > 1 and self.dist is not None and self.dist.is_initialized():
+            self.gather_words(np.zeros(1, dtype=np.uint32), [1] * self.world)
+            if self.owns_group:
+                self.dist.destroy_process_group()
+                self.owns_group = False
 
     @classmethod
     def from_env(cls):
@@ -212,16 +223,17 @@ class Shard(object):
         if world <= 1:
             return cls()
         import torch.distributed as dist
-        if not dist.is_initialized():
+        owns = not dist.is_initialized()
+        if owns:
             import torch
             # BRX_DIST_BACKEND=gloo keeps the exchange on the host (CPU tensors) whatever the engine computes on: several ranks
             # can then share ONE GPU (BRX_DEVICE picks it), which is how the tests run the HIP engine under world > 1 on a 1-GPU box
             backend = os.environ.get('BRX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             if torch.cuda.is_available():
-                n_dev = max(torch.cuda.device_count(), 1)
-                torch.cuda.set_device(int(os.environ.get('BRX_DEVICE', int(os.environ.get('LOCAL_RANK', '0')) % n_dev)))
+                from .engine import rank_device_index
+                torch.cuda.set_device(rank_device_index(torch.cuda.device_count()))
             dist.init_process_group(backend=backend)
-        return cls(dist.get_rank(), dist.get_world_size(), dist)
+        return cls(dist.get_rank(), dist.get_world_size(), dist, owns_group=owns)
 
     def slice_of(self, first, count):
         """Contiguous slice of the super-batch [first, first+count) owned by this rank."""
@@ -307,6 +319,7 @@ class _HostRing(object):
             self.free.put(None)                     # allocated (and grown) on first use
         self.todo = queue.Queue()
         self.error = None
+        self.defer_errors = False                   # multi-rank runs: a failed sink is reported through the per-batch exchange, so that every rank stops at the same batch
         self.sink = None
         self.sink_seconds = self.alloc_seconds = 0.0
         self.thread = threading.Thread(target=self._run, daemon=True)
@@ -330,7 +343,7 @@ class _HostRing(object):
     def stage(self, nbytes):
         """A host buffer of at least nbytes (blocks while all buffers are with the writer).  A sink that has failed
         (BrokenPipe behind `| head`, a full disk) stops the run here, at the next batch, not after the whole target."""
-        if self.error is not None:
+        if self.error is not None and not self.defer_errors:
             raise self.error
         buf = self.free.get()
         if buf is None or buf.numel() < nbytes:
@@ -382,24 +395,30 @@ class _BatchPool(object):
         self.free = queue.Queue()
         self.free.put(0)                                 # engine 0 exists already: it takes the first batch
         self.create_seconds = 0.0
-        self.create_error = None
+        self.create_errors = []                          # clones that could not be made: the job runs on fewer engines
+        import threading
+        self.lock = threading.Lock()                     # the counters below are updated by several worker threads
         # Mapping a clone's 40 GB arena takes ~0.6-1.2 s per engine whoever does it and whenever (the driver clears the memory:
         # 14-29 ms per GB measured, also for ONE 200 GB allocation on an idle device -- 5.9 s), so the clones are made by their own
-        # threads while engine 0 already computes: a job's first seconds run on fewer engines instead of on none.
+        # threads while engine 0 already computes: a job's first seconds run on fewer engines instead of on none.  Clone i is
+        # started when the job submits its (i + 1)-th batch: a one-batch job (a bacterial genome at 100x) maps no clone at all.
         def make(i):                                     # a clone maps tens of GB of scratch: its own thread, beside the first batches
             t0 = time.perf_counter()
             try:
                 if self.on_gpu:
                     torch.cuda.set_device(self.engines[0].device)
                 self.engines[i] = self.engines[0].clone()
-            except BaseException as ex:                  # surfaced by the job that would have used this engine
-                self.create_error = ex
-            self.create_seconds += time.perf_counter() - t0
+            except BaseException as ex:                  # this slot never joins the queue; engine 0 and the other clones carry on
+                with self.lock:
+                    self.create_errors.append(ex)
+                    self.create_seconds += time.perf_counter() - t0
+                return
+            with self.lock:
+                self.create_seconds += time.perf_counter() - t0
             self.free.put(i)
-        import threading
         self.makers = [threading.Thread(target=make, args=(i,), daemon=True) for i in range(1, len(self.engines))]
-        for th in self.makers:
-            th.start()
+        self.started = 0                                 # makers started so far
+        self.submitted = 0
         self.depth = len(self.engines) + (2 if len(self.engines) > 1 else 0)
         self.job_seconds = self.job_count = 0.0          # wall time of the device batches (bench.py --d2h reports the average)
         self.wait_engine_seconds = 0.0
@@ -426,16 +445,20 @@ class _BatchPool(object):
         return n
 
     def submit(self, seed, first, n_mine):
+        self.submitted += 1
+        while self.started < min(self.submitted - 1, len(self.makers)):      # the k-th batch in the pipeline is what clone k - 1 is for
+            self.makers[self.started].start()
+            self.started += 1
+
         def job():
             import torch
             t_q = time.perf_counter()
             i = self.free.get()
             t_job = time.perf_counter()
-            self.wait_engine_seconds += t_job - t_q
+            with self.lock:
+                self.wait_engine_seconds += t_job - t_q
             try:
                 stream = self.streams[i]
-                if self.engines[i] is None:
-                    raise self.create_error or RuntimeError('engine clone missing')
                 eng = self.engines[i]
                 if n_mine == 0:
                     return torch.zeros(0, dtype=torch.uint8), np.zeros(0, dtype=eng.stats_dtype)
@@ -449,8 +472,9 @@ class _BatchPool(object):
                     stream.synchronize()                     # ... and is complete before the engine is handed to the next batch
                     return out, stats.copy()
             finally:
-                self.job_seconds += time.perf_counter() - t_job
-                self.job_count += 1
+                with self.lock:
+                    self.job_seconds += time.perf_counter() - t_job
+                    self.job_count += 1
                 self.free.put(i)
         if self.pool is None:
             class _Done(object):
@@ -460,7 +484,7 @@ class _BatchPool(object):
         return self.pool.submit(job)
 
     def close(self):
-        for th in self.makers:
+        for th in self.makers[:self.started]:            # clones no batch asked for were never started
             th.join()
         if self.pool is not None:
             self.pool.shutdown(wait=True)
@@ -469,7 +493,8 @@ class _BatchPool(object):
                 eng.close()
 
 
-def run_batches(engine, seed, target_size, mean_length, write, output, shard=None, max_batch=None, in_flight=1, device_gzip=False):
+def run_batches(engine, seed, target_size, mean_length, write, output, shard=None, max_batch=None, in_flight=1, device_gzip=False,
+                local_write=None, local_parts=None):
     """
     The `while total_size < target_size` loop (simulate.py:63-86) over super-batches of read indices.
     `write(bytes_like)` receives the FASTQ bytes in read order on rank 0 only.  Returns (read count, total bases).
@@ -485,6 +510,14 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
 
     device_gzip: every rank turns the bytes it keeps into gzip members ON ITS GPU (brx_gzip_device, blocks cut at the
     lines of the records: badread_amd.output.fastq_blocks) before they go anywhere; `write` then receives gzip data.
+
+    local_write (--output-shards): EVERY rank hands the bytes it keeps to its own `local_write` through its own pinned ring
+    (its own PCIe link, its own file) and nothing travels to rank 0; `local_parts(n)` receives the byte count of every
+    super-batch, which is what puts the ranks' files back into read order (batch by batch, rank after rank).  The
+    exchange of 4 bytes per read and the stop rule are the same: the same reads are kept.
+
+    A sink that fails on one rank of a multi-rank run (a full disk, a closed pipe) is reported in the same exchange -- one
+    word per rank -- so that every rank leaves the loop at the same batch instead of waiting in a collective.
     """
     import collections
     import torch
@@ -514,9 +547,11 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     pool = _BatchPool(engine, fit)
     timing['create_engines'] = time.perf_counter() - t0
     ring = None
-    if shard.rank == 0:
+    if local_write is not None or shard.rank == 0:
         ring = _HostRing(torch, pinned=pool.on_gpu)
-        ring.sink = write
+        ring.sink = local_write if local_write is not None else write
+        ring.defer_errors = shard.world > 1
+    sink_failed_on = None
     dev_staging = {}
 
     def staging(nbytes):                     # where rank 0 receives another rank's records (device memory under RCCL)
@@ -564,7 +599,16 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             words |= np.where(stats['status'] & RS_NOFRAG, FLAG_NOFRAG, 0).astype(np.uint32)
             words |= np.where(stats['status'] & BAD_STATUS, FLAG_BAD, 0).astype(np.uint32)
             per_rank = [Shard(r, shard.world).slice_of(base, n_super)[1] for r in range(shard.world)]
-            allw = np.concatenate(shard.gather_words(words, per_rank)) if shard.world > 1 else words
+            if shard.world > 1:                     # one more word per rank: "my sink has failed"
+                mine = np.append(words, np.uint32(1 if ring is not None and ring.error is not None else 0))
+                parts = shard.gather_words(mine, [c + 1 for c in per_rank])
+                failed = [r for r, part in enumerate(parts) if part[-1]]
+                if failed:
+                    sink_failed_on = failed[0]
+                    break
+                allw = np.concatenate([part[:-1] for part in parts])
+            else:
+                allw = words
             lens = (allw & (FLAG_BAD - 1)).astype(np.int64)
             cut = cut_point(lens, total, target_size)
             wrong = np.flatnonzero(allw & (FLAG_NOFRAG | FLAG_BAD))
@@ -589,7 +633,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
                 packed = True
                 timing['device_gzip'] += time.perf_counter() - t0
             sizes = [my_bytes]
-            if shard.world > 1:
+            if shard.world > 1 and local_write is None:
                 sizes = [int(x[0]) for x in shard.gather_words(np.array([my_bytes], dtype=np.uint32), [1] * shard.world)]
                 assert my_bytes < 2 ** 32
             if pool.on_gpu and my_bytes and not packed:
@@ -603,8 +647,14 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             if not stop and total < target_size:
                 fill()                              # the freed engine starts its next batch while this one's bytes leave
             t0 = time.perf_counter()
-            for _, part in shard.collect_bytes(out, sizes, staging):
-                ring.write(part)                    # rank 0: through pinned memory to the writer thread
+            if local_write is not None:             # every rank: its own bytes through its own ring to its own file
+                if my_bytes:
+                    ring.write(out[:my_bytes])
+                if local_parts is not None:
+                    local_parts(my_bytes)
+            else:
+                for _, part in shard.collect_bytes(out, sizes, staging):
+                    ring.write(part)                # rank 0: through pinned memory to the writer thread
             timing['copy_out'] += time.perf_counter() - t0
             if shard.rank == 0:
                 print_progress(count, total, target_size, output)
@@ -623,7 +673,8 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         timing['close_engines'] = time.perf_counter() - t0
         t0 = time.perf_counter()
         if ring is not None:
-            ring.flush(reraise=sys.exc_info()[0] is None)     # a sink error must not mask the exception that is already propagating
+            # a sink error must not mask the exception that is already propagating; in a multi-rank run it is reported below
+            ring.flush(reraise=sys.exc_info()[0] is None and sink_failed_on is None and not ring.defer_errors)
             timing['sink'] = ring.sink_seconds
             timing['ring_alloc'] = ring.alloc_seconds
         timing['flush'] = time.perf_counter() - t0
@@ -633,8 +684,15 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         timing['engines'] = len(pool.engines)
         timing['run_batches_seconds'] = time.perf_counter() - t_job
         timing['create_clones_thread_seconds'] = pool.create_seconds
+        if pool.create_errors and shard.rank == 0:
+            print(f'\n  {len(pool.create_errors)} of the {len(pool.engines) - 1} extra batch engines could not be created '
+                  f'({pool.create_errors[0]}): the job ran on fewer', file=output)
     if shard.rank == 0:
         print('\n', file=output)
+    if ring is not None and ring.error is not None and (sink_failed_on is not None or ring.defer_errors):
+        raise ring.error                     # this rank's own sink
+    if sink_failed_on is not None:
+        sys.exit(f'Error: the output of rank {sink_failed_on} failed; every rank stopped at the same batch')
     if fatal:
         sys.exit(NOFRAG_MESSAGE)
     if bad_read is not None:
@@ -696,8 +754,39 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
     else:                                   # a text-only stdout (e.g. captured in tests)
         def write(part):
             sys.stdout.write(bytes(part).decode('latin-1'))
-    result = run_batches(engine, seed, target_size, float(args.mean_frag_length), write, quiet, shard,
-                         in_flight=getattr(args, 'gpu_streams', None) or DEFAULT_IN_FLIGHT, device_gzip=device_gzip)
+    # --output-shards PREFIX: every rank writes PREFIX.<rank>.fastq[.gz] itself (and the bytes per batch to PREFIX.<rank>.parts),
+    # so that N ranks leave through N PCIe links and N files instead of rank 0's one of each (simulate.py:77-82 is one print loop)
+    local_write = local_parts = shard_file = parts_file = None
+    prefix = getattr(args, 'output_shards', None)
+    if prefix:
+        zipped = device_gzip or gzip_level is not None
+        shard_file = open(f'{prefix}.{shard.rank}.fastq' + ('.gz' if zipped else ''), 'wb')
+        parts_file = open(f'{prefix}.{shard.rank}.parts', 'w')
+        shard_sink = shard_file
+        if gzip_level is not None:
+            from .output import GzipSink
+            shard_sink = GzipSink(shard_file, gzip_level)
+
+        def local_write(part):
+            shard_sink.write(memoryview(part))
+
+        def local_parts(n):
+            parts_file.write(f'{n}\n')
+    try:
+        try:
+            result = run_batches(engine, seed, target_size, float(args.mean_frag_length), write, quiet, shard,
+                                 in_flight=getattr(args, 'gpu_streams', None) or DEFAULT_IN_FLIGHT, device_gzip=device_gzip,
+                                 local_write=local_write, local_parts=local_parts)
+            if prefix and hasattr(shard_sink, 'flush') and shard_sink is not shard_file:
+                shard_sink.flush()
+        finally:
+            for f in (shard_file, parts_file):
+                if f is not None:
+                    f.close()
+    except (SystemExit, OSError):
+        shard.finish()                      # exits every rank takes at the same batch: NOFRAG, a bad read, a failed sink
+        raise
+    shard.finish()
     if sink is not None and hasattr(sink, 'flush'):
         sink.flush()
     if os.environ.get('BRX_DRIVER_TIMING') and shard.rank == 0:      # seconds of the consumer thread per activity + rate, for tools/cli_30x.sh

@@ -46,6 +46,7 @@
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 v; v.x = x; v.y = y; return v; }
+struct alignas(16) uint4 { unsigned x, y, z, w; };
 
 namespace emu {
 
