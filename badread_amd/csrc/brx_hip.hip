@@ -162,9 +162,9 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         if ((e = hipEventCreateWithFlags(&c->ev_fork2[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
-    { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }
+    { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 512u; }
     { const char *v = getenv("BRX_STAGE_WORDS"); c->stage_words = v ? std::min<uint32_t>((uint32_t)atoi(v), (uint32_t)BRX_STAGE_WORDS) : (uint32_t)BRX_STAGE_WORDS; }
-    { const char *v = getenv("BRX_RUN_WPS_HEAD"); c->run_wps_head = v && atoi(v) == 4 ? 4u : 2u; }
+    { const char *v = getenv("BRX_RUN_WPS_HEAD"); c->run_wps_head = v && atoi(v) == 2 ? 2u : 4u; }
     { const char *v = getenv("BRX_RUN_WPS_TAIL"); c->run_wps_tail = v && atoi(v) == 2 ? 2u : 4u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
@@ -198,6 +198,8 @@ extern "C" int brx_set_reference(brx_ctx *c, const brx_reference *r) {
 extern "C" int brx_set_error_model(brx_ctx *c, const brx_error_model *m) {
     if (!c || !m) return BRX_E_ARG;
     if (m->k < 1 || m->k > 16) return fail(c, BRX_E_ARG, "error model k-mer size %d out of range", m->k);
+    if (m->type != 0 && (!m->d_rowx || !m->d_altx))
+        return fail(c, BRX_E_ARG, "error model without its lookup-order tables (d_rowx, d_altx: include/brx.h)");
     c->dev.em = *m; c->has_em = true; return BRX_OK;
 }
 extern "C" int brx_set_qscore_model(brx_ctx *c, const brx_qscore_model *m) {
@@ -775,11 +777,11 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             {
                 KTIMED(BRX_KERN_MUTATE_SEG, st);
                 if (c->profile)
-                    hipLaunchKernelGGL((k_mutate_seg<false, true>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                    hipLaunchKernelGGL((k_mutate_seg<false, true, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
                                        ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                        win, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words);
                 else
-                    hipLaunchKernelGGL((k_mutate_seg<false, false>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
+                    hipLaunchKernelGGL((k_mutate_seg<false, false, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
                                        ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
                                        win, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words);
             }

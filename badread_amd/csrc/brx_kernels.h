@@ -456,27 +456,31 @@ __global__ void __launch_bounds__(64) k_build(BrxDev d, const RS *rs, const PSeg
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);                 /* the bytes of every lane are in place */
     uint32_t *f2 = F2buf + (s.F_off >> 4), *cm = Cbuf + (s.F_off >> 4);
-    const uint32_t nw = (n + 15u) >> 4;
+    const uint32_t nw = (n + 15u) >> 4, nwc = (n + 31u) >> 5;
+    for (uint32_t w = lane; w <= nw; w += 64) cm[w] = 0u;       /* changed map [0, nwc), map of the symbols outside ACGT [nwc, 2 nwc) */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
     bool odd = false;
     for (uint32_t w = lane; w < nw; w += 64) {
         const uint4 q = *reinterpret_cast<const uint4 *>(F + 16u * w);       /* F + F_off is 16-byte aligned (k_scan_plan) */
         const uint32_t v[4] = {q.x, q.y, q.z, q.w};
-        uint32_t word = 0;
+        uint32_t word = 0, oddbits = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             /* bytes beyond n are 0xFF (set above): they count as codes, not as odd symbols */
             const uint32_t left = n - 16u * w - 4u * (uint32_t)i;      /* bases of the read from this dword on (may wrap: then none) */
             const uint32_t live = 16u * w + 4u * (uint32_t)i >= n ? 0u : left >= 4u ? 0xFFFFFFFFu : (1u << (8u * left)) - 1u;
-            odd |= (v[i] & live & 0xFCFCFCFCu) != 0u;
+            const uint32_t hi6 = ((v[i] & live) >> 2) & 0x3F3F3F3Fu;          /* per byte: non-zero iff the symbol is outside 0..3 */
+            oddbits |= ((((hi6 + 0x3F3F3F3Fu) >> 6) & 0x01010101u) * 0x01020408u >> 24) << (4 * i);
             uint32_t x = v[i] & 0x03030303u;                           /* byte j (bits 8j) -> digit j, first base most significant */
             x = ((x & 0x3u) << 6) | ((x >> 4) & 0x30u) | ((x >> 14) & 0xCu) | (x >> 24);
             word |= x << (24 - 8 * i);
         }
         f2[w] = word;
+        if (oddbits) { odd = true; atomicOr(&cm[nwc + (w >> 1)], oddbits << (16u * (w & 1u))); }
     }
     const bool any_odd = __ballot(odd) != 0ull;
     if (lane == 0) f2[nw] = any_odd ? 1u : 0u;
-    for (uint32_t w = lane; w <= nw; w += 64) cm[w] = 0u;
 }
 
 /* sequence_fragments entry: copy caller fragments behind the start pad */
@@ -502,22 +506,34 @@ __global__ void __launch_bounds__(64) k_init_raw(BrxDev d, RS *rs, const uint64_
  * error model lookup: ErrorModel.add_errors_to_kmer / add_one_random_change
  * (error_model.py:135-176).  rep[j] = 0x80000000 | len<<24 | pool offset, or 0 if unchanged.
  * ========================================================================================== */
+/* The draw of add_one_random_change split into its choices -- two divisions by the run-time k.  A call, not inline code:
+ * table models reach it for a few draws in a million, and a dozen inlined copies of the divisions were a fifth of the mutate
+ * kernels' instructions (which have to stay inside the instruction cache next to five other batches' kernels). */
+struct BrxRc { uint32_t type, pos, rest; };
+__device__ __attribute__((noinline)) BrxRc dev_random_change_split(uint32_t w3, int k) {
+    BrxRc c;
+    c.type = w3 % 3u;
+    c.pos = (w3 / 3u) % (uint32_t)k;
+    c.rest = w3 / (3u * (uint32_t)k);
+    return c;
+}
+__device__ __forceinline__ uint32_t dev_random_change_word(const BrxRc c, uint32_t o) {
+    if (c.type == 0) return 0x80000000u | (1u << 24) | (o < 4 ? ((o + 1u + c.rest % 3u) & 3u) : (c.rest & 3u));
+    if (c.type == 1) {
+        const uint32_t after = c.rest & 1u, nb = (c.rest >> 1) & 3u;
+        const uint32_t x = after ? o : nb, y = after ? nb : o;
+        return 0x80000000u | (2u << 24) | (16u + 2u * (16u * x + y));
+    }
+    return 0x80000000u;
+}
 __device__ inline void dev_random_change(const uint8_t *kmer, int k, uint32_t w3, uint32_t *rep) {
-    uint32_t type = w3 % 3u;
-    uint32_t pos = (w3 / 3u) % (uint32_t)k;
-    uint32_t rest = w3 / (3u * (uint32_t)k);
-    uint32_t o = kmer[pos];
-    uint32_t word;
-    if (type == 0) {
-        uint32_t nb = o < 4 ? ((o + 1u + rest % 3u) & 3u) : (rest & 3u);
-        word = 0x80000000u | (1u << 24) | nb;
-    } else if (type == 1) {
-        uint32_t after = rest & 1u, nb = (rest >> 1) & 3u;
-        uint32_t x = after ? o : nb, y = after ? nb : o;
-        word = 0x80000000u | (2u << 24) | (16u + 2u * (16u * x + y));
-    } else word = 0x80000000u;
+    const BrxRc c = dev_random_change_split(w3, k);
+    uint32_t o = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) if (j < k) rep[j] = ((uint32_t)j == pos) ? word : 0u;
+    for (int j = 0; j < 16; ++j) if (j < k) o = ((uint32_t)j == c.pos) ? kmer[j] : o;
+    const uint32_t word = dev_random_change_word(c, o);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (j < k) rep[j] = ((uint32_t)j == c.pos) ? word : 0u;
 }
 
 /* returns false if the k-mer is unchanged */
@@ -552,33 +568,87 @@ __device__ inline bool dev_choose_alt(const brx_error_model &em, const uint8_t *
     return true;
 }
 
-/* The same choice for a k-mer of ACGT codes given as its table row (digits most significant first, as read from F2). */
-__device__ inline bool dev_choose_alt_row(const brx_error_model &em, uint32_t row, uint32_t w2, uint32_t w3, uint32_t *rep) {
-    const int k = em.k;
-    uint8_t kmer[16];
+/* add_one_random_change for a k-mer of ACGT codes given as its table row (digits most significant first). */
+__device__ __forceinline__ void dev_random_change_row(uint32_t row, int k, uint32_t w3, uint32_t *rep) {
+    const BrxRc c = dev_random_change_split(w3, k);
+    const uint32_t word = dev_random_change_word(c, (row >> (2u * ((uint32_t)k - 1u - c.pos))) & 3u);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) kmer[j] = j < k ? (uint8_t)((row >> (2 * (k - 1 - j))) & 3u) : (uint8_t)0;
-    if (em.type == 0) { dev_random_change(kmer, k, w3, rep); return true; }
-    if (w2 < em.d_self_thr[row]) return false;
-    const uint32_t a0 = em.d_row_off[row], a1 = em.d_row_off[row + 1];
-    if (a0 == a1) { dev_random_change(kmer, k, w3, rep); return true; }
-    uint32_t a = a0, hi_ = a1;
-    while (a < hi_) { const uint32_t mid = (a + hi_) >> 1; if (w2 < em.d_thr[mid]) hi_ = mid; else a = mid + 1; }
+    for (int j = 0; j < 16; ++j) if (j < k) rep[j] = ((uint32_t)j == c.pos) ? word : 0u;
+}
+
+struct __attribute__((packed, aligned(4))) BrxU4 { uint32_t x, y, z, w; };      /* four words behind a 4-byte aligned address */
+
+/* A PROPOSAL of the mutate rounds is three words per lane (round 4; it was an array of sixteen replacement words, filled
+ * by every proposing lane and read back with sixteen broadcasts per survivor):
+ *   y = 0                       the k-mer stays as it is (not a survivor)
+ *   y = BRX_PROP_RANDOM | pos   add_one_random_change: x = the replacement word of position pos
+ *   y = BRX_PROP_TABLE | diff | long << 16   an alternative of the table: x = its descriptor's pool offset, z = the lengths of
+ *                               positions 0-7 in 4 bits each (long: the lengths are read from the pool)
+ * The lanes j < k of the wave expand a survivor's proposal TOGETHER (brx_prop_word): lane j derives the word of position j. */
+#define BRX_PROP_TABLE 0x80000000u
+#define BRX_PROP_RANDOM 0x40000000u
+struct BrxProp { uint32_t x, y, z; };
+
+__device__ __forceinline__ BrxProp brx_prop_random(const brx_error_model &em, uint32_t row, uint32_t w3) {
+    const BrxRc c = dev_random_change_split(w3, em.k);
+    BrxProp p; p.x = dev_random_change_word(c, (row >> (2u * ((uint32_t)em.k - 1u - c.pos))) & 3u); p.y = BRX_PROP_RANDOM | c.pos; p.z = 0u;
+    return p;
+}
+
+/* ErrorModel.add_errors_to_kmer (error_model.py:135-160) for a k-mer of ACGT codes given as its table row (digits most
+ * significant first, as read from F2), on the lookup-order tables (include/brx.h: d_rowx, d_altx).  Every step is ONE load:
+ * the row entry (self threshold and both ends of the row's alternatives), the thresholds in blocks of eight (first
+ * alternative whose cumulative threshold exceeds the draw: the alternatives of a row are few and the likely ones come
+ * first), the alternative's descriptor with its lengths. */
+__device__ inline BrxProp dev_propose_row(const brx_error_model &em, uint32_t row, uint32_t w2, uint32_t w3) {
+    BrxProp none; none.x = none.y = none.z = 0u;
+    if (em.type == 0) return brx_prop_random(em, row, w3);
+    const BrxU4 e = *reinterpret_cast<const BrxU4 *>(em.d_rowx + 2u * row);
+    if (w2 < e.x) return none;                                   /* the common case (~93 % of draws, simulate.py:300): unchanged */
+    const uint32_t a0 = e.y, a1 = e.w;
+    if (a0 == a1) return brx_prop_random(em, row, w3);
+    uint32_t a = a1, last = 0u;
+    for (uint32_t c = a0; c < a1 && a == a1; c += 8u) {
+        const BrxU4 t0 = *reinterpret_cast<const BrxU4 *>(em.d_thr + c), t1 = *reinterpret_cast<const BrxU4 *>(em.d_thr + c + 4u);
+        const uint32_t t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        uint32_t hit = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool in = c + (uint32_t)i < a1;
+            hit |= (in && w2 < t[i]) ? (1u << i) : 0u;
+            last = (c + (uint32_t)i == a1 - 1u) ? t[i] : last;
+        }
+        if (hit) a = c + (uint32_t)(__ffs((int)hit) - 1);
+    }
     if (a == a1) {
-        if (em.d_thr[a1 - 1] == 0xFFFFFFFFu) a = a1 - 1;
-        else { dev_random_change(kmer, k, w3, rep); return true; }
+        if (last == 0xFFFFFFFFu) a = a1 - 1u;
+        else return brx_prop_random(em, row, w3);
     }
-    const uint32_t o = em.d_desc[a];
-    const uint32_t diff = (uint32_t)em.d_pool[o] | ((uint32_t)em.d_pool[o + 1] << 8);
-    if (diff == 0) return false;
-    uint32_t coff = o + 2u + (uint32_t)k;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) if (j < k) {
-        const uint32_t len = em.d_pool[o + 2 + (uint32_t)j];
-        rep[j] = ((diff >> j) & 1u) ? (0x80000000u | (len << 24) | coff) : 0u;
-        coff += len;
+    const BrxU4 inf = *reinterpret_cast<const BrxU4 *>(em.d_altx + 4u * a);
+    if ((inf.y & 0xFFFFu) == 0u) return none;
+    BrxProp p; p.x = inf.x; p.y = BRX_PROP_TABLE | (inf.y & 0x1FFFFu); p.z = inf.z;
+    return p;
+}
+
+/* The replacement word of position `lane` (0 for an unchanged position and for lanes >= k) of a proposal whose three words
+ * are wave-uniform here (broadcast from the proposing lane). */
+__device__ __forceinline__ uint32_t brx_prop_word(const brx_error_model &em, uint32_t px, uint32_t py, uint32_t pz) {
+    const int lane = lane_id();
+    const int k = em.k;
+    if (py & BRX_PROP_RANDOM) return (uint32_t)lane == (py & 0xFFu) ? px : 0u;
+    uint32_t len, before;
+    if (py & 0x10000u) {                                         /* a length above 15 (or k > 8): lengths from the pool */
+        len = lane < k ? (uint32_t)em.d_pool[px + 2u + (uint32_t)lane] : 0u;
+        before = wave_incl_scan(len) - len;
+    } else {
+        const uint32_t l7 = (uint32_t)lane & 7u;
+        len = lane < 8 ? (pz >> (4u * l7)) & 15u : 0u;
+        const uint32_t m = pz & ((1u << (4u * l7)) - 1u);        /* the lengths of the positions before this one ... */
+        const uint32_t t = (m & 0x0F0F0F0Fu) + ((m >> 4) & 0x0F0F0F0Fu);
+        before = (t * 0x01010101u) >> 24;                        /* ... summed */
     }
-    return true;
+    const bool on = lane < k && ((py >> lane) & 1u);
+    return on ? (0x80000000u | (len << 24) | (px + 2u + (uint32_t)k + before)) : 0u;
 }
 
 __device__ __forceinline__ uint32_t rep_len(uint32_t w) { return w ? ((w >> 24) & 0x7Fu) : 1u; }

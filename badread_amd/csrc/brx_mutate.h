@@ -26,6 +26,9 @@
 #ifndef BRX_MUTATE_H
 #define BRX_MUTATE_H
 
+#ifndef BRX_SEG_WPS
+#define BRX_SEG_WPS 3                                    /* register budget of the pass kernel k_mutate_seg<false>: waves per SIMD */
+#endif
 #define BRX_WIN_Q 1024                                   /* slot bytes reserved for the window of F           */
 #define BRX_WIN_BYTES 5120                               /* byte part of a slot: [0,1024) query, then target  */
 #define BRX_WIN_TMAX (BRX_WIN_BYTES - BRX_WIN_Q - 16)    /* longer joined windows go to the legacy kernel     */
@@ -77,48 +80,111 @@ enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WOR
 __shared__ uint32_t brx_stage_lds[BRX_STAGE_WORDS];
 #define brx_park_lds (reinterpret_cast<uint8_t *>(brx_stage_lds))
 static_assert(BRX_STAGE_WORDS * 4 >= BRX_PARK_LDS + 64, "the parking window lives in the staging slice");
+struct __attribute__((packed, aligned(1))) BrxB16 { uint32_t x, y, z, w; };      /* sixteen bytes behind any address */
+static_assert(BRX_ALIGN_SIZE + 16 <= 1024 && BRX_WIN_Q >= 1024, "a window is 64 lanes x 16 positions");
+
+/* bit j of the result = bit `bit` of byte j of v (j = 0..3) */
+__device__ __forceinline__ uint32_t brx_byte_bits(uint32_t v, int bit) { return (((v >> bit) & 0x01010101u) * 0x01020408u) >> 24; }
+
+/* Round 4: ONE round of loads instead of sixteen.  A lane takes SIXTEEN CONSECUTIVE positions of the window (1000 <= 64 x 16):
+ * their fragment bytes (one 16-byte load) and replacement words (four), then everything is registers and LDS -- the
+ * lengths are summed per lane and scanned once over the wave, a lane writes its stretch of the joined string to the LDS
+ * window (a changed position looks its characters up in the pool), and the window leaves for the slot in 16-byte rows;
+ * both strings' bit planes come from the same registers / LDS rows by multiplication (brx_byte_bits) and a pair of
+ * neighbouring lanes per plane word.  (The loop over 64-position steps it replaces made ~45 dependent global round trips
+ * per parked window -- fragment byte and replacement, pool characters, scan, stores, sixteen times over: 77 k of the ~290 k
+ * cycles of a mutate cycle, profiles/r04b.)  Memory image of the slot: as before. */
 template <bool PLANES>
 __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F, const uint32_t *repl, uint32_t a, uint32_t b,
                                      uint8_t *qb, uint8_t *tbuf, uint32_t tmax, uint32_t *cost, bool *odd, uint32_t *pl = nullptr) {
     const int lane = lane_id();
-    uint32_t run = 0, c = 0, it = 0;
-    bool o_ = false;
-    for (uint32_t base = a; base < b; base += 64, ++it) {
-        const uint32_t p = base + lane;
-        const bool valid = p < b;
-        uint32_t w = 0, len = 0;
-        uint8_t fb = 0xFF;
-        if (valid) { fb = F[p]; w = repl[p]; len = rep_len(w); c += rep_cost(em, w, fb); qb[p - a] = fb; o_ |= fb > 3; }
-        if constexpr (PLANES) {
-            const unsigned long long lo = __ballot(valid && (fb & 1u)), hi = __ballot(valid && (fb & 2u));
-            if (lane < 2 && it < 16u) { pl[2 * it + lane] = (uint32_t)(lo >> (32 * lane)); pl[32 + 2 * it + lane] = (uint32_t)(hi >> (32 * lane)); }
+    const uint32_t ql = b - a;
+    const uint32_t p0 = a + 16u * (uint32_t)lane;
+    const uint32_t nv = p0 >= b ? 0u : (b - p0 < 16u ? b - p0 : 16u);            /* positions of this lane inside the window */
+    uint32_t fw[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t rw[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rw[i] = 0u;
+    if (nv) {
+        const BrxB16 f = *reinterpret_cast<const BrxB16 *>(F + p0);              /* F holds 16 bytes behind the read */
+        fw[0] = f.x; fw[1] = f.y; fw[2] = f.z; fw[3] = f.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const BrxU4 r4 = *reinterpret_cast<const BrxU4 *>(repl + p0 + 4u * (uint32_t)q);
+            rw[4 * q] = r4.x; rw[4 * q + 1] = r4.y; rw[4 * q + 2] = r4.z; rw[4 * q + 3] = r4.w;
         }
-        const uint32_t inc = wave_incl_scan(len);
-        if (valid) {
-            const uint32_t o = run + inc - len;
-            if (!w) {
-                if (o < tmax) tbuf[o] = fb;
-                if constexpr (PLANES) { if (o < BRX_PARK_LDS) brx_park_lds[o] = fb; }
-            } else for (uint32_t x = 0; x < len; ++x) {
-                const uint8_t ch = rep_char(em, w, x);
-                o_ |= ch > 3;
-                if (o + x < tmax) tbuf[o + x] = ch;
-                if constexpr (PLANES) { if (o + x < BRX_PARK_LDS) brx_park_lds[o + x] = ch; }
+    }
+    /* positions behind the window: byte 0xFF (the query's terminator), no replacement, no length */
+    uint32_t L = 0u;
+    bool o_ = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const bool in = (uint32_t)i < nv;
+        if (!in) { rw[i] = 0u; fw[i >> 2] |= 0xFFu << (8 * (i & 3)); }
+        else { L += rep_len(rw[i]); o_ |= ((fw[i >> 2] >> (8 * (i & 3))) & 0xFCu) != 0u; }
+    }
+    const uint32_t inc = wave_incl_scan(L);
+    const uint32_t run = wave_bcast_u32(inc, 63);
+    /* ---- query: the bytes in one 16-byte row per lane (rows up to 16 bytes behind the window carry the 0xFF terminator) ---- */
+    if (16u * (uint32_t)lane < ql + 16u) {
+        BrxU4 q4; q4.x = fw[0]; q4.y = fw[1]; q4.z = fw[2]; q4.w = fw[3];
+        *reinterpret_cast<BrxU4 *>(qb + 16u * (uint32_t)lane) = q4;
+    }
+    if constexpr (PLANES) {
+        uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t nvq = nv > 4u * (uint32_t)q ? (nv - 4u * (uint32_t)q >= 4u ? 0xFFFFFFFFu : (1u << (8u * (nv - 4u * (uint32_t)q))) - 1u) : 0u;
+            const uint32_t v = fw[q] & nvq;
+            lo |= brx_byte_bits(v, 0) << (4 * q); hi |= brx_byte_bits(v, 1) << (4 * q);
+        }
+        const uint32_t lo1 = (uint32_t)__shfl_down((int)lo, 1, 64), hi1 = (uint32_t)__shfl_down((int)hi, 1, 64);
+        /* words 0 .. 2 ceil(ql / 64) - 1, as the 64-position steps wrote them */
+        if (!(lane & 1) && 16u * (uint32_t)lane < ((ql + 63u) & ~63u)) { pl[lane >> 1] = lo | (lo1 << 16); pl[32 + (lane >> 1)] = hi | (hi1 << 16); }
+    }
+    /* ---- target: this lane's stretch of the joined string into the LDS window ---- */
+    uint32_t o = inc - L, c = 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if ((uint32_t)i < nv) {
+            const uint32_t w = rw[i];
+            const uint8_t fb = (uint8_t)(fw[i >> 2] >> (8 * (i & 3)));
+            if (!w) { if (o < tmax) brx_park_lds[o] = fb; o += 1u; }
+            else {
+                const uint32_t len = (w >> 24) & 0x7Fu;
+                bool has = false;
+                for (uint32_t x = 0; x < len; ++x) {
+                    const uint8_t ch = rep_char(em, w, x);
+                    o_ |= ch > 3; has |= ch == fb;
+                    if (o + x < tmax) brx_park_lds[o + x] = ch;
+                }
+                c += len < 2u ? 1u : len - (has ? 1u : 0u);                        /* rep_cost */
+                o += len;
             }
         }
-        run += wave_bcast_u32(inc, 63);
     }
-    const uint32_t ql = b - a;
-    for (uint32_t x = lane; x < 16; x += 64) { qb[ql + x] = 0xFF; if (run <= tmax) tbuf[run + x] = 0xFE; }
+    if (run <= tmax && lane < 16) brx_park_lds[run + (uint32_t)lane] = 0xFE;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                           /* the LDS bytes of every lane are in place */
+    const uint32_t nbytes = run <= tmax ? run + 16u : tmax;
+    for (uint32_t g = (uint32_t)lane; 16u * g < nbytes; g += 64u)
+        *reinterpret_cast<BrxU4 *>(tbuf + 16u * g) = *reinterpret_cast<const BrxU4 *>(brx_park_lds + 16u * g);
     if constexpr (PLANES) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);                       /* the LDS bytes of every lane are in place */
         const uint32_t tl = run < BRX_PARK_LDS ? run : BRX_PARK_LDS;
-        for (uint32_t t = 0; 64u * t < tl; ++t) {
-            const uint32_t x = 64u * t + (uint32_t)lane;
-            const uint32_t ch = x < tl ? brx_park_lds[x] : 0u;
-            const unsigned long long lo = __ballot(ch & 1u), hi = __ballot(ch & 2u);
-            if (lane < 2) { pl[64 + 2 * t + lane] = (uint32_t)(lo >> (32 * lane)); pl[64 + BRX_LANE_TMAX / 32 + 2 * t + lane] = (uint32_t)(hi >> (32 * lane)); }
+        for (uint32_t g0 = 0; 16u * g0 < ((tl + 63u) & ~63u); g0 += 64u) {
+            const uint32_t g = g0 + (uint32_t)lane;
+            const BrxU4 t4 = *reinterpret_cast<const BrxU4 *>(brx_park_lds + 16u * (g < (BRX_STAGE_WORDS / 4u) ? g : 0u));
+            const uint32_t tv[4] = {t4.x, t4.y, t4.z, t4.w};
+            uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t at = 16u * g + 4u * (uint32_t)q;
+                const uint32_t live = at >= tl ? 0u : (tl - at >= 4u ? 0xFFFFFFFFu : (1u << (8u * (tl - at))) - 1u);
+                const uint32_t v = tv[q] & live;
+                lo |= brx_byte_bits(v, 0) << (4 * q); hi |= brx_byte_bits(v, 1) << (4 * q);
+            }
+            const uint32_t lo1 = (uint32_t)__shfl_down((int)lo, 1, 64), hi1 = (uint32_t)__shfl_down((int)hi, 1, 64);
+            if (!(lane & 1) && 16u * g < ((tl + 63u) & ~63u)) { pl[64 + (g >> 1)] = lo | (lo1 << 16); pl[64 + BRX_LANE_TMAX / 32 + (g >> 1)] = hi | (hi1 << 16); }
         }
     }
     *cost = wave_sum(c);
@@ -185,12 +251,17 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
         uint32_t *cmg = Cbuf + (s.F_off >> 4);
         const uint32_t nw2 = (n + 15u) >> 4, nwc = (n + 31u) >> 5;
         const bool coded = uni(f2g[nw2] == 0u);
-        const uint32_t cm0 = nw2 + 1u;                                   /* first word of the map in the slice */
-        const bool staged = !INLINE && coded && uni(cm0 + nwc <= stage_words);
+        /* the slice: [0, nwc) the changed map when it fits (reads up to 82 kb), behind it the codes when they fit as well
+           (up to 27 kb).  With the map in LDS an applied change is visible to the next survivor's test without waiting
+           for its store to repl[] to come back (the fence per change below: ~2 k cycles each, 25 per cycle). */
+        const bool staged_cm = !INLINE && uni(nwc <= stage_words);
+        const bool staged = staged_cm && uni(nwc + nw2 + 1u <= stage_words);
+        const uint32_t *oddg = cmg + nwc;                                /* a bit per base: a symbol outside ACGT (k_build) */
+        const uint32_t f20 = nwc;                                        /* first word of the codes in the slice */
         if constexpr (!INLINE) {
-            if (staged) {
-                for (uint32_t x = (uint32_t)lane; x <= nw2; x += 64u) brx_stage_lds[x] = f2g[x];
-                for (uint32_t x = (uint32_t)lane; x < nwc; x += 64u) brx_stage_lds[cm0 + x] = cmg[x];
+            if (staged_cm) {
+                for (uint32_t x = (uint32_t)lane; x < nwc; x += 64u) brx_stage_lds[x] = cmg[x];
+                if (staged) for (uint32_t x = (uint32_t)lane; x <= nw2; x += 64u) brx_stage_lds[f20 + x] = f2g[x];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_s_waitcnt(0);
             }
@@ -234,71 +305,70 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
             const uint32_t B = room < 64 ? (uint32_t)room : 64u;
             /* ---- propose (identical draws on a resumed round) ---- */
             BRX_PHASE(0);
-            uint32_t rep[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) rep[j] = 0;
-            bool live = false;
+            BrxProp pr; pr.x = pr.y = pr.z = 0u;
             uint64_t ipos = 0;
             if ((uint32_t)lane < B) {
                 uint32_t w[4];
                 brx_draw4(d.seed, read, BRX_ST_MUT, loops + (uint64_t)lane, w);
                 ipos = brx_mulhi64(((uint64_t)w[1] << 32) | w[0], max_i + 1);
-                if (coded) {
-                    const uint32_t wi = (uint32_t)(ipos >> 4), sh = 2u * ((uint32_t)ipos & 15u);
-                    uint32_t w0, w1;
-                    /* two loads in two address spaces: the empty asm keeps the compiler from folding the branches into ONE load
-                       through a selected generic pointer (a flat load: DESIGN.md section 5, lessons) */
-                    if (staged) { w0 = brx_stage_lds[wi]; w1 = brx_stage_lds[wi + 1u]; BRX_KEEP2(w0, w1); }
-                    else { w0 = f2g[wi]; w1 = f2g[wi + 1u]; BRX_KEEP2(w0, w1); }
-                    const uint32_t row = (uint32_t)(((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) >> (64 - 2 * k));
-                    live = dev_choose_alt_row(em, row, w[2], w[3], rep);
-                } else {
-                    uint8_t kmer[16];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) kmer[j] = j < k ? F[ipos + j] : 0;
-                    live = dev_choose_alt(em, kmer, w[2], w[3], rep);
+                const uint32_t wi = (uint32_t)(ipos >> 4), sh = 2u * ((uint32_t)ipos & 15u);
+                uint32_t w0, w1;
+                /* two loads in two address spaces: the empty asm keeps the compiler from folding the branches into ONE load
+                   through a selected generic pointer (a flat load: DESIGN.md section 5, lessons) */
+                if (staged) { w0 = brx_stage_lds[f20 + wi]; w1 = brx_stage_lds[f20 + wi + 1u]; BRX_KEEP2(w0, w1); }
+                else { w0 = f2g[wi]; w1 = f2g[wi + 1u]; BRX_KEEP2(w0, w1); }
+                const uint32_t row = (uint32_t)(((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) >> (64 - 2 * k));
+                bool bad = false;                   /* a symbol outside ACGT in the k-mer: error_model.py:142-143 */
+                if (!coded) {
+                    const uint32_t p_lo = (uint32_t)ipos;             /* two words of the map: the one behind the last is zero */
+                    const uint64_t both = (((uint64_t)oddg[(p_lo >> 5) + 1u] << 32) | (uint64_t)oddg[p_lo >> 5]) >> (p_lo & 31u);
+                    bad = (both & ((1ull << k) - 1ull)) != 0ull;
                 }
+                if (bad) {
+                    const BrxRc c = dev_random_change_split(w[3], k);
+                    pr.x = dev_random_change_word(c, (uint32_t)F[ipos + c.pos]); pr.y = BRX_PROP_RANDOM | c.pos;
+                } else pr = dev_propose_row(em, row, w[2], w[3]);
             }
-            unsigned long long surv = __ballot(live);
+            unsigned long long surv = __ballot(pr.y != 0u);
             BRX_PHASE(1);
             int j0 = 0;
             if (resume) { surv &= ~((1ull << ms.surv_lane) - 1ull); j0 = (int)ms.j_next; }
             bool first = resume;
+            bool fresh = !resume;                  /* est is 1 - errors / dn of the CURRENT errors (a resumed round starts with the parked estimate and blended errors) */
             resume = false;
             /* ---- apply survivors in iteration order ---- */
             while (surv) {
                 const int l = __ffsll((long long)surv) - 1;
                 surv &= surv - 1;
                 const uint64_t i0 = wave_bcast_u64(ipos, l);
-                const double scale = est * brx_sqrt(est);
-                /* lane j < k takes position j of the k-mer: its replacement word from the proposing lane and
-                   the current state of that position with ONE load for all positions, then the untouched,
+                /* lane j < k takes position j of the k-mer: its replacement word, derived from the proposing lane's three
+                   words, and the current state of that position with ONE load for all positions, then the untouched,
                    changed positions (simulate.py:309) are applied in order */
-                uint32_t wj = 0;
-#pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
-                    if (jj < k) { const uint32_t v = wave_bcast_u32(rep[jj], l); wj = (lane == jj) ? v : wj; }
-                }
+                const uint32_t wj = brx_prop_word(em, wave_bcast_u32(pr.x, l), wave_bcast_u32(pr.y, l), wave_bcast_u32(pr.z, l));
                 uint32_t curj = 1u;
-                if (staged) {
+                if (staged_cm) {
                     const uint32_t pp = (uint32_t)i0 + (uint32_t)lane;
-                    if (lane < k) curj = (brx_stage_lds[cm0 + (pp >> 5)] >> (pp & 31u)) & 1u;
+                    if (lane < k) curj = (brx_stage_lds[pp >> 5] >> (pp & 31u)) & 1u;
                 } else if (lane < k) curj = rp[i0 + (uint64_t)lane];
                 unsigned long long todo = __ballot(lane < k && wj != 0u && curj == 0u);
                 if (first) todo &= ~((1ull << j0) - 1ull);
+                const bool applies = todo != 0ull;
+                /* a survivor whose changed positions are all taken already leaves errors, change and est as they are: the
+                   square root, the division and the tests below would repeat the previous survivor's, bit for bit */
+                const double scale = applies ? est * brx_sqrt(est) : 0.0;
                 while (todo) {
                     const int j = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
                     const uint32_t w = wave_bcast_u32(wj, j);
                     if (lane == j) {
                         rp[i0 + (uint64_t)j] = w;
-                        if (coded) {          /* the map in global memory is what the next pass stages; the slice is what this one reads */
+                        if constexpr (!INLINE) {      /* the map in global memory is what the next pass stages; the slice is what this one reads */
                             const uint32_t pp = (uint32_t)i0 + (uint32_t)j;
                             atomicOr(&cmg[pp >> 5], 1u << (pp & 31u));
-                            if (staged) atomicOr(&brx_stage_lds[cm0 + (pp >> 5)], 1u << (pp & 31u));
+                            if (staged_cm) atomicOr(&brx_stage_lds[pp >> 5], 1u << (pp & 31u));
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (!staged_cm) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      /* the next survivor tests repl[] */
                     change += 1;
                     const uint32_t len = (w >> 24) & 0x7Fu;
                     errors += (double)(len < 2 ? 1u : len - 1u) * scale;
@@ -313,6 +383,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                             b = a + BRX_ALIGN_SIZE;
                         }
                         nalign += 1;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      /* repl[] as the other lanes left it */
                         __builtin_amdgcn_s_waitcnt(0);
                         /* one pass over the window: F[a:b] -> query slot, join(new[a:b]) -> target slot (clipped to the
                            slot; an overflowing window goes to the whole-read kernel), edit bound, non-ACGT flag */
@@ -359,9 +430,12 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                 if (parked) break;
                 first = false;
                 /* top-of-loop tests of the iteration that follows this survivor */
-                const double est2 = 1.0 - errors / dn;
-                if ((double)change > 0.9 * dn || est2 <= target) { loops += (uint64_t)l + 2; done = true; break; }
-                est = est2;
+                if (applies || !fresh) {
+                    const double est2 = 1.0 - errors / dn;
+                    if ((double)change > 0.9 * dn || est2 <= target) { loops += (uint64_t)l + 2; done = true; break; }
+                    est = est2;
+                    fresh = true;
+                }
             }
             if (parked || done) break;
             loops += B;
@@ -397,6 +471,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
             continue;
         }
         /* epilogue: lengths of the mutated read, trims (simulate.py:348-349), proven distance bound */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         uint32_t cost = 0;
         const uint32_t m = wave_join(em, F, rp, 0, n, nullptr, &cost);

@@ -47,7 +47,8 @@ class BrxErrorModel(ctypes.Structure):
     _fields_ = [('k', ctypes.c_int32), ('type', ctypes.c_int32), ('n_rows', ctypes.c_uint32),
                 ('n_alts', ctypes.c_uint32), ('pool_len', ctypes.c_uint32), ('pad_', ctypes.c_uint32),
                 ('d_row_off', ctypes.c_void_p), ('d_self_thr', ctypes.c_void_p), ('d_thr', ctypes.c_void_p),
-                ('d_desc', ctypes.c_void_p), ('d_pool', ctypes.c_void_p)]
+                ('d_desc', ctypes.c_void_p), ('d_pool', ctypes.c_void_p),
+                ('d_rowx', ctypes.c_void_p), ('d_altx', ctypes.c_void_p)]
 
 
 class BrxQScoreModel(ctypes.Structure):
@@ -178,14 +179,18 @@ class EngineBase(object):
     def _fill_error_model(self, t):
         s = BrxErrorModel()
         s.k, s.type, s.n_rows, s.n_alts, s.pool_len = t['k'], t['type'], t['n_rows'], t['n_alts'], len(t['pool'])
+        held = t
+        if 'rowx' not in t:                  # a table dict built by hand (tests): the lookup-order layout is derived here
+            from .error_model import derive_lookup_tables
+            t = dict(t, **derive_lookup_tables(t))
         keep = []
         for field, key in (('d_row_off', 'row_off'), ('d_self_thr', 'self_thr'), ('d_thr', 'thr'),
-                           ('d_desc', 'desc'), ('d_pool', 'pool')):
+                           ('d_desc', 'desc'), ('d_pool', 'pool'), ('d_rowx', 'rowx'), ('d_altx', 'altx')):
             ptr, k = self._upload(t[key])
             setattr(s, field, ptr)
             keep.append(k)
         self._keep['em'] = keep
-        self._configured = dict(getattr(self, '_configured', {}), em=t)       # which tables this engine holds now (simulate.sequence_fragment)
+        self._configured = dict(getattr(self, '_configured', {}), em=held)    # which tables this engine holds now (simulate.sequence_fragment)
         return s
 
     def _fill_qscore_model(self, t):

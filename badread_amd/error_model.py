@@ -156,6 +156,31 @@ def add_one_random_change(kmer):
 
 
 # ---------------------------------------------------------------------------------------------
+def derive_lookup_tables(t):
+    """The lookup-order layout of an error-model table (include/brx.h, d_rowx / d_altx): one load per step of
+    add_errors_to_kmer's choice (error_model.py:135-160) instead of a chain of ten.  Returns rowx, altx and thr padded by
+    eight zero entries (thresholds are scanned in blocks of eight)."""
+    k, n_rows, n_alts = int(t['k']), int(t['n_rows']), int(t['n_alts'])
+    rowx = np.zeros(2 * (n_rows + 1) + 4, dtype=np.uint32)
+    rowx[0:2 * n_rows:2] = t['self_thr'][:n_rows]
+    rowx[1:2 * (n_rows + 1):2] = t['row_off'][:n_rows + 1]
+    pool = t['pool']
+    desc = t['desc'][:n_alts].astype(np.int64)
+    altx = np.zeros(4 * max(n_alts, 1), dtype=np.uint32)
+    if n_alts:
+        diff = pool[desc].astype(np.uint32) | (pool[desc + 1].astype(np.uint32) << 8)
+        lens = np.stack([pool[desc + 2 + j].astype(np.uint32) if j < k else np.zeros(n_alts, np.uint32) for j in range(8)], axis=1)
+        long_ = (lens.max(axis=1) > 15) | (k > 8)
+        packed = np.zeros(n_alts, dtype=np.uint32)
+        for j in range(8):
+            packed |= (lens[:, j] & 15) << np.uint32(4 * j)
+        altx[0::4] = t['desc'][:n_alts]
+        altx[1::4] = diff | (long_.astype(np.uint32) << 16)
+        altx[2::4] = np.where(long_, 0, packed)
+    thr = np.concatenate([t['thr'][:max(n_alts, 1)], np.zeros(8, dtype=np.uint32)])
+    return dict(rowx=rowx, altx=altx, thr=thr)
+
+
 class ErrorModel(object):
 
     def __init__(self, model_type_or_filename, output=sys.stderr, aligner=None, use_cache=True):
@@ -312,7 +337,8 @@ class ErrorModel(object):
             pool = _preamble()
             self._tables = dict(k=1, type=0, n_rows=0, n_alts=0,
                                 row_off=np.zeros(1, np.uint32), self_thr=np.zeros(1, np.uint32),
-                                thr=np.zeros(1, np.uint32), desc=np.zeros(1, np.uint32), pool=pool)
+                                thr=np.zeros(9, np.uint32), desc=np.zeros(1, np.uint32), pool=pool,
+                                rowx=np.zeros(8, np.uint32), altx=np.zeros(4, np.uint32))
             return self._tables
         k = self.kmer_size
         if k > 9:
@@ -367,6 +393,7 @@ class ErrorModel(object):
             sys.exit('Error: error model too large for the HIP path (alternative pool exceeds 16 MiB)')
         self._tables = dict(k=k, type=1, n_rows=n_rows, n_alts=n_alts, row_off=row_off, self_thr=self_thr,
                             thr=thr, desc=desc, pool=np.frombuffer(bytes(pool), dtype=np.uint8).copy())
+        self._tables.update(derive_lookup_tables(self._tables))
         return self._tables
 
     # ------------------------------------------------------------------ cache (.npz)

@@ -110,6 +110,17 @@ typedef struct {
     const uint32_t *d_thr;      /* [n_alts]                                                      */
     const uint32_t *d_desc;     /* [n_alts]                                                      */
     const uint8_t *d_pool;      /* [pool_len]                                                    */
+    /* The same table laid out for ONE load per step of the lookup (round 4; required when type = 1).  The proposal rounds of
+     * the mutate loop are chains of dependent L2 round trips: self_thr -> row_off -> five probes of a binary search -> desc ->
+     * pool was ten deep; with these it is three (row entry -> a block of eight thresholds -> the alternative's descriptor).
+     *   d_rowx[2 r], [2 r + 1] = self_thr[r], row_off[r] for r <= n_rows (self_thr[n_rows] = 0): a 16-byte load at row r
+     *            also holds row_off[r + 1]; 16 bytes of padding behind the last pair.
+     *   d_thr    must be readable 8 entries past n_alts (zeros): thresholds are scanned in blocks of eight.
+     *   d_altx[4 a .. 4 a + 3] = desc[a]; diff | flags << 16; lengths of positions 0-7 in 4 bits each; 0.
+     *            flags bit 0: a length above 15 or k > 8 -- the kernel then reads the lengths from the pool.
+     * badread_amd.error_model.derive_lookup_tables builds both from the arrays above.                */
+    const uint32_t *d_rowx;     /* [2 (n_rows + 1) + 4]                                          */
+    const uint32_t *d_altx;     /* [4 n_alts]                                                    */
 } brx_error_model;
 
 /* ------------------------------------------------------------------ qscore model (qscore_model.py:178-287)
