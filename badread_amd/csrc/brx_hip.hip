@@ -47,12 +47,13 @@ struct brx_ctx {
     uint32_t lane_threshold;
     uint32_t lane_waves;         /* BRX_LANE_WAVES: most waves of one k_win_lane launch */
     uint32_t stage_words;        /* BRX_STAGE_WORDS: LDS words of a pass wave's slice that may hold a read (0 = never stage; at most the compiled size) */
-    uint32_t run_wps_head, run_wps_tail;   /* BRX_RUN_WPS_HEAD / _TAIL: register budget (waves per SIMD: 2 or 4) of the run-to-completion launches */
     uint32_t fin_head_reads;     /* BRX_FIN_HEAD_READS: the longest reads of a batch form the head set of the final stage (side streams) */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
     int wide_stream;             /* BRX_WIDE_STREAM: the head set's widest band class aligns on a third stream */
     hipStream_t side2;
     hipEvent_t ev_fork2[2], ev_join2[2], ev_head_mut;
+    hipEvent_t ev_fork3, ev_join3[2];   /* the bulk set's band classes on the head chain's streams */
+    int fin_spread;                      /* BRX_FIN_SPREAD (default 1) */
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
                                     three wide classes: a stream per class measured 30 % slower, r01d) */
     hipEvent_t ev_fork, ev_join;
@@ -116,6 +117,8 @@ static void release(brx_ctx *c) {
     if (c->side2) (void)hipStreamDestroy(c->side2);
     for (int i = 0; i < 2; ++i) { if (c->ev_fork2[i]) (void)hipEventDestroy(c->ev_fork2[i]); if (c->ev_join2[i]) (void)hipEventDestroy(c->ev_join2[i]); }
     if (c->ev_head_mut) (void)hipEventDestroy(c->ev_head_mut);
+    if (c->ev_fork3) (void)hipEventDestroy(c->ev_fork3);
+    for (int i = 0; i < 2; ++i) if (c->ev_join3[i]) (void)hipEventDestroy(c->ev_join3[i]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -162,10 +165,12 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         if ((e = hipEventCreateWithFlags(&c->ev_fork2[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&c->ev_join2[i], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_head_mut, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_fork3, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_join3[0], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_join3[1], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
+    { const char *v = getenv("BRX_FIN_SPREAD"); c->fin_spread = v ? atoi(v) : 1; }
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 512u; }
     { const char *v = getenv("BRX_STAGE_WORDS"); c->stage_words = v ? std::min<uint32_t>((uint32_t)atoi(v), (uint32_t)BRX_STAGE_WORDS) : (uint32_t)BRX_STAGE_WORDS; }
-    { const char *v = getenv("BRX_RUN_WPS_HEAD"); c->run_wps_head = v && atoi(v) == 2 ? 2u : 4u; }
-    { const char *v = getenv("BRX_RUN_WPS_TAIL"); c->run_wps_tail = v && atoi(v) == 2 ? 2u : 4u; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
     /* a context owns exactly three streams besides the caller's: every stream of a context takes a hardware queue, and two idle
@@ -177,7 +182,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
     { const char *pf = getenv("BRX_PROFILE"); c->profile = (pf && atoi(pf)) ? 1 : 0; }
     { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
-    { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 0xFFFFFFFFu; }   /* unset: a twelfth of the batch, at least 1024 */
+    { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 0xFFFFFFFFu; }   /* unset: an eighth of the batch, at least 1024 */
     { const char *sw = getenv("BRX_SEG_WAVES_PER_CU"); c->seg_waves_per_cu = sw && atoi(sw) > 0 ? (uint32_t)atoi(sw) : 8u; }
     { const char *lt = getenv("BRX_LANE_THRESHOLD"); c->lane_threshold = lt ? (uint32_t)atoi(lt) : 3000u; }
     { const char *v = getenv("BRX_LANE_WAVES"); c->lane_waves = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 512u; }
@@ -412,7 +417,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint2 *lane_tb = (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
     /* traceback stores of the packed window aligner: one set of 8 per wave of k_win_pack */
     const uint32_t pack_waves = std::min<uint32_t>((std::min<uint32_t>(n_reads, c->lane_threshold) + BRX_PACK_NG - 1) / BRX_PACK_NG, (uint32_t)c->n_cu * 4u);
-    const uint32_t tail_eff = c->tail_reads != 0xFFFFFFFFu ? c->tail_reads : std::max<uint32_t>(1024u, n_reads / 12u);
+    const uint32_t tail_eff = c->tail_reads != 0xFFFFFFFFu ? c->tail_reads : std::max<uint32_t>(1024u, n_reads / 8u);
     const bool all_head = c->mutate_inline || n_reads <= tail_eff;      /* the whole batch in one run-to-completion launch */
     uint2 *pack_tb = (uint2 *)A.take((size_t)std::max<uint32_t>(pack_waves, 1u) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
@@ -597,25 +602,45 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                                reinterpret_cast<unsigned long long *>(cq + 6), d_slabs + slab_at[3], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
         }
         if (fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
+        /* The 4-, 2- and 1-word classes are independent (own lists, own slabs), each scored (k_fin_qscore on its class-pure list) as
+           soon as it is aligned.  The bulk set spreads them over the head chain's two streams, which are idle by the time the
+           bulk passes end (round 3 ran the three classes and their scoring one after the other on the set's stream: ~490 ms of
+           the batch's critical path where the longest of them takes ~300). */
+        const bool spread = c->fin_spread && S.id == 1 && sets[0].e > sets[0].b && c->side != S.st;
+        hipStream_t cls_stream[3] = {S.st, spread ? c->side : S.st, spread ? c->side2 : S.st};
+        if (spread) {
+            HIPCHK(c, hipEventRecord(c->ev_fork3, S.st));
+            HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork3, 0));
+            HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork3, 0));
+        }
+        auto score_class = [&](int k, hipStream_t s_, uint32_t *queue) {
+            KTIMED(BRX_KERN_FIN_QSCORE, s_);
+            hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(cnt[k], waves)), dim3(64), 0, s_, dev, rs, d_lists + list_at[k], 0u, cnt[k], queue,
+                               phase, 0, 0xFFFF, c->scratch, c->scratch, col_base, clk);
+        };
         if (cnt[2]) {
-            KTIMED(BRX_KERN_FIN_ALIGN4, S.st);
-            hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(grid[2]), dim3(64), 0, S.st, dev, rs, d_lists + list_at[2], cnt[2],
-                               reinterpret_cast<unsigned long long *>(cq + 4), d_slabs + slab_at[2], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
+            { KTIMED(BRX_KERN_FIN_ALIGN4, cls_stream[2]);
+              hipLaunchKernelGGL((k_fin_align<4, 4, 4>), dim3(grid[2]), dim3(64), 0, cls_stream[2], dev, rs, d_lists + list_at[2], cnt[2],
+                                 reinterpret_cast<unsigned long long *>(cq + 4), d_slabs + slab_at[2], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk); }
+            score_class(2, cls_stream[2], cq + 11);
         }
         if (cnt[1]) {
-            KTIMED(BRX_KERN_FIN_ALIGN2, S.st);
-            hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(grid[1]), dim3(64), 0, S.st, dev, rs, d_lists + list_at[1], cnt[1],
-                               reinterpret_cast<unsigned long long *>(cq + 2), d_slabs + slab_at[1], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
+            { KTIMED(BRX_KERN_FIN_ALIGN2, cls_stream[1]);
+              hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(grid[1]), dim3(64), 0, cls_stream[1], dev, rs, d_lists + list_at[1], cnt[1],
+                                 reinterpret_cast<unsigned long long *>(cq + 2), d_slabs + slab_at[1], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk); }
+            score_class(1, cls_stream[1], cq + 10);
         }
         if (cnt[0]) {
-            KTIMED(BRX_KERN_FIN_ALIGN1, S.st);
-            hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(grid[0]), dim3(64), 0, S.st, dev, rs, d_lists + list_at[0], cnt[0],
-                               reinterpret_cast<unsigned long long *>(cq + 0), d_slabs + slab_at[0], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
+            { KTIMED(BRX_KERN_FIN_ALIGN1, cls_stream[0]);
+              hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(grid[0]), dim3(64), 0, cls_stream[0], dev, rs, d_lists + list_at[0], cnt[0],
+                                 reinterpret_cast<unsigned long long *>(cq + 0), d_slabs + slab_at[0], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk); }
+            score_class(0, cls_stream[0], cq + 8);
         }
-        {
-            KTIMED(BRX_KERN_FIN_QSCORE, S.st);
-            hipLaunchKernelGGL(k_fin_qscore, dim3(waves), dim3(64), 0, S.st, dev, rs, order, b, e, cq + 8, phase, 1, 4,
-                               c->scratch, c->scratch, col_base, clk);
+        if (spread) {
+            HIPCHK(c, hipEventRecord(c->ev_join3[0], c->side));
+            HIPCHK(c, hipEventRecord(c->ev_join3[1], c->side2));
+            HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join3[0], 0));
+            HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join3[1], 0));
         }
         if (fork) HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join2[S.id], 0));
         if (cnt[3]) {
@@ -714,14 +739,13 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
        taking these windows to a cheaper aligner -- workgroups of 8 reads with packed alignments, 8-wave pass kernels, a
        persistent launch with device queues -- and every one lost to this chain on the batch's critical path: DESIGN.md section 7.) */
     auto launch_run = [&](hipStream_t s, uint32_t count, const uint32_t *act_in, const uint32_t *n_in, uint32_t *act_out, uint32_t *ctr,
-                          uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr, uint32_t wps) {
+                          uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr) {
         KTIMED(BRX_KERN_MUTATE_RUN, s);
-#define BRX_LAUNCH_RUN(PROF, WPS)                                                                                                   \
-        hipLaunchKernelGGL((k_mutate_seg<true, PROF, WPS>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in,   \
+#define BRX_LAUNCH_RUN(PROF)                                                                                                        \
+        hipLaunchKernelGGL((k_mutate_seg<true, PROF, BRX_SEG_WPS>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in,   \
                            act_out, ctr, req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,        \
                            winscr, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words)
-        if (c->profile) { if (wps == 2) BRX_LAUNCH_RUN(true, 2); else BRX_LAUNCH_RUN(true, 4); }
-        else { if (wps == 2) BRX_LAUNCH_RUN(false, 2); else BRX_LAUNCH_RUN(false, 4); }
+        if (c->profile) BRX_LAUNCH_RUN(true); else BRX_LAUNCH_RUN(false);
 #undef BRX_LAUNCH_RUN
     };
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_MUTATE], st));
@@ -732,7 +756,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
         }
         launch_run(s_head, n_mh, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, req_legacy_head,
-                   mctr + 5 * MC_WORDS, win_head, n_mb ? c->run_wps_head : c->run_wps_tail);
+                   mctr + 5 * MC_WORDS, win_head);
         if (n_mb) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
         c->mutate_passes = 1;
     }
@@ -767,7 +791,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                     HIPCHK(c, hipStreamSynchronize(st));
                     for (uint32_t x : h_act) if (x < n_reads) tail_bases += h_rs[x].n;
                 }
-                launch_run(st, n_up, act_in, n_in, act_out, ctr, req_legacy, legacy_ctr, win, c->run_wps_tail);
+                launch_run(st, n_up, act_in, n_in, act_out, ctr, req_legacy, legacy_ctr, win);
                 rc2 = read_counts(ctr);
                 if (rc2) return rc2;
                 n_up = h_ctr[MC_OUT];                   /* 0 unless a window overflowed its slot (then: legacy list) */

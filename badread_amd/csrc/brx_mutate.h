@@ -9,12 +9,16 @@
  * every alignment:
  *
  *   k_mutate_seg   1 wave = 1 read.  Runs the loop until the read finishes or reaches an alignment;
- *                  there it writes the window pair to the read's slot, saves the loop state (MS) and
- *                  parks the read.  On the next pass it resumes in the middle of the same k-mer.
- *   k_win_lane     1 LANE = 1 parked window (64 windows per wave): banded block Myers over the
- *                  window with the query as 2-bit planes, the target planes and the band state in
- *                  LDS, traceback words to global memory in a lane-interleaved layout, then a
- *                  per-lane canonical traceback that prefetches 8 columns per memory round trip.
+ *                  there it writes the window pair to the read's slot (bytes and 2-bit planes), saves the
+ *                  loop state (MS) and parks the read.  On the next pass it resumes in the middle of the
+ *                  same k-mer.  k-mers come from the read's 2-bit codes (F2) and the "already changed"
+ *                  test from a bit map, both staged in the wave's LDS slice for reads that fit; the error
+ *                  model is read through its lookup-order tables (include/brx.h: d_rowx, d_altx).
+ *   k_win_lane     1 LANE = 1 parked window (64 windows per wave): banded block Myers over the window
+ *                  with the band state, the query planes and a 32-column window of the target planes in
+ *                  REGISTERS (the lanes are skewed so that every band moves in the same loop trip; no
+ *                  LDS), 2-bit move codes to global memory in a [trip][slot][lane] layout, then a per-lane
+ *                  canonical traceback on those codes, 16 columns per memory round trip.
  *   k_win_wave     1 wave = 1 parked window, for windows the lane kernel does not take (non-ACGT
  *                  symbols, very wide bands, very long targets): the wave-systolic aligner.
  *
@@ -27,7 +31,7 @@
 #define BRX_MUTATE_H
 
 #ifndef BRX_SEG_WPS
-#define BRX_SEG_WPS 3                                    /* register budget of the pass kernel k_mutate_seg<false>: waves per SIMD */
+#define BRX_SEG_WPS 4                                    /* register budget of the mutate kernels: waves per SIMD (below) */
 #endif
 #define BRX_WIN_Q 1024                                   /* slot bytes reserved for the window of F           */
 #define BRX_WIN_BYTES 5120                               /* byte part of a slot: [0,1024) query, then target  */
@@ -213,9 +217,12 @@ __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F
  * kernel that needs 4-8 free wave slots on ONE CU is dispatched late), a workgroup kernel with packed alignments (round 2: 1.57-1.71
  * vs 2.04), a persistent launch with device queues (round 3: 0.65-1.6 vs 2.96).  What the table would save
  * is one 4-byte L2 hit per proposal. */
-/* WPS = waves per SIMD the register budget is set for.  The run-to-completion instantiation carries the wave aligner's
- * registers beside the loop state: at four waves per SIMD (128 VGPRs) it keeps 128 B per lane in scratch memory, at two
- * (197 VGPRs) nothing.  The head chain is 1024 waves -- one per SIMD -- so the four-wave budget bought it nothing. */
+/* WPS = waves per SIMD the register budget is set for.  Measured (round 4, configs[3], six batches in flight): the run-to-
+ * completion instantiation carries the wave aligner's registers beside the loop state and keeps 160 B per lane in scratch memory
+ * at four waves per SIMD (128 VGPRs), nothing at two (214) -- and the un-spilled build is SLOWER (4.30-4.34 against 4.46 Gbases/s,
+ * again 4.70-4.72 against 4.76 on the next tree): the head chain is one wave per SIMD, but its registers are taken from the
+ * other five batches' kernels on the same SIMDs.  The pass kernel at three waves (156 VGPRs, no scratch) against four (128,
+ * 116 B): 4.76 against 4.88.  Four it is, for both. */
 template <bool INLINE, bool PROFILE = false, int WPS = 4>
 __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
                                                     const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,

@@ -469,10 +469,6 @@ def main():
             raw.close()
         engines[:] = [first]
 
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
     n_batches = args.steps * C
     stage_sum, kern = {}, {}
     for a in acc:
@@ -481,6 +477,32 @@ def main():
         for name, (n_l, ms, b) in a['kernels'].items():
             k = kern.setdefault(name, [0, 0.0, 0.0])
             k[0] += n_l; k[1] += ms; k[2] += b
+    extra = {'passes': float(sum(a['passes'] for a in acc)), 'misses': float(sum(a['misses'] for a in acc)),
+             'host_ms': float(sum(a['host_ms'] for a in acc)), 'host_cpu_s': float(host_cpu_s),
+             'lane_useful': float(sum(a['lane_useful'] for a in acc)), 'lane_issued': float(sum(a['lane_issued'] for a in acc))}
+    if dist is not None and not dry:
+        # the per-kernel, per-stage and host statistics of EVERY rank (round 3 reported rank 0's alone): one sum over a fixed layout
+        from badread_amd.engine import KERNEL_NAMES, STAGE_NAMES
+        vec = [stage_sum.get(n, 0.0) for n in STAGE_NAMES]
+        for n in KERNEL_NAMES:
+            vec += list(kern.get(n, [0, 0.0, 0.0]))
+        vec += [extra[k] for k in sorted(extra)]
+        tv = torch.tensor(vec, dtype=torch.float64, device='cuda')
+        dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+        vec = tv.tolist()
+        stage_sum = dict(zip(STAGE_NAMES, vec[:len(STAGE_NAMES)]))
+        at = len(STAGE_NAMES)
+        kern = {}
+        for n in KERNEL_NAMES:
+            if vec[at]:
+                kern[n] = [vec[at], vec[at + 1], vec[at + 2]]
+            at += 3
+        extra = dict(zip(sorted(extra), vec[at:]))
+        n_batches *= world
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     stages = {k: v / n_batches for k, v in stage_sum.items()}          # per device batch
     bases_per_step_rank0 = sum(a['bases'] for a in acc) / args.steps
     result = {
@@ -537,7 +559,7 @@ def main():
         rate = vpb['valu_per_base'] * value / world
         from badread_amd.build import source_hash
         tree = source_hash()
-        lane_useful, lane_issued = sum(a['lane_useful'] for a in acc), sum(a['lane_issued'] for a in acc)
+        lane_useful, lane_issued = extra['lane_useful'], extra['lane_issued']
         result['roofline_alu'] = {'bound': 'valu-issue', 'achieved': rate, 'peak': VALU_PEAK_PER_S, 'peak_source': 'profiles/valu_rate.json (measured integer VALU issue rate: 4 cycles per wave64 instruction per SIMD)',
                                   'unit': 'wave-instructions/s', 'frac': rate / VALU_PEAK_PER_S,
                                   'peak_guide': 2.0 * VALU_PEAK_PER_S, 'frac_of_guide_peak': rate / (2.0 * VALU_PEAK_PER_S),
@@ -553,13 +575,14 @@ def main():
                                                'useful_lane_frac_aligner_model = band words / (64 lanes x words per lane) of the final alignments of THIS run '
                                                '(the kernels that issue more than half of the instructions)'}
     result['stage_ms_per_device_batch'] = stages
-    result['host_ms_per_device_batch'] = sum(a['host_ms'] for a in acc) / n_batches        # wall time of one brx_simulate_batch call
-    result['host_cpu'] = {'cpu_seconds_per_device_batch': host_cpu_s / n_batches, 'busy_cores_of_this_rank': host_cpu_s / elapsed, 'usable_cores': usable_cores(),
-                          'note': 'process CPU time of rank 0 (six batch threads + main) over the timed region: busy_cores x 8 ranks must fit the usable cores of an 8-GPU node'}
+    result['host_ms_per_device_batch'] = extra['host_ms'] / n_batches        # wall time of one brx_simulate_batch call
+    result['host_cpu'] = {'cpu_seconds_per_device_batch': extra['host_cpu_s'] / n_batches, 'busy_cores_per_rank': extra['host_cpu_s'] / elapsed / world,
+                          'busy_cores_all_ranks': extra['host_cpu_s'] / elapsed, 'usable_cores': usable_cores(),
+                          'note': 'process CPU time of every rank (six batch threads + main each) over the timed region, summed: it must fit the usable cores of the node'}
     result['scratch_or_output_retries'] = sum(getattr(e, 'retries', 0) for e in engines)
     result['retry_log'] = [m for e in engines for m in getattr(e, 'retry_log', [])][:8]
-    result['mutate_passes_per_device_batch'] = sum(a['passes'] for a in acc) / n_batches
-    result['traceback_window_misses_per_step'] = sum(a['misses'] for a in acc) / args.steps
+    result['mutate_passes_per_device_batch'] = extra['passes'] / n_batches
+    result['traceback_window_misses_per_step'] = extra['misses'] / args.steps
     if d2h is not None:
         for key, leg in (('value_incl_d2h', 'devnull'), ('value_incl_d2h_cold', 'devnull_cold'), ('value_incl_gzip', 'gzip1'), ('value_incl_gzip_device', 'gzip_device')):
             if leg in d2h:
@@ -575,6 +598,8 @@ def main():
             result['gpu_over_reference_same_cores'] = value / (ref['per_core'] * result['cpu_baseline']['cores'])
     else:
         result['cpu_baseline'] = None
+        if world > 1:
+            result['cpu_baseline_note'] = 'the CPU leg runs at N = 1 only (the bench contract: rank 0, a bounded sample); the N = 1 line of the same tree carries it'
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()

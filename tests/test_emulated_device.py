@@ -82,7 +82,7 @@ ROUTES = [
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
     {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0, 'BRX_WAVES_PER_CU': 2},       # lane passes; four slab-owning waves per band class reuse their slabs
     {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 0},       # pass waves never stage a read in LDS: 2-bit codes from global memory, changed test on repl[]
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 120, 'BRX_RUN_WPS_HEAD': 4, 'BRX_RUN_WPS_TAIL': 2},   # a slice of 120 words: reads up to 1.2 kb staged, longer ones beside them from global memory; the other register budgets of the run-to-completion launches
+    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 120},   # a slice of 120 words: reads up to 1.2 kb staged, longer ones beside them from global memory
 ]
 
 

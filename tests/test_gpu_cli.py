@@ -118,3 +118,63 @@ def test_two_ranks_on_one_gpu_give_the_single_rank_bytes(tmp_path):
                         '--master-port', str(port), str(script)], cwd=REPO, env=env, capture_output=True, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     assert open(out_path, 'rb').read() == single
+
+
+def _launch_ranks(tmp_path, world, extra_args, env_extra, out_name='ranks.fastq'):
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    out_path = tmp_path / out_name
+    script = tmp_path / 'rank.py'
+    argv = ["badread", "simulate", "--reference", SMALL_REF, "--quantity", "40x", "--length", "400,300", "--seed", "11"] + list(extra_args)
+    script.write_text(
+        'import os, sys\n'
+        f'sys.path.insert(0, {REPO!r})\n'
+        'from badread_amd.__main__ import main\n'
+        f'sys.argv = {argv!r}\n'
+        'if int(os.environ.get("RANK", "0")) == 0:\n'
+        f'    sys.stdout = open({str(out_path)!r}, "w")\n'
+        'main()\n'
+        'sys.stdout.flush()\n')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), **env_extra)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), str(script)], cwd=REPO, env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return out_path
+
+
+def test_two_ranks_on_two_gpus_over_rccl_give_the_single_rank_bytes(tmp_path):
+    """the `nccl` flavour of the three distributed calls of the driver -- Shard.gather_words (all_gather
+    of device tensors), Shard.collect_bytes (send / recv of device tensors: the records travel GPU to GPU over xGMI) and the
+    seed broadcast -- with one rank per GPU, against the single-process bytes.  Skips itself on a box with fewer than two
+    devices (the builder's and the round-end 1-GPU boxes); the driver's multi-GPU box runs it before the scaling curve."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (RCCL refuses two ranks on one device)')
+    single, _ = run_cli('--quantity', '40x')
+    out_path = _launch_ranks(tmp_path, 2, [], {})
+    assert open(out_path, 'rb').read() == single
+    # and every rank writing its own shard (no record leaves its GPU for another)
+    prefix = str(tmp_path / 'shard')
+    _launch_ranks(tmp_path, 2, ['--output-shards', prefix], {}, out_name='unused.fastq')
+    import test_host_simulate as THS
+    got, parts = THS.reassemble(prefix, 2)
+    assert got == single and len(parts[0]) == len(parts[1])
+
+
+def test_output_shards_with_the_hip_engine_on_one_gpu(tmp_path):
+    """--output-shards on the real engine: two ranks on device 0 (exchange over gloo), each writing the records of its own
+    reads from its own pinned ring; the files put back batch by batch, rank after rank, are the single-process bytes, and
+    with --gzip-device the members each rank packed on the GPU decompress to the same records."""
+    import gzip
+    import test_host_simulate as THS
+    single, _ = run_cli('--quantity', '40x')
+    prefix = str(tmp_path / 'shard')
+    _launch_ranks(tmp_path, 2, ['--output-shards', prefix], dict(BRX_DIST_BACKEND='gloo', BRX_DEVICE='0'))
+    got, _ = THS.reassemble(prefix, 2)
+    assert got == single
+    prefix = str(tmp_path / 'shardz')
+    _launch_ranks(tmp_path, 2, ['--output-shards', prefix, '--gzip-device'], dict(BRX_DIST_BACKEND='gloo', BRX_DEVICE='0'))
+    texts = [gzip.decompress(open(f'{prefix}.{r}.fastq.gz', 'rb').read()) for r in range(2)]
+    assert sorted(THS.parse_fastq(b''.join(texts))) == sorted(THS.parse_fastq(single))

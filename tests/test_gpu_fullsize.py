@@ -31,8 +31,8 @@ SEED = 42
 HEADER = re.compile(rb'length=(\d+) error-free_length=(\d+) read_identity=([0-9.]+)%$')
 
 
-def compare_with_oracle_slices(wlname, ref_dir, n, st, raw, tmp_path, fields):
-    """Every read of [0, n): one oracle process per usable host core on disjoint slices; FASTQ bytes and statistics."""
+def compare_with_oracle_slices(wlname, ref_dir, n, st, raw, tmp_path, fields, base=0):
+    """Every read of [base, base + n): one oracle process per usable host core on disjoint slices; FASTQ bytes and statistics."""
     import os
     import subprocess
     import sys
@@ -48,7 +48,7 @@ def compare_with_oracle_slices(wlname, ref_dir, n, st, raw, tmp_path, fields):
             continue
         path = str(tmp_path / f'slice{i}.npz')
         procs.append((first, count, path, subprocess.Popen([sys.executable, os.path.join(here, 'oracle_slice_worker.py'), wlname, ref_dir or '-',
-                                                            str(SEED), str(first), str(count), path], env=env,
+                                                            str(SEED), str(base + first), str(count), path], env=env,
                                                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
     for first, count, path, pr in procs:
         _, err = pr.communicate(timeout=1500)
@@ -57,7 +57,7 @@ def compare_with_oracle_slices(wlname, ref_dir, n, st, raw, tmp_path, fields):
         so = z['stats']
         lo = int(st['rec_off'][first])
         hi = int(st['rec_off'][first + count - 1] + st['rec_len'][first + count - 1])
-        assert z['data'].tobytes() == raw[lo:hi], f'{wlname}: reads {first}..{first + count - 1} differ from the oracle'
+        assert z['data'].tobytes() == raw[lo:hi], f'{wlname}: reads {base + first}..{base + first + count - 1} differ from the oracle'
         for f in fields:
             assert (so[f] == st[f][first:first + count]).all(), (wlname, f, first)
 
@@ -179,3 +179,51 @@ def test_configs3_and_4_every_read_of_a_full_batch_equals_the_oracle(wlname, tmp
         assert float(np.mean(ident)) > 0.995                      # qscore-distributed identities around Q30
     else:
         assert 0.93 < float(np.mean(ident)) < 0.97
+
+
+def test_configs3_a_device_batch_deep_in_the_index_space_equals_the_oracle(tmp_path):
+    """the driver's bench walks read indices up to ~9.8 M, the full-size parity above only [0, 65536).
+    One more device batch of configs[3] at the shipped geometry, read indices 5 000 000 ..., every read against the oracle."""
+    import bench
+    from badread_amd.engine import HipEngine, RS_EMPTY
+    ref_dir = bench.default_ref_dir()
+    wl = bench.build_workload(io.StringIO(), 'human', ref_dir)
+    base = 5_000_000
+    eng = bench.configure(HipEngine(0, scratch_bytes=int(bench.SCRATCH_GB_DEFAULT * (1 << 30))), wl)
+    out, st = eng.simulate_batch(SEED, base, SHIPPED_BATCH)
+    out, st = out.copy(), st.copy()
+    assert getattr(eng, 'retries', 0) == 0
+    eng.close()
+    assert (st['status'] & ~np.uint32(RS_EMPTY) == 0).all()
+    compare_with_oracle_slices('human', ref_dir, SHIPPED_BATCH, st, out.tobytes(), tmp_path, ALL_FIELDS, base=base)
+
+
+def _rare_routes():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rare_routes.json')
+    return json.load(open(path)) if os.path.isfile(path) else {'pins': []}
+
+
+@pytest.mark.parametrize('pin', _rare_routes()['pins'], ids=lambda p: f"{p['route']}@{p['read']}")
+def test_pinned_reads_on_the_rare_routes_of_the_final_stage(pin, tmp_path):
+    """reads of configs[3] found on the GPU (tools/find_rare_routes.py, scanned range in
+    tests/golden/rare_routes.json) whose final alignment leaves the 2 sqrt(ub) + 24 traceback window -- the second phase with
+    the full store -- or whose band is beyond 16 words per lane (the memory-resident wide path): a 64-read batch around
+    each, DEFAULT environment, against the oracle; and the route is asserted to be taken."""
+    import bench
+    from badread_amd.engine import HipEngine
+    ref_dir = bench.default_ref_dir()
+    wl = bench.build_workload(io.StringIO(), 'human', ref_dir)
+    first = (int(pin['read']) // 64) * 64
+    eng = bench.configure(HipEngine(0, scratch_bytes=8 << 30), wl)
+    out, st = eng.simulate_batch(SEED, first, 64)
+    out, st = out.copy(), st.copy()
+    cyc = eng.read_cycles(64)
+    r = int(pin['read']) - first
+    if pin['route'] == 'window_miss':
+        assert eng.window_misses() >= 1 and cyc[r, 2] != 0
+    else:
+        assert (int(cyc[r, 7]) & 0xFFFF) > 16
+    eng.close()
+    compare_with_oracle_slices('human', ref_dir, 64, st, out.tobytes(), tmp_path, ALL_FIELDS, base=first)

@@ -94,7 +94,7 @@ def test_sequence_fragments_matches_oracle():
                                  {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1', 'BRX_WIDE_STREAM': '0'},
                                  {'BRX_TAIL_READS': '16', 'BRX_LANE_THRESHOLD': '100', 'BRX_FIN_HEAD_READS': '64'},   # lane passes, then packed passes, then the tail
                                  {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0', 'BRX_STAGE_WORDS': '0'},    # pass waves never stage a read in LDS
-                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_STAGE_WORDS': '500', 'BRX_RUN_WPS_HEAD': '4', 'BRX_RUN_WPS_TAIL': '2'},   # short reads staged, long ones not; the other register budgets
+                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_STAGE_WORDS': '500'},   # short reads staged, long ones not
                                  {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0', 'BRX_WAVES_PER_CU': '1'}])     # 256 slab-owning waves per band class
 def test_alternative_kernel_routes_give_the_same_bytes(env, monkeypatch):
     """The optional routes (full / 8-row / narrow traceback window of the final alignment -- the 8-row window
