@@ -60,6 +60,8 @@ struct BrxDev {
     int tb_hmul;                     /* window of the final traceback store: H = tb_hmul sqrt(ub) + 24 rows (brx_make_geom); 0 = full */
     PSeg *plan_ovf;                  /* BRX_OVF_LISTS x BRX_OVF_SEGS: continuation of base-segment lists longer than BRX_MAX_BASE_SEGS */
     uint32_t *plan_ovf_ctr;
+    uint32_t early_begin;            /* reads at positions >= early_begin of the longest-first order form the EARLY set of the final stage ... */
+    uint32_t *early_ctr;             /* ... and count themselves here when their mutate loop is done (RS.tb_off holds the position until then) */
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -359,23 +361,31 @@ __global__ void __launch_bounds__(64) k_scan_plan(uint32_t n_reads, RS *rs, uint
     if (lane == 0) { totals[0] = seg_run; totals[1] = piece_run; totals[2] = f_run; }
 }
 
-/* longest-first processing order: counting sort on n/512 (256 buckets), one wave */
-__global__ void __launch_bounds__(64) k_order(uint32_t n_reads, const RS *rs, uint32_t *order) {
-    __shared__ uint32_t hist[256];
+/* Processing order, most work first: counting sort on the EXPECTED NUMBER OF CHANGES n (1 - target identity) in steps of 32
+ * (1024 buckets), one wave.  A read's mutate loop runs one alignment cycle per 25 changes, and its final alignment's band is as
+ * wide as its changes: both the passes a read needs and the class of its final alignment follow the changes, not the length
+ * (rounds 1-3 sorted by length: a 22 kb read at 85 % identity -- 130 cycles -- sat among reads that are done after 35 and kept
+ * its set of the final stage waiting for the in-place tail). */
+#define BRX_ORDER_BUCKETS 1024
+__device__ __forceinline__ uint32_t brx_order_key(const RS &s) {
+    const double e = (double)s.n * (1.0 - s.target);
+    uint32_t key = e > 0.0 ? (uint32_t)(e * (1.0 / 32.0)) : 0u;
+    if (s.n == 0) key = 0;
+    return key > BRX_ORDER_BUCKETS - 1u ? BRX_ORDER_BUCKETS - 1u : key;
+}
+__global__ void __launch_bounds__(64) k_order(uint32_t n_reads, RS *rs, uint32_t *order) {
+    __shared__ uint32_t hist[BRX_ORDER_BUCKETS];
     const int lane = lane_id();
-    for (int b = lane; b < 256; b += 64) hist[b] = 0;
+    for (int b = lane; b < BRX_ORDER_BUCKETS; b += 64) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t r = lane; r < n_reads; r += 64) atomicAdd(&hist[BRX_ORDER_BUCKETS - 1u - brx_order_key(rs[r])], 1u);
+    __syncthreads();
+    if (lane == 0) { uint32_t run = 0; for (int b = 0; b < BRX_ORDER_BUCKETS; ++b) { uint32_t c = hist[b]; hist[b] = run; run += c; } }
     __syncthreads();
     for (uint32_t r = lane; r < n_reads; r += 64) {
-        uint32_t key = rs[r].n >> 9; if (key > 255) key = 255;
-        atomicAdd(&hist[255 - key], 1u);
-    }
-    __syncthreads();
-    if (lane == 0) { uint32_t run = 0; for (int b = 0; b < 256; ++b) { uint32_t c = hist[b]; hist[b] = run; run += c; } }
-    __syncthreads();
-    for (uint32_t r = lane; r < n_reads; r += 64) {
-        uint32_t key = rs[r].n >> 9; if (key > 255) key = 255;
-        uint32_t slot = atomicAdd(&hist[255 - key], 1u);
+        uint32_t slot = atomicAdd(&hist[BRX_ORDER_BUCKETS - 1u - brx_order_key(rs[r])], 1u);
         order[slot] = r;
+        rs[r].tb_off = slot;                       /* the read's position in the order, until the final stage assigns tb_off */
     }
 }
 
@@ -576,7 +586,8 @@ __device__ __forceinline__ void dev_random_change_row(uint32_t row, int k, uint3
     for (int j = 0; j < 16; ++j) if (j < k) rep[j] = ((uint32_t)j == c.pos) ? word : 0u;
 }
 
-struct __attribute__((packed, aligned(4))) BrxU4 { uint32_t x, y, z, w; };      /* four words behind a 4-byte aligned address */
+struct __attribute__((packed, aligned(4))) BrxU4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) BrxB16x3 { uint32_t x, y, z; };        /* twelve bytes behind any address */      /* four words behind a 4-byte aligned address */
 
 /* A PROPOSAL of the mutate rounds is three words per lane (round 4; it was an array of sixteen replacement words, filled
  * by every proposing lane and read back with sixteen broadcasts per survivor):
@@ -1000,8 +1011,8 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
                                                     uint8_t *tb_base, uint64_t *clk) {
     __shared__ uint32_t qhist[256];
     __shared__ uint32_t hot_thr[BRX_QS_HOT_MAX], hot_score[BRX_QS_HOT_MAX];
+    __shared__ uint8_t hot_idx[256];
     __shared__ uint32_t pend_sp[BRX_QS_PEND], pend_h[BRX_QS_PEND];          /* windows waiting for the slow path (a ring) */
-    __shared__ uint64_t pend_ops[BRX_QS_PEND], pend_gap[BRX_QS_PEND];
     const int lane = lane_id();
     const brx_qscore_model &qm = d.qm;
     /* The full-width window of matches ('=' x k: 89 % of all lookups with nanopore2023) keeps its row in LDS: no hash
@@ -1015,6 +1026,15 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
                 hot_n = e1 - e0;
                 for (uint32_t x = lane; x < hot_n; x += 64) { hot_thr[x] = qm.d_thr[e0 + x]; hot_score[x] = qm.d_score[e0 + x]; }
             }
+        }
+        __syncthreads();
+        /* hot_idx[b] = first entry whose threshold exceeds b << 24: a draw starts its search at the entry of its top byte and
+           walks one or two entries, instead of seven dependent probes of a binary search over the whole row */
+        for (uint32_t b = lane; b < 256u && hot_n; b += 64) {
+            const uint32_t u = b << 24;
+            uint32_t e = 0, hi_ = hot_n - 1;
+            while (e < hi_) { const uint32_t mid = (e + hi_) >> 1; if (u < hot_thr[mid]) hi_ = mid; else e = mid + 1; }
+            hot_idx[b] = (uint8_t)e;
         }
         __syncthreads();
     }
@@ -1059,7 +1079,21 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
            EVERY group of 64 bases for the seven lanes that needed them.  Those lanes now only queue their window (centre, half
            width, ops and gaps of the widest window: 24 bytes in LDS) and the slow path runs when 64 are waiting: full lanes. */
         uint32_t q_head = 0, q_tail = 0;                                   /* ring of BRX_QS_PEND entries, wave-uniform */
-        auto slow_lane = [&](uint32_t sp, uint32_t h, uint64_t opsbits, uint64_t gapbits) {
+        auto slow_lane = [&](uint32_t sp, uint32_t h) {
+            /* ops and D-runs of the widest window (2 h + 1 read bases around sp): 2 bits per op, op i at bits 2 i; 4 bits per gap
+               (saturated), the gap after op i at bits 4 i */
+            uint64_t opsbits = 0, gapbits = 0;
+            {
+                const uint32_t c0 = col_of[sp - h], c1 = col_of[sp + h];
+                uint32_t idx = 0, rn = 0;
+                for (uint32_t cc = c0; cc <= c1; ++cc) {
+                    const uint32_t op = ops[cc];
+                    if (op == BRX_OP_D) { rn += 1; continue; }
+                    if (idx > 0) { const uint32_t code = rn >= maxrun ? maxrun : rn; gapbits |= (uint64_t)code << (4 * (idx - 1)); }
+                    opsbits |= (uint64_t)op << (2 * idx);
+                    rn = 0; idx += 1;
+                }
+            }
             uint32_t score = 0; bool found = false;
             uint32_t hh = h;
             for (;;) {
@@ -1097,38 +1131,47 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
             __syncthreads();
             if ((uint32_t)lane < count) {
                 const uint32_t e = (q_head + (uint32_t)lane) & (BRX_QS_PEND - 1u);
-                slow_lane(pend_sp[e], pend_h[e], pend_ops[e], pend_gap[e]);
+                slow_lane(pend_sp[e], pend_h[e]);
             }
             q_head += count;
             __syncthreads();                                               /* the slots may be written again */
         };
+        /* The draw of base sp is word sp & 3 of block sp >> 2 (qscore_model.py:54-71 draws once per base): 256 bases share 64
+           blocks, so the wave computes ONE block per lane per 256 bases and every 64-base step fetches its word from the lane
+           that holds it (four shuffles), instead of four lanes computing the same block in every step. */
+        uint32_t blk_w[4] = {0u, 0u, 0u, 0u};
         if (ok) for (uint32_t sp0 = 0; sp0 < m; sp0 += 64) {
+            if ((sp0 & 255u) == 0u) brx_draw4(d.seed, read, BRX_ST_QS, (uint64_t)(sp0 >> 2) + (uint64_t)lane, blk_w);
+            const int src = (int)(((sp0 & 255u) >> 2) + ((uint32_t)lane >> 2));        /* lane that drew the block of base sp0 + lane */
+            const uint32_t u0 = wave_bcast_u32(blk_w[0], src), u1 = wave_bcast_u32(blk_w[1], src);
+            const uint32_t u2 = wave_bcast_u32(blk_w[2], src), u3 = wave_bcast_u32(blk_w[3], src);
+            const uint32_t u_step = (lane & 2) ? ((lane & 1) ? u3 : u2) : ((lane & 1) ? u1 : u0);
             const uint32_t sp = sp0 + (uint32_t)lane;
             const bool valid = sp < m;
             uint32_t h = margin;
-            uint64_t opsbits = 0;     /* 2 bits per op, op i of the widest window at bits 2i  */
-            uint64_t gapbits = 0;     /* 4 bits per gap (saturated), gap after op i at bits 4i */
+            bool hot = false;
             if (valid) {
                 if (sp < h) h = sp;
                 if (m - 1 - sp < h) h = m - 1 - sp;
-                /* ops and D-runs of the widest window, centre at index `margin` of the local arrays */
-                uint32_t c0 = col_of[sp - h], c1 = col_of[sp + h];
-                uint32_t idx = 0, rn = 0;
-                for (uint32_t cc = c0; cc <= c1; ++cc) {
-                    uint32_t op = ops[cc];
-                    if (op == BRX_OP_D) { rn += 1; continue; }
-                    if (idx > 0) { uint32_t code = rn >= maxrun ? maxrun : rn; gapbits |= (uint64_t)code << (4 * (idx - 1)); }
-                    opsbits |= (uint64_t)op << (2 * idx);
-                    rn = 0; idx += 1;
+                /* the all-match window of full width (the LDS row): its 2 margin + 1 bases sit in consecutive columns -- no 'D'
+                   between them -- and those columns' ops are all '=' (code 0): two column numbers and twelve op bytes, not a
+                   walk over the window.  Every other window is queued with its centre and half width; the lanes of a drain
+                   walk theirs together. */
+                if (hot_n && h == margin) {
+                    const uint32_t c0 = col_of[sp - h], c1 = col_of[sp + h];
+                    if (c1 - c0 == 2u * margin) {
+                        const BrxB16x3 o3 = *reinterpret_cast<const BrxB16x3 *>(ops + c0);       /* ops is followed by the slack of its buffer */
+                        const uint32_t nb = 2u * margin + 1u;                                     /* <= 12 for k <= 11: asserted at load */
+                        const uint32_t last = nb > 8u ? (nb >= 12u ? 0xFFFFFFFFu : (1u << (8u * (nb - 8u))) - 1u) : 0u;
+                        const uint64_t first8 = nb >= 8u ? ~0ull : (1ull << (8u * nb)) - 1ull;
+                        hot = ((((uint64_t)o3.y << 32) | (uint64_t)o3.x) & first8) == 0ull && (o3.z & last) == 0u;
+                    }
                 }
             }
-            const bool hot = valid && hot_n && h == margin && opsbits == 0 && gapbits == 0;     /* all matches, full width: the LDS row */
             if (hot) {
-                uint32_t w4[4];
-                brx_draw4(d.seed, read, BRX_ST_QS, (uint64_t)(sp >> 2), w4);
-                const uint32_t u = w4[sp & 3];
-                uint32_t e = 0, hi_ = hot_n - 1;
-                while (e < hi_) { const uint32_t mid = (e + hi_) >> 1; if (u < hot_thr[mid]) hi_ = mid; else e = mid + 1; }
+                const uint32_t u = u_step;
+                uint32_t e = hot_idx[u >> 24];                 /* first entry whose cumulative threshold exceeds the draw, else the last one */
+                while (e < hot_n - 1u && u >= hot_thr[e]) e += 1u;
                 const uint32_t score = hot_score[e];
                 qual[sp] = (uint8_t)(score + 33);
                 atomicAdd(&qhist[score & 255u], 1u);
@@ -1138,7 +1181,7 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
             if (sm) {
                 if (slow) {
                     const uint32_t e = (q_tail + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))) & (BRX_QS_PEND - 1u);
-                    pend_sp[e] = sp; pend_h[e] = h; pend_ops[e] = opsbits; pend_gap[e] = gapbits;
+                    pend_sp[e] = sp; pend_h[e] = h;
                 }
                 q_tail += (uint32_t)__popcll(sm);
                 if (q_tail - q_head >= 64u) drain(64u);

@@ -242,7 +242,10 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
         if (qi >= n_in) break;
         const uint32_t r = active_in[qi];
         const RS s = rs[r];
-        if (s.n == 0) continue;
+        if (s.n == 0) {                                  /* no fragment: nothing to mutate (met once, in the first pass) */
+            if (lane == 0 && (uint32_t)s.tb_off >= d.early_begin) atomicAdd(d.early_ctr, 1u);
+            continue;
+        }
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
         if constexpr (PROFILE) { ph0 = ph1 = ph2 = ph3 = ph4 = 0; pclk[0] = pclk[1] = 0; ph_last = t_begin; ph_cur = 4; }
         MS ms = msv[r];
@@ -491,6 +494,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
             o->loops = (uint32_t)loops; o->changes = change; o->naligns = nalign;
             o->units = 0;                                          /* sized by k_fin_join */
             msv[r].phase = 2u;
+            if ((uint32_t)s.tb_off >= d.early_begin) atomicAdd(d.early_ctr, 1u);      /* the early set of the final stage starts when all its reads are here */
             ck[0] += __builtin_amdgcn_s_memtime() - t_begin; ck[1] = INLINE ? nalign : ms.passes;
         }
     }
