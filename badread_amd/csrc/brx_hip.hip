@@ -54,8 +54,6 @@ struct brx_ctx {
     hipEvent_t ev_fork2[2], ev_join2[2], ev_head_mut;
     hipEvent_t ev_fork3, ev_join3[2];   /* the bulk set's band classes on the head chain's streams */
     int fin_spread;                      /* BRX_FIN_SPREAD (default 1) */
-    double early_frac;                   /* BRX_EARLY_FRAC: the shortest reads of the bulk set (this fraction of them) form the early set of the final stage (0 = off) */
-    hipEvent_t ev_fork2x, ev_join2x;     /* wide-class fork / join of the early set */
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
                                     three wide classes: a stream per class measured 30 % slower, r01d) */
     hipEvent_t ev_fork, ev_join;
@@ -120,8 +118,6 @@ static void release(brx_ctx *c) {
     for (int i = 0; i < 2; ++i) { if (c->ev_fork2[i]) (void)hipEventDestroy(c->ev_fork2[i]); if (c->ev_join2[i]) (void)hipEventDestroy(c->ev_join2[i]); }
     if (c->ev_head_mut) (void)hipEventDestroy(c->ev_head_mut);
     if (c->ev_fork3) (void)hipEventDestroy(c->ev_fork3);
-    if (c->ev_fork2x) (void)hipEventDestroy(c->ev_fork2x);
-    if (c->ev_join2x) (void)hipEventDestroy(c->ev_join2x);
     for (int i = 0; i < 2; ++i) if (c->ev_join3[i]) (void)hipEventDestroy(c->ev_join3[i]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
@@ -173,9 +169,6 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         (e = hipEventCreateWithFlags(&c->ev_join3[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_join3[1], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *v = getenv("BRX_FIN_SPREAD"); c->fin_spread = v ? atoi(v) : 1; }
-    { const char *v = getenv("BRX_EARLY_FRAC"); c->early_frac = v ? atof(v) : 0.8; if (c->early_frac < 0.0 || c->early_frac > 0.98) c->early_frac = 0.0; }
-    if ((e = hipEventCreateWithFlags(&c->ev_fork2x, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_join2x, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 512u; }
     { const char *v = getenv("BRX_STAGE_WORDS"); c->stage_words = v ? std::min<uint32_t>((uint32_t)atoi(v), (uint32_t)BRX_STAGE_WORDS) : (uint32_t)BRX_STAGE_WORDS; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
@@ -415,7 +408,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *mctr = (uint32_t *)A.take(8 * MC_WORDS * sizeof(uint32_t));   /* pass counters 0/1, 2 first bulk input, 3 bulk legacy, 4 head input, 5 head legacy, 6 head pass */
     uint32_t *active_a = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *active_b = (uint32_t *)A.take((size_t)n_reads * 4);
-    uint32_t *req_easy = (uint32_t *)A.take((size_t)n_reads * 4);
+    uint32_t *req_easy = (uint32_t *)A.take((size_t)n_reads * 4 * BRX_LANE_CLASSES);    /* lane passes: one list per band-width class */
+    uint32_t *lane_cls = (uint32_t *)A.take(2 * MC_WORDS * sizeof(uint32_t));             /* their counts, a block per pass parity */
     uint32_t *req_hard = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy_head = (uint32_t *)A.take((size_t)n_reads * 4);
@@ -479,30 +473,19 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         size_t tb_at, tb_cap, col_bytes;   /* the set's region of the arena: col_of[] of its reads, then the slabs of its align kernels */
         uint64_t bases_by_class[5];    /* G = 1, 2, 4, 8+, all */
     };
-    /* THREE sets (round 4).  The order is longest first and a read's mutate loop takes a pass per ~600 bases, so the short reads
-       of the bulk set are done long before its last pass: the shortest BRX_EARLY_FRAC of the bulk reads (0.8: reads up to ~22 kb,
-       half of the bases, done after ~40 of ~64 passes) form the EARLY set, whose final stage runs on the head chain's wide stream
-       beside the remaining passes and the tail instead of behind them.  Every early read counts itself (BrxDev.early_ctr) when its
-       loop is done; the set starts when the count is complete and that stream is idle.  (Round 3: ~440 ms of final stage behind
-       ~640 ms of mutate stage per batch.) */
-    uint32_t n_early = 0;
-    if (n_mh && n_mb >= 8 && c->early_frac > 0.0 && !all_head) n_early = (uint32_t)((double)n_mb * c->early_frac);
-    const uint32_t early_b = n_reads - n_early;
-    FinalSet sets[3];
+    /* (Round 4 also ran THREE sets -- the reads with the fewest expected changes as an EARLY set whose final stage started
+       during the passes on the head chain's idle stream, every early read counting itself when its loop was done.  It overlapped
+       as designed -- final stage behind the mutate stage 250 -> 205 ms -- and the passes it ran beside slowed down by as much:
+       5.16-5.18 against 5.22-5.26 Gbases/s without it, six batches in flight; removed.  profiles/r04i, r04j.) */
+    FinalSet sets[2];
     sets[0] = FinalSet{0, n_head, s_head, (c->wide_stream && n_bulk) ? c->side2 : s_head, 0, false, false, 0, 0, 0, {0, 0, 0, 0, 0}};
-    sets[1] = FinalSet{n_head, early_b, st, st, 1, false, false, 0, 0, 0, {0, 0, 0, 0, 0}};
-    sets[2] = FinalSet{early_b, n_reads, c->side2, c->side2, 2, false, false, 0, 0, 0, {0, 0, 0, 0, 0}};
-    dev.early_begin = n_early ? early_b : 0xFFFFFFFFu;
-    dev.early_ctr = counters + 13;
+    sets[1] = FinalSet{n_head, n_reads, st, st, 1, false, false, 0, 0, 0, {0, 0, 0, 0, 0}};
     uint64_t *set_tboff = tboff_sorted;       /* staging array of the col_of[] offsets, indexed by order position */
     uint64_t *fin_slabs = units_sorted;        /* slab offset tables of the sets' align kernels (n_reads + 16 words) */
     std::vector<uint64_t> h_tboff(n_reads);
     /* counters: [0],[3] join queues of head / bulk; [1] flags; [2],[4] window misses of head / bulk;
        [16 + 16 x (set x 2 + phase)] final-stage queue heads (four 64-bit class counters, two qscore counters) */
-    auto set_counter = [&](const FinalSet &S, int which) -> uint32_t * {      /* [6], [7]: join queue and window misses of the early set; [13] its completion count */
-        static const int slot[3][2] = {{0, 2}, {3, 4}, {6, 7}};
-        return counters + slot[S.id][which];
-    };
+    auto set_counter = [&](const FinalSet &S, int which) -> uint32_t * { return counters + (which == 0 ? (S.id ? 3 : 0) : (S.id ? 4 : 2)); };
     bool legacy_handled = false;       /* the whole-read fallback already ran for every read (no separate mutate head chain) */
     uint64_t tail_bases = 0;           /* kernel statistics: bases of the bulk reads that finished in the in-place tail */
 
@@ -626,15 +609,15 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
            (k_fin_qscore) as soon as its class is aligned. */
         const bool fork = S.wide != S.st;
         if (fork) {
-            HIPCHK(c, hipEventRecord(S.id < 2 ? c->ev_fork2[S.id] : c->ev_fork2x, S.st));
-            HIPCHK(c, hipStreamWaitEvent(S.wide, S.id < 2 ? c->ev_fork2[S.id] : c->ev_fork2x, 0));
+            HIPCHK(c, hipEventRecord(c->ev_fork2[S.id], S.st));
+            HIPCHK(c, hipStreamWaitEvent(S.wide, c->ev_fork2[S.id], 0));
         }
         if (cnt[3]) {
             KTIMED(BRX_KERN_FIN_ALIGN16, S.wide);
             hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(grid[3]), dim3(64), 0, S.wide, dev, rs, d_lists + list_at[3], cnt[3],
                                reinterpret_cast<unsigned long long *>(cq + 6), d_slabs + slab_at[3], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
         }
-        if (fork) { HIPCHK(c, hipEventRecord(S.id < 2 ? c->ev_join2[S.id] : c->ev_join2x, S.wide)); S.wide_forked = true; }
+        if (fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
         /* The 4-, 2- and 1-word classes are independent (own lists, own slabs), each scored (k_fin_qscore on its class-pure list) as
            soon as it is aligned.  The bulk set spreads them over the head chain's two streams, which are idle by the time the
            bulk passes end (round 3 ran the three classes and their scoring one after the other on the set's stream: ~490 ms of
@@ -675,7 +658,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join3[0], 0));
             HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join3[1], 0));
         }
-        if (fork) HIPCHK(c, hipStreamWaitEvent(S.st, S.id < 2 ? c->ev_join2[S.id] : c->ev_join2x, 0));
+        if (fork) HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join2[S.id], 0));
         if (cnt[3]) {
             KTIMED(BRX_KERN_FIN_QSCORE, S.st);
             hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
@@ -691,9 +674,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         S.launched = true;
         if (ns == 0) return BRX_OK;
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
-        uint32_t *legacy = mctr + (S.id ? 3 : 5) * MC_WORDS;                       /* [0] count, [1] queue (bulk and early share the bulk chain's list) */
-        const int tot_dev = S.id == 0 ? 8 : S.id == 1 ? 3 : 10;                    /* two words of `totals` per set (k_scan_mut) ... */
-        const int tot_host = S.id == 0 ? 6 : S.id == 1 ? 3 : 1;                    /* ... and of the pinned h_totals */
+        uint32_t *legacy = mctr + (S.id ? 3 : 5) * MC_WORDS;                       /* [0] count, [1] queue */
+        const int tot_dev = S.id ? 3 : 8, tot_host = S.id ? 3 : 6;                 /* two words of `totals` (k_scan_mut) and of the pinned h_totals per set */
         HIPCHK(c, hipMemcpyAsync(h_ctr, legacy, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, S.st));
         HIPCHK(c, hipMemcpyAsync(h_ctr + 2, counters + 1, 4, hipMemcpyDeviceToHost, S.st));
         { int rcw = wait_stream(c, S.st, S.id ? "mutate stage (bulk)" : "mutate stage (head)"); if (rcw) return rcw; }
@@ -707,7 +689,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         }
         /* reads whose window did not fit a slot: the whole-read kernel with the inline wave aligner */
         DBG("set %d: %u reads, %u to the whole-read kernel", S.id, ns, h_ctr[0]);
-        if (h_ctr[0] > 0 && !legacy_handled && S.id != 2)        /* the early set's stragglers are on the bulk chain's list: start_final(bulk) ran first */
+        if (h_ctr[0] > 0 && !legacy_handled)
             hipLaunchKernelGGL(k_mutate, dim3(std::min(S.id ? side_waves : std::min(std::max(n_mh, 1u), side_waves), h_ctr[0])), dim3(64), 0, S.st, dev, rs,
                                S.id ? req_legacy : req_legacy_head, legacy, legacy + 1, Fbuf, repl, S.id ? win : win_head,
                                (uint64_t)c->win_bytes, counters + 1, clk);
@@ -759,6 +741,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     HIPCHK(c, hipMemcpyAsync(h_order.data(), order, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemsetAsync(msv, 0, (size_t)n_reads * sizeof(MS), st));
     HIPCHK(c, hipMemsetAsync(mctr, 0, 8 * MC_WORDS * sizeof(uint32_t), st));
+    HIPCHK(c, hipMemsetAsync(lane_cls, 0, 2 * MC_WORDS * sizeof(uint32_t), st));
     {
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         memset(h_ctr, 0, 2 * MC_WORDS * sizeof(uint32_t));
@@ -779,7 +762,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
 #define BRX_LAUNCH_RUN(PROF)                                                                                                        \
         hipLaunchKernelGGL((k_mutate_seg<true, PROF, BRX_SEG_WPS>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in,   \
                            act_out, ctr, req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,        \
-                           winscr, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words)
+                           winscr, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words, lane_cls)
         if (c->profile) BRX_LAUNCH_RUN(true); else BRX_LAUNCH_RUN(false);
 #undef BRX_LAUNCH_RUN
     };
@@ -805,21 +788,13 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         const uint32_t *act_in = order + n_mh;
         uint32_t n_up = n_mb, pass = 0;
         const uint32_t tail_reads = tail_eff;   /* this few reads left: run them to completion in place (no host round trips) */
-        uint32_t *h_early = h_ctr + 12;                                              /* pinned: the early set's completion count */
-        h_early[0] = 0;
         auto read_counts = [&](uint32_t *ctr) -> int {
             HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            if (n_early) HIPCHK(c, hipMemcpyAsync(h_early, counters + 13, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             return wait_stream(c, st, "mutate pass");
         };
         auto poll_head = [&]() -> int {      /* the head set's final stage starts as soon as its reads are mutated */
-            if (n_mh && !sets[0].launched && hipEventQuery(c->ev_head_mut) == hipSuccess) { int r_ = start_final(sets[0]); if (r_) return r_; }
-            /* the early set: every read of it is done (none of them waits for the whole-read kernel: those do not count themselves),
-               the head set is under way and its wide stream has nothing queued -- start_final waits on that stream from this thread */
-            if (n_early && !sets[2].launched && sets[0].launched && h_early[0] == n_early && hipStreamQuery(c->side2) == hipSuccess) {
-                int r_ = start_final(sets[2]); if (r_) return r_;
-            }
-            return BRX_OK;
+            if (!n_mh || sets[0].launched || hipEventQuery(c->ev_head_mut) != hipSuccess) return BRX_OK;
+            return start_final(sets[0]);
         };
         for (; n_up > 0 && pass < (1u << 20); ++pass) {
             uint32_t *ctr = mctr + (pass & 1u) * MC_WORDS;
@@ -841,21 +816,24 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 ++pass;
                 break;
             }
+            /* which window kernel follows is the HOST's choice (its count of active reads may be a few passes old): the segment
+               kernel lists the windows for that kernel -- by band class for the lane kernel, one list for the packed one */
+            const uint32_t lane_pass_thr = n_up > lane_threshold ? 0u : 0xFFFFFFFFu;
             {
                 KTIMED(BRX_KERN_MUTATE_SEG, st);
                 if (c->profile)
                     hipLaunchKernelGGL((k_mutate_seg<false, true, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                                       ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                                       win, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words);
+                                       ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_pass_thr,
+                                       win, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS);
                 else
                     hipLaunchKernelGGL((k_mutate_seg<false, false, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                                       ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,
-                                       win, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words);
+                                       ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_pass_thr,
+                                       win, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS);
             }
             if (n_up > lane_threshold) {
                 KTIMED(BRX_KERN_WIN_LANE, st);
-                hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64)), dim3(64), 0, st, msv, req_easy,
-                                   ctr + MC_EASY, winbuf, lane_tb);
+                hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64 + BRX_LANE_CLASSES)), dim3(64), 0, st, msv, req_easy,
+                                   lane_cls + (pass & 1u) * MC_WORDS, n_reads, winbuf, lane_tb);
             } else {                                   /* few reads left: eight windows per wave (same list, same class) */
                 KTIMED(BRX_KERN_WIN_LANE, st);
                 hipLaunchKernelGGL(k_win_pack, dim3(std::min(pack_waves, (n_up + BRX_PACK_NG - 1) / BRX_PACK_NG)), dim3(64), 0, st, msv, req_easy,
@@ -864,7 +842,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             {   /* the windows the lane / pack kernel does not take: one per wave; it also zeroes the counter block of the NEXT pass */
                 KTIMED(BRX_KERN_WIN_WAVE, st);
                 hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
-                                   ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1, mctr + ((pass + 1) & 1u) * MC_WORDS);
+                                   ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1, mctr + ((pass + 1) & 1u) * MC_WORDS,
+                                   lane_cls + ((pass + 1) & 1u) * MC_WORDS);
             }
             /* the active count only shrinks: look at it every 4th pass while it is large, every pass near the end */
             if (n_up <= 4 * std::min<uint32_t>(tail_reads, 48u) || n_up <= tail_reads + 64 || (pass & 3u) == 3u) {
@@ -902,16 +881,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_FINAL], st));
     /* ---- final stages: whichever set is not started yet (head first: it is the longer chain), then wait for both ---- */
     if (!sets[0].launched) { rc2 = start_final(sets[0]); if (rc2) return rc2; }
-    rc2 = start_final(sets[1]); if (rc2) return rc2;                 /* also runs the whole-read kernel for the bulk chain's stragglers, early reads included */
-    if (!sets[2].launched) {
-        if (n_early) {                                                 /* the early set did not get away during the passes: behind the bulk chain's kernels now */
-            HIPCHK(c, hipEventRecord(c->ev_fork2x, st));
-            HIPCHK(c, hipStreamWaitEvent(c->side2, c->ev_fork2x, 0));
-        }
-        rc2 = start_final(sets[2]); if (rc2) return rc2;
-    }
+    rc2 = start_final(sets[1]); if (rc2) return rc2;
     rc2 = finish_final(sets[0]); if (rc2) return rc2;
-    rc2 = finish_final(sets[2]); if (rc2) return rc2;
     rc2 = finish_final(sets[1]); if (rc2) return rc2;
     if (n_head && n_bulk) {                           /* join: the records need both sets */
         HIPCHK(c, hipEventRecord(c->ev_join, s_head));
@@ -949,7 +920,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     /* per-kernel launch statistics (brx_set_kernel_timing): every event pair recorded by KTIMED above */
     if (c->ktiming) {
         if (n_head && n_bulk) HIPCHK(c, hipStreamSynchronize(c->side));
-        if (sets[0].wide_forked || n_early) HIPCHK(c, hipStreamSynchronize(c->side2));
+        if (sets[0].wide_forked) HIPCHK(c, hipStreamSynchronize(c->side2));
         for (int i = 0; i < c->kev_n; ++i) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, c->kev_b[i], c->kev_e[i]) != hipSuccess) continue;

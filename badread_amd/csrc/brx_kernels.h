@@ -60,8 +60,6 @@ struct BrxDev {
     int tb_hmul;                     /* window of the final traceback store: H = tb_hmul sqrt(ub) + 24 rows (brx_make_geom); 0 = full */
     PSeg *plan_ovf;                  /* BRX_OVF_LISTS x BRX_OVF_SEGS: continuation of base-segment lists longer than BRX_MAX_BASE_SEGS */
     uint32_t *plan_ovf_ctr;
-    uint32_t early_begin;            /* reads at positions >= early_begin of the longest-first order form the EARLY set of the final stage ... */
-    uint32_t *early_ctr;             /* ... and count themselves here when their mutate loop is done (RS.tb_off holds the position until then) */
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -364,8 +362,7 @@ __global__ void __launch_bounds__(64) k_scan_plan(uint32_t n_reads, RS *rs, uint
 /* Processing order, most work first: counting sort on the EXPECTED NUMBER OF CHANGES n (1 - target identity) in steps of 32
  * (1024 buckets), one wave.  A read's mutate loop runs one alignment cycle per 25 changes, and its final alignment's band is as
  * wide as its changes: both the passes a read needs and the class of its final alignment follow the changes, not the length
- * (rounds 1-3 sorted by length: a 22 kb read at 85 % identity -- 130 cycles -- sat among reads that are done after 35 and kept
- * its set of the final stage waiting for the in-place tail). */
+ * (rounds 1-3 sorted by length: a 22 kb read at 85 % identity -- 130 cycles -- sat among reads that are done after 35). */
 #define BRX_ORDER_BUCKETS 1024
 __device__ __forceinline__ uint32_t brx_order_key(const RS &s) {
     const double e = (double)s.n * (1.0 - s.target);
@@ -373,7 +370,7 @@ __device__ __forceinline__ uint32_t brx_order_key(const RS &s) {
     if (s.n == 0) key = 0;
     return key > BRX_ORDER_BUCKETS - 1u ? BRX_ORDER_BUCKETS - 1u : key;
 }
-__global__ void __launch_bounds__(64) k_order(uint32_t n_reads, RS *rs, uint32_t *order) {
+__global__ void __launch_bounds__(64) k_order(uint32_t n_reads, const RS *rs, uint32_t *order) {
     __shared__ uint32_t hist[BRX_ORDER_BUCKETS];
     const int lane = lane_id();
     for (int b = lane; b < BRX_ORDER_BUCKETS; b += 64) hist[b] = 0;
@@ -385,7 +382,6 @@ __global__ void __launch_bounds__(64) k_order(uint32_t n_reads, RS *rs, uint32_t
     for (uint32_t r = lane; r < n_reads; r += 64) {
         uint32_t slot = atomicAdd(&hist[BRX_ORDER_BUCKETS - 1u - brx_order_key(rs[r])], 1u);
         order[slot] = r;
-        rs[r].tb_off = slot;                       /* the read's position in the order, until the final stage assigns tb_off */
     }
 }
 

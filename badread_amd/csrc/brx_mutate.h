@@ -60,6 +60,14 @@ struct MS {                       /* loop state of a parked read */
 };
 
 enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WORDS = 8 };
+/* Windows bound for the lane kernel are listed by band width: a wave of k_win_lane computes as many band slots per column
+ * as its WIDEST window needs, and the widest of 64 windows taken as they come is near the top of the range (7-8 slots) while
+ * most need 3-5.  Class c = band blocks - 3 (<= 3 blocks: class 0; 8 blocks: class 5). */
+#define BRX_LANE_CLASSES 6
+__device__ __forceinline__ uint32_t brx_lane_class(int band_blocks) {
+    const int c = band_blocks - 3;
+    return (uint32_t)(c < 0 ? 0 : c > BRX_LANE_CLASSES - 1 ? BRX_LANE_CLASSES - 1 : c);
+}
 
 /* Park a window in ONE pass: qb[0, b-a) = F[a:b] (+16 bytes 0xFF), tbuf[0, tl) = join(new_fragment_bases[a:b]) clipped
  * to `tmax` bytes (+16 bytes 0xFE when it fits), *cost = edit bound of the pair, *odd = a symbol outside ACGT on either
@@ -229,7 +237,8 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                                                     uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
                                                     const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk,
                                                     uint32_t lane_threshold, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags,
-                                                    uint64_t *phase, const uint32_t *F2buf, uint32_t *Cbuf, uint32_t stage_words) {
+                                                    uint64_t *phase, const uint32_t *F2buf, uint32_t *Cbuf, uint32_t stage_words,
+                                                    uint32_t *lane_cls) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
@@ -242,10 +251,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
         if (qi >= n_in) break;
         const uint32_t r = active_in[qi];
         const RS s = rs[r];
-        if (s.n == 0) {                                  /* no fragment: nothing to mutate (met once, in the first pass) */
-            if (lane == 0 && (uint32_t)s.tb_off >= d.early_begin) atomicAdd(d.early_ctr, 1u);
-            continue;
-        }
+        if (s.n == 0) continue;
         const uint64_t t_begin = __builtin_amdgcn_s_memtime();
         if constexpr (PROFILE) { ph0 = ph1 = ph2 = ph3 = ph4 = 0; pclk[0] = pclk[1] = 0; ph_last = t_begin; ph_cur = 4; }
         MS ms = msv[r];
@@ -404,6 +410,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                                                                reinterpret_cast<uint32_t *>(qb + BRX_WIN_PLANES));
                         const uint32_t ql = b - a;
                         uint32_t klass = MC_LEGACY;
+                        int band_blocks_of = 0;
                         if (tl <= BRX_WIN_TMAX) {
                             if constexpr (INLINE) {                    /* the in-place aligner below reads the bytes back */
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -411,6 +418,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                             }
                             const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
                             const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
+                            band_blocks_of = band_blocks;
                             /* "easy" windows go to a throughput kernel: one window per LANE while the pass is large, eight
                                windows per wave (k_win_pack) once fewer than lane_threshold reads are active */
                             const bool easy = !INLINE && !odd && g.G == 1 && tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 &&
@@ -427,8 +435,16 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                             if (INLINE && klass != MC_LEGACY) ms = o;          /* stays in registers: aligned below */
                             else if (lane == 0) {
                                 msv[r] = o;
-                                uint32_t *list = klass == MC_EASY ? req_easy : klass == MC_HARD ? req_hard : req_legacy;
-                                list[atomicAdd(klass == MC_LEGACY ? legacy_ctr : &ctr[klass], 1u)] = r;
+                                if (klass == MC_EASY && n_in > lane_threshold) {
+                                    /* lane passes: the windows are listed by band width (BRX_LANE_CLASSES lists of d.n_reads entries),
+                                       so that the 64 windows of a lane-kernel wave are equally wide (k_win_lane) */
+                                    const uint32_t cls = brx_lane_class(band_blocks_of);
+                                    req_easy[(size_t)cls * d.n_reads + atomicAdd(&lane_cls[cls], 1u)] = r;
+                                    atomicAdd(&ctr[MC_EASY], 1u);
+                                } else {
+                                    uint32_t *list = klass == MC_EASY ? req_easy : klass == MC_HARD ? req_hard : req_legacy;
+                                    list[atomicAdd(klass == MC_LEGACY ? legacy_ctr : &ctr[klass], 1u)] = r;
+                                }
                                 if (klass != MC_LEGACY) active_out[atomicAdd(&ctr[MC_OUT], 1u)] = r;
                             }
                             if (klass == MC_LEGACY) ms.phase = 3u;
@@ -494,7 +510,6 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
             o->loops = (uint32_t)loops; o->changes = change; o->naligns = nalign;
             o->units = 0;                                          /* sized by k_fin_join */
             msv[r].phase = 2u;
-            if ((uint32_t)s.tb_off >= d.early_begin) atomicAdd(d.early_ctr, 1u);      /* the early set of the final stage starts when all its reads are here */
             ck[0] += __builtin_amdgcn_s_memtime() - t_begin; ck[1] = INLINE ? nalign : ms.passes;
         }
     }
@@ -505,11 +520,11 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
  * ----------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(64, 5) k_win_wave(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr, uint32_t *queue,
                                                   const uint8_t *winbuf, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags,
-                                                  uint32_t *next_ctr) {
+                                                  uint32_t *next_ctr, uint32_t *next_cls) {
     const int lane = lane_id();
     const uint32_t n_req = uni(*n_req_ptr);
     /* the counter block of the NEXT pass: last read (as the input count) by this pass's k_mutate_seg, which is done */
-    if (next_ctr && blockIdx.x == 0 && lane < (int)MC_WORDS) next_ctr[lane] = 0u;
+    if (next_ctr && blockIdx.x == 0 && lane < (int)MC_WORDS) { next_ctr[lane] = 0u; next_cls[lane] = 0u; }
     uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)blockIdx.x * scr_bytes);
     for (;;) {
         const uint32_t qi = wave_pop(queue);
@@ -707,15 +722,25 @@ __device__ inline void brx_lanes_align(const bool valid, const uint32_t *__restr
 }
 
 
-__global__ void __launch_bounds__(64, 4) k_win_lane(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr,
+__global__ void __launch_bounds__(64, 4) k_win_lane(MS *msv, const uint32_t *req, const uint32_t *cls_cnt, uint32_t stride,
                                                      const uint8_t *winbuf, uint2 *tbw_base) {
     const int lane = lane_id();
-    const uint32_t n_req = uni(*n_req_ptr);
     uint2 *tbw = tbw_base + (uint64_t)blockIdx.x * BRX_LANE_TB_UNITS;
-    for (uint32_t base = blockIdx.x * 64u; base < n_req; base += gridDim.x * 64u) {
-        const uint32_t idx = base + (uint32_t)lane;
+    /* groups of 64 windows, the widest class first (it is also the longest-running: every column computes more slots) */
+    uint32_t cnt[BRX_LANE_CLASSES], total = 0;
+#pragma unroll
+    for (int cidx = 0; cidx < BRX_LANE_CLASSES; ++cidx) { cnt[cidx] = uni(cls_cnt[cidx]); total += (cnt[cidx] + 63u) >> 6; }
+    for (uint32_t grp = blockIdx.x; grp < total; grp += gridDim.x) {
+        uint32_t g0 = grp, cls = 0, n_req = 0;
+#pragma unroll
+        for (int cidx = BRX_LANE_CLASSES - 1; cidx >= 0; --cidx) {
+            const uint32_t ng = (cnt[cidx] + 63u) >> 6;
+            if (n_req == 0u && g0 < ng) { cls = (uint32_t)cidx; n_req = cnt[cidx]; }
+            else if (n_req == 0u) g0 -= ng;
+        }
+        const uint32_t idx = g0 * 64u + (uint32_t)lane;
         const bool valid = idx < n_req;
-        const uint32_t r = valid ? req[idx] : 0u;
+        const uint32_t r = valid ? req[(size_t)cls * stride + idx] : 0u;
         MS ms;
         if (valid) ms = msv[r];
         const int Q = valid ? (int)(ms.win_b - ms.win_a) : 0, T = valid ? (int)ms.tl : 0, kb = valid ? (int)ms.cost : 0;

@@ -81,8 +81,7 @@ ROUTES = [
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},         # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
     {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0, 'BRX_WAVES_PER_CU': 2},       # lane passes; four slab-owning waves per band class reuse their slabs
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_EARLY_FRAC': 0.5, 'BRX_FIN_SPREAD': 0},   # three final sets: head, long bulk, early (the shorter half of the bulk reads, started during the passes); classes of the bulk set on one stream
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_EARLY_FRAC': 0},                     # no early set
+    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_FIN_SPREAD': 0},       # the bulk set's band classes one after the other on its own stream
     {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 0},       # pass waves never stage a read in LDS: 2-bit codes from global memory, changed test on repl[]
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 120},   # a slice of 120 words: reads up to 1.2 kb staged, longer ones beside them from global memory
 ]

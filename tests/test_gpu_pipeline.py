@@ -93,8 +93,7 @@ def test_sequence_fragments_matches_oracle():
                                  {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_LANE_THRESHOLD': '0'},        # two chains + in-place tail
                                  {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1', 'BRX_WIDE_STREAM': '0'},
                                  {'BRX_TAIL_READS': '16', 'BRX_LANE_THRESHOLD': '100', 'BRX_FIN_HEAD_READS': '64'},   # lane passes, then packed passes, then the tail
-                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_EARLY_FRAC': '0.5', 'BRX_FIN_SPREAD': '0'},       # early set = the shorter half of the bulk reads; bulk classes on one stream
-                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_EARLY_FRAC': '0'},                              # no early set
+                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_FIN_SPREAD': '0'},                              # bulk band classes on one stream
                                  {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0', 'BRX_STAGE_WORDS': '0'},    # pass waves never stage a read in LDS
                                  {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_STAGE_WORDS': '500'},   # short reads staged, long ones not
                                  {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0', 'BRX_WAVES_PER_CU': '1'}])     # 256 slab-owning waves per band class
