@@ -378,10 +378,16 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                     const uint32_t w = wave_bcast_u32(wj, j);
                     if (lane == j) {
                         rp[i0 + (uint64_t)j] = w;
-                        if constexpr (!INLINE) {      /* the map in global memory is what the next pass stages; the slice is what this one reads */
+                        if constexpr (!INLINE) {
+                            /* the map in global memory is what the next pass stages; the slice is what this one reads.  One lane,
+                               plain read-modify-write: this wave is the only writer of the read's map, its LDS operations stay in
+                               order, and without the slice the fence below orders the words in memory.  (As atomics these two cost
+                               ~25 instructions each: the compiler wraps every atomic in a wave-wide reduction.) */
                             const uint32_t pp = (uint32_t)i0 + (uint32_t)j;
-                            atomicOr(&cmg[pp >> 5], 1u << (pp & 31u));
-                            if (staged_cm) atomicOr(&brx_stage_lds[pp >> 5], 1u << (pp & 31u));
+                            uint32_t word;
+                            if (staged_cm) { word = brx_stage_lds[pp >> 5] | (1u << (pp & 31u)); brx_stage_lds[pp >> 5] = word; }
+                            else word = cmg[pp >> 5] | (1u << (pp & 31u));
+                            cmg[pp >> 5] = word;
                         }
                     }
                     if (!staged_cm) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      /* the next survivor tests repl[] */

@@ -18,6 +18,6 @@ res = {'command': 'python -m badread_amd simulate --reference grch38_like.fa --q
        'bases': t.get('bases'), 'reads': t.get('reads'), 'gbases_per_s_whole_command': round(t.get('bases', 0) / wall / 1e9, 3),
        'gbases_per_s_read_loop': round(t.get('bases', 0) / max(t.get('run_batches_seconds', 1e9), 1e-9) / 1e9, 3), 'driver_timing': t}
 print(json.dumps(res))
-open('$out/r03_cli_${tag}.json', 'w').write(json.dumps(res, indent=1))
+open('$out/${BRX_ROUND_TAG:-r04}_cli_${tag}.json', 'w').write(json.dumps(res, indent=1))
 PY
 tail -c 400 $out/cli_${tag}.err | tr '\r' '\n' | tail -4
