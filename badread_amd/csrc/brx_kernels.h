@@ -960,7 +960,13 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
 #define BRX_FIN4_WAVES 4         /* waves per SIMD the four-word class is compiled for (4: 128 VGPRs and 8 spilled words; 3: 147 VGPRs) */
 #endif
 template <int MAXG, int GLO, int GHI>
-__global__ void __launch_bounds__(64, (MAXG == 1 ? 5 : MAXG == 2 ? 4 : MAXG == 4 ? BRX_FIN4_WAVES : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *list, uint32_t n_list,
+#ifndef BRX_FIN1_WAVES
+#define BRX_FIN1_WAVES 5
+#endif
+#ifndef BRX_FIN2_WAVES
+#define BRX_FIN2_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, (MAXG == 1 ? BRX_FIN1_WAVES : MAXG == 2 ? BRX_FIN2_WAVES : MAXG == 4 ? BRX_FIN4_WAVES : 1)) k_fin_align(BrxDev d, RS *rs, const uint32_t *list, uint32_t n_list,
                                                    unsigned long long *ctr, const uint64_t *slabs, uint32_t *retries, int phase, const uint8_t *Fbuf,
                                                    uint8_t *seqbuf, uint8_t *opsbuf, uint8_t *slab_base, uint64_t *clk) {
     const int lane = lane_id();

@@ -537,8 +537,9 @@ def main():
     if os.path.isfile(tfile):
         try:
             rec = json.load(open(tfile))
-            if rec.get('reads_per_step') == R and rec.get('kernel') == top and rec.get('workload', 'kpn') == args.workload:
-                traffic = rec.get('hbm_bytes_per_launch')
+            one = rec.get('kernels', {}).get(top) if 'kernels' in rec else (rec if rec.get('kernel') == top else None)      # tools/pmc_traffic.py --all: every kernel that may rank first
+            if one and rec.get('reads_per_step') == R and rec.get('workload', 'kpn') == args.workload:
+                traffic = one.get('hbm_bytes_per_launch')
                 traffic_tree = rec.get('csrc_sha16')
         except (OSError, ValueError):
             pass

@@ -8,16 +8,8 @@ tail -3 $out/${tag}_pytest_gpu.log
 bash tools/profile_round.sh $tag human "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" "FETCH_SIZE" "WRITE_SIZE" > $out/${tag}_profile.log 2>&1
 cd "$root"
 cp $out/${tag}_valu_per_base.json profiles/valu_per_base.json          # bench.py's roofline_alu reads it (same tree: not stale)
-top=$(python - <<PY
-import csv
-rows = list(csv.DictReader(open('$out/${tag}_bench_kernel_stats.csv')))
-print(rows[0]['kernel'])
-PY
-)
-label=$(python -c "import sys; n = sys.argv[1].replace('void ', ''); n = 'k_mutate_seg<false>' if 'k_mutate_seg<false' in n else 'k_mutate_seg<true>' if 'k_mutate_seg<true' in n else n.replace(' ', ''); print(n)" "$top")
-# a kernel launched once per pass is averaged over all its dispatches; the few-launches-per-batch kernels over their full-size launches (2 batches x 2)
-full=$(python -c "import sys; print('' if 'k_mutate_seg<false' in sys.argv[1] or 'k_win' in sys.argv[1] else 4)" "$top")
-python tools/pmc_traffic.py $out/${tag}_pmc_per_kernel.csv 65536 "${top#void }" human "$label" $full > profiles/pmc_traffic.json 2>> $out/${tag}_profile.log
+python tools/pmc_traffic.py $out/${tag}_pmc_per_kernel.csv 65536 --all human > profiles/pmc_traffic.json 2>> $out/${tag}_profile.log
+cp profiles/pmc_traffic.json $out/${tag}_pmc_traffic.json          # profiles/ on the box is not merged back: gpurun_out/ is
 timeout 400 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 python bench.py --workload hifi --cpu-seconds 8 > $out/${tag}_bench_hifi.json 2> $out/${tag}_bench_hifi.err
 timeout 300 python bench.py --workload kpn --cpu-seconds 6 > $out/${tag}_bench_kpn.json 2> $out/${tag}_bench_kpn.err
