@@ -410,6 +410,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *active_b = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_easy = (uint32_t *)A.take((size_t)n_reads * 4 * BRX_LANE_CLASSES);    /* lane passes: one list per band-width class */
     uint32_t *lane_cls = (uint32_t *)A.take(2 * MC_WORDS * sizeof(uint32_t));             /* their counts, a block per pass parity */
+    MutAux *aux_dev = (MutAux *)A.take(2 * sizeof(MutAux));                               /* [0] bulk chain, [1] head chain: what k_mutate_seg reads where it uses it */
     uint32_t *req_hard = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy_head = (uint32_t *)A.take((size_t)n_reads * 4);
@@ -464,6 +465,12 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
     } else win_head = win;
     hipStream_t s_head = n_bulk ? c->side : st;            /* an all-head batch stays on the caller's stream */
+    MutAux h_aux[2];                                       /* lives until the call returns: the copy below is waited for with the mutate counters */
+    {
+        h_aux[0] = MutAux{req_easy, req_hard, req_legacy, mctr + 3 * MC_WORDS, winbuf, clk, win, (uint64_t)c->win_bytes, counters + 1, phase};
+        h_aux[1] = MutAux{req_easy, req_hard, req_legacy_head, mctr + 5 * MC_WORDS, winbuf, clk, win_head, (uint64_t)c->win_bytes, counters + 1, phase};
+        HIPCHK(c, hipMemcpyAsync(aux_dev, h_aux, sizeof(h_aux), hipMemcpyHostToDevice, st));
+    }
 
     struct FinalSet {
         uint32_t b, e;                 /* range of `order` */
@@ -757,12 +764,11 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
        taking these windows to a cheaper aligner -- workgroups of 8 reads with packed alignments, 8-wave pass kernels, a
        persistent launch with device queues -- and every one lost to this chain on the batch's critical path: DESIGN.md section 7.) */
     auto launch_run = [&](hipStream_t s, uint32_t count, const uint32_t *act_in, const uint32_t *n_in, uint32_t *act_out, uint32_t *ctr,
-                          uint32_t *legacy_list, uint32_t *legacy_ctr, uint8_t *winscr) {
+                          const MutAux *aux) {
         KTIMED(BRX_KERN_MUTATE_RUN, s);
 #define BRX_LAUNCH_RUN(PROF)                                                                                                        \
         hipLaunchKernelGGL((k_mutate_seg<true, PROF, BRX_SEG_WPS>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in,   \
-                           act_out, ctr, req_easy, req_hard, legacy_list, legacy_ctr, Fbuf, repl, winbuf, clk, lane_threshold,        \
-                           winscr, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words, lane_cls)
+                           act_out, ctr, aux, Fbuf, repl, lane_threshold, F2buf, Cbuf, c->stage_words, lane_cls)
         if (c->profile) BRX_LAUNCH_RUN(true); else BRX_LAUNCH_RUN(false);
 #undef BRX_LAUNCH_RUN
     };
@@ -773,8 +779,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             HIPCHK(c, hipEventRecord(c->ev_fork, st));
             HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
         }
-        launch_run(s_head, n_mh, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, req_legacy_head,
-                   mctr + 5 * MC_WORDS, win_head);
+        launch_run(s_head, n_mh, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, aux_dev + 1);
         if (n_mb) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
         c->mutate_passes = 1;
     }
@@ -809,7 +814,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                     HIPCHK(c, hipStreamSynchronize(st));
                     for (uint32_t x : h_act) if (x < n_reads) tail_bases += h_rs[x].n;
                 }
-                launch_run(st, n_up, act_in, n_in, act_out, ctr, req_legacy, legacy_ctr, win);
+                launch_run(st, n_up, act_in, n_in, act_out, ctr, aux_dev);
                 rc2 = read_counts(ctr);
                 if (rc2) return rc2;
                 n_up = h_ctr[MC_OUT];                   /* 0 unless a window overflowed its slot (then: legacy list) */
@@ -823,12 +828,10 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 KTIMED(BRX_KERN_MUTATE_SEG, st);
                 if (c->profile)
                     hipLaunchKernelGGL((k_mutate_seg<false, true, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                                       ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_pass_thr,
-                                       win, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS);
+                                       ctr, aux_dev, Fbuf, repl, lane_pass_thr, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS);
                 else
                     hipLaunchKernelGGL((k_mutate_seg<false, false, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                                       ctr, req_easy, req_hard, req_legacy, legacy_ctr, Fbuf, repl, winbuf, clk, lane_pass_thr,
-                                       win, (uint64_t)c->win_bytes, counters + 1, phase, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS);
+                                       ctr, aux_dev, Fbuf, repl, lane_pass_thr, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS);
             }
             if (n_up > lane_threshold) {
                 KTIMED(BRX_KERN_WIN_LANE, st);
@@ -841,7 +844,9 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             }
             {   /* the windows the lane / pack kernel does not take: one per wave; it also zeroes the counter block of the NEXT pass */
                 KTIMED(BRX_KERN_WIN_WAVE, st);
-                hipLaunchKernelGGL(k_win_wave, dim3(std::min(side_waves, n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
+                /* few windows take this kernel (symbols outside ACGT, very wide bands): 512 waves pull them from the queue; a grid of one
+                   wave per active read was 4096 waves that start only to find the queue empty, once per pass on the critical path */
+                hipLaunchKernelGGL(k_win_wave, dim3(std::min(std::min(side_waves, 512u), n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
                                    ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1, mctr + ((pass + 1) & 1u) * MC_WORDS,
                                    lane_cls + ((pass + 1) & 1u) * MC_WORDS);
             }

@@ -90,8 +90,11 @@ __device__ __forceinline__ uint32_t brx_lane_class(int band_blocks) {
 #define BRX_STAGE_WORDS 2560                              /* 10 KB: sixteen waves per CU keep their slices; F2 + map of reads up to 27 kb */
 #endif
 __shared__ uint32_t brx_stage_lds[BRX_STAGE_WORDS];
-#define brx_park_lds (reinterpret_cast<uint8_t *>(brx_stage_lds))
-static_assert(BRX_STAGE_WORDS * 4 >= BRX_PARK_LDS + 64, "the parking window lives in the staging slice");
+/* the run-to-completion kernel never stages a read: its parking window is its own, smaller array (a 10 KB slice beside the
+   aligner's 2 KB ring would keep a CU at 13 of its 16 waves) */
+__shared__ uint32_t brx_park_small_lds[(BRX_WIN_BYTES - BRX_WIN_Q) / 4 + 4];
+#define brx_park_lds (reinterpret_cast<uint8_t *>(PLANES ? brx_stage_lds : brx_park_small_lds))
+static_assert(BRX_STAGE_WORDS * 4 >= BRX_WIN_BYTES - BRX_WIN_Q + 16, "the parking window lives in the staging slice");
 struct __attribute__((packed, aligned(1))) BrxB16 { uint32_t x, y, z, w; };      /* sixteen bytes behind any address */
 static_assert(BRX_ALIGN_SIZE + 16 <= 1024 && BRX_WIN_Q >= 1024, "a window is 64 lanes x 16 positions");
 
@@ -231,13 +234,32 @@ __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F
  * again 4.70-4.72 against 4.76 on the next tree): the head chain is one wave per SIMD, but its registers are taken from the
  * other five batches' kernels on the same SIMDs.  The pass kernel at three waves (156 VGPRs, no scratch) against four (128,
  * 116 B): 4.76 against 4.88.  Four it is, for both. */
+/* What only parking, the in-place alignment and the epilogue use -- once per alignment cycle -- lives in device memory and is read
+ * where it is used (a volatile load: not hoisted), not in kernel arguments: the kernel runs at its SGPR limit (106), a fifth of its
+ * instructions were v_readlane / v_writelane spill traffic, and every argument is two SGPRs that stay live over the whole loop. */
+struct MutAux {
+    uint32_t *req_easy, *req_hard, *req_legacy, *legacy_ctr;
+    uint8_t *winbuf;
+    uint64_t *clk;
+    uint8_t *scr_base;
+    uint64_t scr_bytes;
+    uint32_t *flags;
+    uint64_t *phase;
+};
+template <typename T>
+__device__ __forceinline__ T brx_cold(T const *field) {
+    static_assert(sizeof(T) == 8, "pointers and 64-bit sizes");
+    const uint64_t v = *reinterpret_cast<const volatile uint64_t *>(field);
+    const uint64_t u = uni(v);
+    T out; __builtin_memcpy(&out, &u, 8);
+    return out;
+}
+
 template <bool INLINE, bool PROFILE = false, int WPS = 4>
 __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
                                                     const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,
-                                                    uint32_t *req_easy, uint32_t *req_hard, uint32_t *req_legacy, uint32_t *legacy_ctr,
-                                                    const uint8_t *Fbuf, uint32_t *repl, uint8_t *winbuf, uint64_t *clk,
-                                                    uint32_t lane_threshold, uint8_t *scr_base, uint64_t scr_bytes, uint32_t *flags,
-                                                    uint64_t *phase, const uint32_t *F2buf, uint32_t *Cbuf, uint32_t stage_words,
+                                                    const MutAux *aux, const uint8_t *Fbuf, uint32_t *repl,
+                                                    uint32_t lane_threshold, const uint32_t *F2buf, uint32_t *Cbuf, uint32_t stage_words,
                                                     uint32_t *lane_cls) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
@@ -410,7 +432,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                         /* one pass over the window: F[a:b] -> query slot, join(new[a:b]) -> target slot (clipped to the
                            slot; an overflowing window goes to the whole-read kernel), edit bound, non-ACGT flag */
                         uint32_t cost = 0;
-                        uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+                        uint8_t *qb = brx_cold(&aux->winbuf) + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
                         bool odd = false;
                         const uint32_t tl = wave_park<!INLINE>(em, F, rp, a, b, qb, tbuf, BRX_WIN_TMAX, &cost, &odd,
                                                                reinterpret_cast<uint32_t *>(qb + BRX_WIN_PLANES));
@@ -431,6 +453,9 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                                               (n_in > lane_threshold ? band_blocks <= BRX_LANE_W : brx_pack_eligible(ql, tl, cost, odd));
                             klass = easy ? MC_EASY : MC_HARD;
                         }
+                        /* the lists a parked read is entered in (read here by the whole wave, used by lane 0) */
+                        uint32_t *c_easy = brx_cold(&aux->req_easy), *c_hard = brx_cold(&aux->req_hard), *c_legacy = brx_cold(&aux->req_legacy);
+                        uint32_t *c_legacy_ctr = brx_cold(&aux->legacy_ctr);
                         {
                             MS o = ms;
                             o.errors = errors; o.est = est; o.round_loops = loops; o.change = change; o.nalign = nalign;
@@ -445,11 +470,11 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                                     /* lane passes: the windows are listed by band width (BRX_LANE_CLASSES lists of d.n_reads entries),
                                        so that the 64 windows of a lane-kernel wave are equally wide (k_win_lane) */
                                     const uint32_t cls = brx_lane_class(band_blocks_of);
-                                    req_easy[(size_t)cls * d.n_reads + atomicAdd(&lane_cls[cls], 1u)] = r;
+                                    c_easy[(size_t)cls * d.n_reads + atomicAdd(&lane_cls[cls], 1u)] = r;
                                     atomicAdd(&ctr[MC_EASY], 1u);
                                 } else {
-                                    uint32_t *list = klass == MC_EASY ? req_easy : klass == MC_HARD ? req_hard : req_legacy;
-                                    list[atomicAdd(klass == MC_LEGACY ? legacy_ctr : &ctr[klass], 1u)] = r;
+                                    uint32_t *list = klass == MC_EASY ? c_easy : klass == MC_HARD ? c_hard : c_legacy;
+                                    list[atomicAdd(klass == MC_LEGACY ? c_legacy_ctr : &ctr[klass], 1u)] = r;
                                 }
                                 if (klass != MC_LEGACY) active_out[atomicAdd(&ctr[MC_OUT], 1u)] = r;
                             }
@@ -476,8 +501,9 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
         BRX_PHASE(4);
         if (INLINE && parked && ms.phase == 1u) {
             /* align the parked window here, at the top level where only MS is live, and resume the same read */
-            const uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
-            uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)wave_index * scr_bytes);
+            const uint8_t *qb = brx_cold(&aux->winbuf) + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+            const uint64_t scr_bytes = brx_cold(&aux->scr_bytes);
+            uint2 *tb = reinterpret_cast<uint2 *>(brx_cold(&aux->scr_base) + (uint64_t)wave_index * scr_bytes);
             int ncols = 0, nmatch = 0; bool nospace = false;
             BRX_PHASE(3);
             const bool ok = brx_wave_align<1, 1>(qb, (int)(ms.win_b - ms.win_a), tbuf, (int)ms.tl, (int)ms.cost, tb, scr_bytes / 8, nullptr,
@@ -485,16 +511,19 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
             BRX_PHASE(4);
             ms.res_ncols = (uint32_t)ncols; ms.res_nmatch = (uint32_t)nmatch;
             if (!ok && !nospace) ms.status |= BRX_RS_BAND;
-            if (nospace && lane == 0) { atomicOr(&flags[0], 1u); flags[8] = r; flags[9] = ms.win_b - ms.win_a; flags[10] = ms.tl; flags[11] = ms.cost; }
+            if (nospace) {
+                uint32_t *flags = brx_cold(&aux->flags);
+                if (lane == 0) { atomicOr(&flags[0], 1u); flags[8] = r; flags[9] = ms.win_b - ms.win_a; flags[10] = ms.tl; flags[11] = ms.cost; }
+            }
             continue;
         }
         break;
       }
-        uint64_t *ck = clk + (uint64_t)r * 8;
+        uint64_t *ck = brx_cold(&aux->clk) + (uint64_t)r * 8;
         if constexpr (PROFILE) {
             BRX_PHASE(4);
+            uint64_t *pp = brx_cold(&aux->phase) + (uint64_t)r * 8;
             if (lane == 0) {
-                uint64_t *pp = phase + (uint64_t)r * 8;
                 pp[0] += ph0; pp[1] += ph1; pp[2] += ph2; pp[3] += ph3; pp[4] += ph4; pp[5] += pclk[0]; pp[6] += pclk[1];
             }
         }
