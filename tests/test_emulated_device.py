@@ -196,7 +196,7 @@ def _window_overflow(tmp_path):
     for e in (eng, orc):
         e.set_error_model(tables)
         e.set_qscore_model(H.qscore_tables('ideal'))
-    frags = [rng.integers(0, 4, n).astype(np.uint8) for n in (900, 400)]
+    frags = [rng.integers(0, 4, n).astype(np.uint8) for n in (560, 300)]
     targets = [0.05, 0.3]
     rh, sh = eng.sequence_fragments(9, 0, frags, targets)
     ro, so = orc.sequence_fragments(9, 0, frags, targets)
@@ -204,7 +204,7 @@ def _window_overflow(tmp_path):
         assert (sh[f] == so[f]).all(), f
     for a, b in zip(rh, ro):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-    assert int(sh["padded_len"][0]) > 8 * 900                      # the windows really overflowed
+    assert int(sh["padded_len"][0]) > 8 * 560                      # the windows really overflowed
     return eng
 
 
@@ -213,11 +213,11 @@ def test_final_stage_with_fewer_slabs_than_reads(monkeypatch):
     (brx_hip.hip, launch_final_phase).  An arena that holds the largest store but not one slab per read: the set runs with
     fewer waves, every wave reusing its slab for several reads; same bytes."""
     pref, _ = H.small_reference()
-    p = SimParams(frag_mean=5000, frag_stdev=2000)
+    p = SimParams(frag_mean=3200, frag_stdev=1300)
     orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
     out_o, st_o = orc.simulate_batch(8, 0, 28)
     slabs = []
-    for scratch in (1 << 29, 24 << 20):
+    for scratch in (1 << 29, 20 << 20):
         eng = H.configure(emu_engine(monkeypatch, scratch=scratch, BRX_TB_WINDOW=0, BRX_WIN_KB=128), pref, 'nanopore2023', 'nanopore2023', p)
         out_h, st_h = eng.simulate_batch(8, 0, 28)
         slabs.append(eng.final_launches())

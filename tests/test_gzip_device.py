@@ -169,8 +169,8 @@ def test_driver_gzip_device_option_equals_plain_output():
     from badread_amd import simulate as S
     from test_host_simulate import Args
     plain, packed = io.BytesIO(), io.BytesIO()
-    S.simulate(Args(), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=plain, shard=S.Shard())
-    S.simulate(Args(gzip_device=True), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=packed, shard=S.Shard())
+    S.simulate(Args(quantity='12x'), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=plain, shard=S.Shard())
+    S.simulate(Args(quantity='12x', gzip_device=True), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=packed, shard=S.Shard())
     assert gzip.decompress(packed.getvalue()) == plain.getvalue() and 0 < len(packed.getvalue()) < len(plain.getvalue())
     with pytest.raises(SystemExit):
         S.simulate(Args(gzip_device=True, gzip_level=3), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=io.BytesIO(), shard=S.Shard())
@@ -217,7 +217,7 @@ from test_host_simulate import Args
 S.DEFAULT_MAX_BATCH = 24
 shard = S.Shard.from_env()
 out = io.BytesIO()
-S.simulate(Args(gzip_device=True), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=out, shard=shard)
+S.simulate(Args(quantity='12x', gzip_device=True), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=out, shard=shard)
 if shard.rank == 0:
     open({outfile!r}, 'wb').write(out.getvalue())
 else:
@@ -238,7 +238,7 @@ def test_two_ranks_compress_their_own_bytes_and_rank_0_writes_one_stream(tmp_pat
     here = os.path.dirname(os.path.abspath(__file__))
     monkeypatch.setattr(S, 'DEFAULT_MAX_BATCH', 24)
     plain = io.BytesIO()
-    S.simulate(Args(), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=plain, shard=S.Shard())
+    S.simulate(Args(quantity='12x'), output=io.StringIO(), engine=EE.EmuEngine(1 << 26), stdout=plain, shard=S.Shard())
     port = _free_port()
     outfile = str(tmp_path / 'ranks.fastq.gz')
     script = tmp_path / 'worker.py'
