@@ -480,14 +480,14 @@ def main():
     extra = {'passes': float(sum(a['passes'] for a in acc)), 'misses': float(sum(a['misses'] for a in acc)),
              'host_ms': float(sum(a['host_ms'] for a in acc)), 'host_cpu_s': float(host_cpu_s),
              'lane_useful': float(sum(a['lane_useful'] for a in acc)), 'lane_issued': float(sum(a['lane_issued'] for a in acc))}
-    if dist is not None and not dry:
+    if dist is not None:
         # the per-kernel, per-stage and host statistics of EVERY rank (round 3 reported rank 0's alone): one sum over a fixed layout
         from badread_amd.engine import KERNEL_NAMES, STAGE_NAMES
         vec = [stage_sum.get(n, 0.0) for n in STAGE_NAMES]
         for n in KERNEL_NAMES:
             vec += list(kern.get(n, [0, 0.0, 0.0]))
         vec += [extra[k] for k in sorted(extra)]
-        tv = torch.tensor(vec, dtype=torch.float64, device='cuda')
+        tv = torch.tensor(vec, dtype=torch.float64, device='cpu' if dry else 'cuda')      # the dry run (gloo) takes the same path: tests/test_bench_launch.py
         dist.all_reduce(tv, op=dist.ReduceOp.SUM)
         vec = tv.tolist()
         stage_sum = dict(zip(STAGE_NAMES, vec[:len(STAGE_NAMES)]))
