@@ -54,6 +54,7 @@ struct brx_ctx {
     hipEvent_t ev_fork2[2], ev_join2[2], ev_head_mut;
     hipEvent_t ev_fork3, ev_join3[2];   /* the bulk set's band classes on the head chain's streams */
     int fin_spread;                      /* BRX_FIN_SPREAD (default 1) */
+    int fin_lanes;                       /* BRX_FIN_LANES (default 1): narrow-band final alignments one read per lane (k_fin_lanes) */
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
                                     three wide classes: a stream per class measured 30 % slower, r01d) */
     hipEvent_t ev_fork, ev_join;
@@ -169,6 +170,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         (e = hipEventCreateWithFlags(&c->ev_join3[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_join3[1], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *v = getenv("BRX_FIN_SPREAD"); c->fin_spread = v ? atoi(v) : 1; }
+    { const char *v = getenv("BRX_FIN_LANES"); c->fin_lanes = v ? atoi(v) : 1; }
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 512u; }
     { const char *v = getenv("BRX_STAGE_WORDS"); c->stage_words = v ? std::min<uint32_t>((uint32_t)atoi(v), (uint32_t)BRX_STAGE_WORDS) : (uint32_t)BRX_STAGE_WORDS; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
@@ -478,15 +480,15 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         int id;                        /* 0 head, 1 bulk: selects counter slots and events */
         bool launched, wide_forked;
         size_t tb_at, tb_cap, col_bytes;   /* the set's region of the arena: col_of[] of its reads, then the slabs of its align kernels */
-        uint64_t bases_by_class[5];    /* G = 1, 2, 4, 8+, all */
+        uint64_t bases_by_class[6];    /* G = 1, 2, 4, 8+, all, narrow band one read per lane */
     };
     /* (Round 4 also ran THREE sets -- the reads with the fewest expected changes as an EARLY set whose final stage started
        during the passes on the head chain's idle stream, every early read counting itself when its loop was done.  It overlapped
        as designed -- final stage behind the mutate stage 250 -> 205 ms -- and the passes it ran beside slowed down by as much:
        5.16-5.18 against 5.22-5.26 Gbases/s without it, six batches in flight; removed.  profiles/r04i, r04j.) */
     FinalSet sets[2];
-    sets[0] = FinalSet{0, n_head, s_head, (c->wide_stream && n_bulk) ? c->side2 : s_head, 0, false, false, 0, 0, 0, {0, 0, 0, 0, 0}};
-    sets[1] = FinalSet{n_head, n_reads, st, st, 1, false, false, 0, 0, 0, {0, 0, 0, 0, 0}};
+    sets[0] = FinalSet{0, n_head, s_head, (c->wide_stream && n_bulk) ? c->side2 : s_head, 0, false, false, 0, 0, 0, {0, 0, 0, 0, 0, 0}};
+    sets[1] = FinalSet{n_head, n_reads, st, st, 1, false, false, 0, 0, 0, {0, 0, 0, 0, 0, 0}};
     uint64_t *set_tboff = tboff_sorted;       /* staging array of the col_of[] offsets, indexed by order position */
     uint64_t *fin_slabs = units_sorted;        /* slab offset tables of the sets' align kernels (n_reads + 16 words) */
     std::vector<uint64_t> h_tboff(n_reads);
@@ -510,8 +512,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
      * col_of[] (k_fin_qscore: 4 bytes per read base) stays per read, in front of the slabs. */
     auto launch_final_phase = [&](FinalSet &S, int phase) -> int {
         const uint32_t ns = S.e - S.b;
-        std::vector<uint32_t> cls_list[4];
-        std::vector<uint64_t> cls_units[4];
+        std::vector<uint32_t> cls_list[5];          /* [4]: the narrow-band class (k_fin_lanes), its units are per GROUP of 64 reads */
+        std::vector<uint64_t> cls_units[5];
         uint64_t col_total = 0;
         for (uint32_t i = S.b; i < S.e; ++i) {
             const RS &r = h_rs[h_order[i]];
@@ -524,6 +526,11 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             const uint64_t raw_cols = ((uint64_t)r.m * 4 + 7) / 8 + 2;
             const uint64_t u = (phase == 1 ? brx_final_units(r.m, r.n, r.ub, 0, &too_wide) : r.units) - raw_cols;     /* the aligner's share */
             const uint32_t kl = r.klass & 0xFFFFu;
+            if (r.klass & BRX_KL_LANES) {              /* never repeats (no windowed store): phase 0 only */
+                cls_list[4].push_back(h_order[i]);
+                cls_units[4].push_back(((uint64_t)r.n << 8) | (uint64_t)brx_finl_blocks(r.m, r.n, r.ub));     /* sorted by fragment length below; units per group follow */
+                continue;
+            }
             const int k = kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3;
             cls_list[k].push_back(h_order[i]);
             cls_units[k].push_back((u + 31) & ~31ull);
@@ -533,11 +540,12 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
            store grows with length x band width, and so does the work: the order is also longest-processing-time first), so the
            suffix maximum at position t is the t-th largest store and W waves hold the W largest stores of the class. */
         const uint32_t wpc = (uint32_t)c->waves_per_cu;
-        const uint32_t limit[4] = {(uint32_t)c->n_cu * std::max(wpc / 2u, 1u), (uint32_t)c->n_cu * std::max(wpc / 4u, 1u),
-                                   (uint32_t)c->n_cu * std::max(wpc / 8u, 1u), (uint32_t)c->n_cu * std::max(wpc / 16u, 1u)};
-        uint32_t grid[4];
-        std::vector<uint64_t> sufmax[4];
-        for (int k = 0; k < 4; ++k) {
+        const uint32_t limit[5] = {(uint32_t)c->n_cu * std::max(wpc / 2u, 1u), (uint32_t)c->n_cu * std::max(wpc / 4u, 1u),
+                                   (uint32_t)c->n_cu * std::max(wpc / 8u, 1u), (uint32_t)c->n_cu * std::max(wpc / 16u, 1u),
+                                   (uint32_t)c->n_cu * std::max(wpc / 4u, 1u)};
+        uint32_t grid[5];
+        std::vector<uint64_t> sufmax[5];
+        for (int k = 0; k < 5; ++k) {
             {
                 std::vector<uint32_t> idx(cls_list[k].size());
                 for (size_t x = 0; x < idx.size(); ++x) idx[x] = (uint32_t)x;
@@ -546,13 +554,23 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 for (size_t x = 0; x < idx.size(); ++x) { l2[x] = cls_list[k][idx[x]]; u2[x] = cls_units[k][idx[x]]; }
                 cls_list[k].swap(l2); cls_units[k].swap(u2);
             }
-            const size_t n = cls_list[k].size();
+            if (k == 4) {                             /* groups of 64 reads, longest fragment first: a group's store holds its first read */
+                const size_t ng = (cls_list[4].size() + 63) / 64;
+                std::vector<uint64_t> gu(ng);
+                for (size_t gidx = 0; gidx < ng; ++gidx) {      /* the longest fragment of the group (its first) x the widest band in it */
+                    uint32_t blocks = 0;
+                    for (size_t x = gidx * 64; x < std::min(cls_units[4].size(), gidx * 64 + 64); ++x) blocks = std::max<uint32_t>(blocks, (uint32_t)(cls_units[4][x] & 0xFFu));
+                    gu[gidx] = (brx_finl_units((uint32_t)(cls_units[4][gidx * 64] >> 8), blocks) + 31) & ~31ull;
+                }
+                cls_units[4].swap(gu);
+            }
+            const size_t n = cls_units[k].size();      /* entries the class's waves pop: reads, or groups of reads */
             sufmax[k].assign(n + 1, 0);
             for (size_t x = n; x-- > 0;) sufmax[k][x] = std::max(sufmax[k][x + 1], cls_units[k][x]);
             grid[k] = (uint32_t)std::min<size_t>(n, limit[k]);
         }
         auto slab_units = [&](int k) { uint64_t t = 0; for (uint32_t w = 0; w < grid[k]; ++w) t += sufmax[k][w]; return t; };
-        auto need = [&]() { uint64_t t = (phase == 0 ? col_total : 0) + 512; for (int k = 0; k < 4; ++k) t += slab_units(k); return t * 8; };
+        auto need = [&]() { uint64_t t = (phase == 0 ? col_total : 0) + 512; for (int k = 0; k < 5; ++k) t += slab_units(k); return t * 8; };
         size_t at = (A.used + 255) & ~(size_t)255;
         size_t left = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
         if (phase == 0) {
@@ -572,12 +590,12 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         } else if (S.tb_cap > left) { at = S.tb_at + S.col_bytes; left = S.tb_cap - S.col_bytes; }      /* the set's own slab area is free again */
         for (int guard = 0; need() > left && guard < 96; ++guard) {
             int big = -1;
-            for (int k = 0; k < 4; ++k) if (grid[k] > 1 && (big < 0 || slab_units(k) > slab_units(big))) big = k;
+            for (int k = 0; k < 5; ++k) if (grid[k] > 1 && (big < 0 || slab_units(k) > slab_units(big))) big = k;
             if (big < 0) break;
             grid[big] = (grid[big] + 1) / 2;
         }
-        DBG("final set %d phase %d: %u reads, classes %zu/%zu/%zu/%zu, slabs %u/%u/%u/%u, need %.2f GB, left %.2f GB, arena used %.2f GB", S.id, phase, ns,
-            cls_list[0].size(), cls_list[1].size(), cls_list[2].size(), cls_list[3].size(), grid[0], grid[1], grid[2], grid[3],
+        DBG("final set %d phase %d: %u reads, classes %zu/%zu/%zu/%zu + %zu by lane, slabs %u/%u/%u/%u + %u, need %.2f GB, left %.2f GB, arena used %.2f GB", S.id, phase, ns,
+            cls_list[0].size(), cls_list[1].size(), cls_list[2].size(), cls_list[3].size(), cls_list[4].size(), grid[0], grid[1], grid[2], grid[3], grid[4],
             (double)need() / 1e9, (double)left / 1e9, (double)A.used / 1e9);
         if (need() > left) return scratch_short(c, c->scratch_bytes + (size_t)(need() - left) + ((size_t)1 << 28));
         uint8_t *region = c->scratch + at;
@@ -588,9 +606,9 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         /* device tables, in the set's share [S.b, S.e) of the staging arrays: read lists (u32) and slab offsets (u64, in units) */
         std::vector<uint32_t> h_lists; h_lists.reserve(ns + 8);
         std::vector<uint64_t> h_slabs; h_slabs.reserve(ns + 16);
-        uint32_t list_at[4], slab_at[4];
+        uint32_t list_at[5], slab_at[5];
         uint64_t run = 0;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 5; ++k) {
             list_at[k] = (uint32_t)h_lists.size(); slab_at[k] = (uint32_t)h_slabs.size();
             h_lists.insert(h_lists.end(), cls_list[k].begin(), cls_list[k].end());
             for (uint32_t w = 0; w < grid[k]; ++w) { h_slabs.push_back(run); run += sufmax[k][w]; }
@@ -610,7 +628,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         const uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
         uint32_t *cq = counters + 16 + 16 * (((size_t)S.id * 2 + (size_t)phase));      /* queue heads of this set and phase: [0..7] four 64-bit class counters, [8], [9] qscore */
         uint32_t *misses = set_counter(S, 1);
-        const uint32_t cnt[4] = {(uint32_t)cls_list[0].size(), (uint32_t)cls_list[1].size(), (uint32_t)cls_list[2].size(), (uint32_t)cls_list[3].size()};
+        const uint32_t cnt[5] = {(uint32_t)cls_list[0].size(), (uint32_t)cls_list[1].size(), (uint32_t)cls_list[2].size(), (uint32_t)cls_list[3].size(),
+                                 (uint32_t)cls_list[4].size()};
         /* The widest bands (8+ words per lane: a few dozen reads, each a chain of ~100 k column steps of ~2 us) go first, on
            the set's wide stream when it has one; then the 4-, 2- and 1-word classes on the set's own stream, each scored
            (k_fin_qscore) as soon as its class is aligned. */
@@ -653,6 +672,12 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                                  reinterpret_cast<unsigned long long *>(cq + 2), d_slabs + slab_at[1], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk); }
             score_class(1, cls_stream[1], cq + 10);
         }
+        if (cnt[4]) {                                 /* the narrow-band class, one read per lane: with pacbio2021 / --identity 30,3 nearly every read */
+            { KTIMED(BRX_KERN_FIN_LANES, cls_stream[0]);
+              hipLaunchKernelGGL(k_fin_lanes, dim3(grid[4]), dim3(64), 0, cls_stream[0], dev, rs, d_lists + list_at[4], cnt[4],
+                                 reinterpret_cast<unsigned long long *>(cq + 12), d_slabs + slab_at[4], Fbuf, c->scratch, c->scratch, slab_base, clk); }
+            score_class(4, cls_stream[0], cq + 14);
+        }
         if (cnt[0]) {
             { KTIMED(BRX_KERN_FIN_ALIGN1, cls_stream[0]);
               hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(grid[0]), dim3(64), 0, cls_stream[0], dev, rs, d_lists + list_at[0], cnt[0],
@@ -671,7 +696,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
                                cq + 9, phase, 5, 0xFFFF, c->scratch, c->scratch, col_base, clk);
         }
-        if (phase == 0) c->final_launches += grid[0] + grid[1] + grid[2] + grid[3];     /* slabs = waves of the set's align kernels */
+        if (phase == 0) c->final_launches += grid[0] + grid[1] + grid[2] + grid[3] + grid[4];     /* slabs = waves of the set's align kernels */
         return BRX_OK;
     };
 
@@ -715,7 +740,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         {
             KTIMED(BRX_KERN_FIN_JOIN, S.st);
             hipLaunchKernelGGL(k_fin_join, dim3(std::min<uint64_t>(ns, (uint64_t)c->n_cu * 16u)), dim3(64), 0, S.st, dev, rs, order, S.b, S.e,
-                               set_counter(S, 0), (uint64_t)(seqbuf - c->scratch), (uint64_t)(opsbuf - c->scratch), Fbuf, repl, pieces, c->scratch);
+                               set_counter(S, 0), (uint64_t)(seqbuf - c->scratch), (uint64_t)(opsbuf - c->scratch), Fbuf, repl, pieces, c->scratch,
+                               F2buf, c->fin_lanes);
         }
         HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, S.st));
         { int rcw = wait_stream(c, S.st, "k_fin_join"); if (rcw) return rcw; }
@@ -723,7 +749,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             const RS &r = h_rs[h_order[i]];
             if (!r.n) continue;
             const uint32_t kl = r.klass & 0xFFFFu;
-            S.bases_by_class[kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3] += r.n;
+            S.bases_by_class[(r.klass & BRX_KL_LANES) ? 5 : kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3] += r.n;
             S.bases_by_class[4] += r.n;
         }
         return launch_final_phase(S, 0);
@@ -942,6 +968,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         c->kstat[BRX_KERN_MUTATE_SEG].bases = c->kstat[BRX_KERN_WIN_LANE].bases = c->kstat[BRX_KERN_WIN_WAVE].bases = (double)(all - head_b);
         c->kstat[BRX_KERN_FIN_ALIGN1].bases = by_class[0]; c->kstat[BRX_KERN_FIN_ALIGN2].bases = by_class[1];
         c->kstat[BRX_KERN_FIN_ALIGN4].bases = by_class[2]; c->kstat[BRX_KERN_FIN_ALIGN16].bases = by_class[3];
+        c->kstat[BRX_KERN_FIN_LANES].bases = (double)(sets[0].bases_by_class[5] + sets[1].bases_by_class[5]);
         /* compatibility: the two per-launch stage entries of brx_last_stage_ms */
         if (c->kstat[BRX_KERN_FIN_ALIGN1].launches) c->stage_ms[BRX_STAGE_ALIGN1] = c->kstat[BRX_KERN_FIN_ALIGN1].ms / (float)c->kstat[BRX_KERN_FIN_ALIGN1].launches;
         if (c->kstat[BRX_KERN_FIN_QSCORE].launches) c->stage_ms[BRX_STAGE_QSCORE] = c->kstat[BRX_KERN_FIN_QSCORE].ms / (float)c->kstat[BRX_KERN_FIN_QSCORE].launches;

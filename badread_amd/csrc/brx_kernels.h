@@ -919,12 +919,14 @@ __device__ inline int64_t qs_lookup(const brx_qscore_model &qm, uint64_t key) {
 #define BRX_KL_RETRY 0x10000u     /* phase 0 missed: repeat in phase 1                                   */
 #define BRX_KL_FULL 0x20000u      /* never windowed: the read holds a junk piece (low-complexity repeats, where
                                      the canonical traceback collects every indel at one end of the repeat) */
+#define BRX_KL_LANES 0x40000u     /* narrow band, ACGT only: aligned one read per lane (brx_finlanes.h, k_fin_lanes) */
+#include "brx_finlanes.h"
 
 /* One set of reads (order[q_begin..q_end)).  seq_base / ops_base: where the set's seq and ops buffers start in the
    arena; from here on RS.seq_off / RS.ops_off are offsets from the arena base (`arena`), whichever set a read is in. */
 __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end, uint32_t *queue,
                                                   uint64_t seq_base, uint64_t ops_base, const uint8_t *Fbuf, const uint32_t *repl,
-                                                  const PPiece *pieces, uint8_t *arena) {
+                                                  const PPiece *pieces, uint8_t *arena, const uint32_t *F2buf, int fin_lanes) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     for (;;) {
@@ -945,10 +947,55 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
             if (!d.raw_mode) for (uint32_t i = 0; i < s.n_pieces; ++i) junk |= (pieces[s.piece_off + i].w0 & 3u) == PC_JUNK;
             RS *o = &rs[r];
             o->seq_off = seq_base + s.seq_off; o->ops_off = ops_base + s.ops_off;
-            o->klass = (g.G ? (uint32_t)g.G : 0xFFFFu) | (junk ? BRX_KL_FULL : 0u);
+            /* a band of up to four blocks between strings of ACGT only (the read inherits every symbol outside ACGT from its
+               fragment: F2's flag word says whether there is one) is aligned one read per lane */
+            const bool lanes = fin_lanes && !junk && brx_finl_blocks(s.m, s.n, s.ub) > 0 && F2buf[(s.F_off >> 4) + ((s.n + 15u) >> 4)] == 0u;
+            o->klass = (g.G ? (uint32_t)g.G : 0xFFFFu) | (junk ? BRX_KL_FULL : 0u) | (lanes ? BRX_KL_LANES : 0u);
             o->units = brx_final_units(s.m, s.n, s.ub, junk ? 0 : d.tb_hmul, &too_wide);     /* traceback store + col_of[] */
             if (too_wide) o->status = s.status | BRX_RS_BAND;
         }
+    }
+}
+
+/* The narrow-band class of one set, 64 reads per wave: `list` holds its reads by fragment length, longest first, a GROUP is 64
+   consecutive entries; `ctr` / `slabs` as for k_fin_align below, counted in groups: slab t holds the move codes of the t-th longest
+   group and of every group the wave pops after it. */
+__global__ void __launch_bounds__(64, 4) k_fin_lanes(BrxDev d, RS *rs, const uint32_t *list, uint32_t n_list, unsigned long long *ctr,
+                                                      const uint64_t *slabs, const uint8_t *Fbuf, uint8_t *seqbuf, uint8_t *opsbuf,
+                                                      uint8_t *slab_base, uint64_t *clk) {
+    const int lane = lane_id();
+    const uint32_t n_groups = (n_list + 63u) >> 6;
+    const uint64_t first = uni((uint64_t)atomicAdd(ctr, lane == 0 ? ((1ull << 32) | 1ull) : 0ull));
+    uint32_t gi = (uint32_t)first;
+    if (gi >= n_groups) return;
+    const uint32_t ticket = (uint32_t)(first >> 32);
+    const uint64_t slab_at = slabs[ticket], tb_cap = slabs[ticket + 1] - slab_at;
+    uint2 *tb = reinterpret_cast<uint2 *>(slab_base) + slab_at;
+    for (; gi < n_groups; gi = (uint32_t)uni((uint64_t)atomicAdd(ctr, lane == 0 ? 1ull : 0ull))) {
+        const uint32_t idx = gi * 64u + (uint32_t)lane;
+        bool valid = idx < n_list;
+        const uint32_t r = valid ? list[idx] : 0u;
+        RS s;
+        if (valid) s = rs[r];
+        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        const uint32_t n = valid ? s.n : 0u, m = valid ? s.m : 0u;
+        /* the slab holds the longest read of the group (the host sized it from the same list): a group that does not fit is a bug */
+        const uint32_t blocks = wave_max_u32(valid ? (uint32_t)brx_finl_blocks(m, n, s.ub) : 0u);      /* = the Wb of brx_lanes_final */
+        const bool fits = brx_finl_units(wave_max_u32(n), blocks) <= tb_cap;
+        const uint8_t *F = Fbuf + (valid ? s.F_off : 0ull);
+        const uint8_t *seq = seqbuf + (valid ? s.seq_off : 0ull);
+        uint8_t *ops_end = opsbuf + (valid ? s.ops_off + (uint64_t)n + (uint64_t)m : 0ull);
+        uint32_t ncols = 0, nmatch = 0; bool ok = false;
+        brx_lanes_final(valid && fits, seq, (int)m, F, (int)n, valid ? (int)s.ub : 0, tb, ops_end, &ncols, &nmatch, &ok);
+        if (valid) {
+            RS *o = &rs[r];
+            o->status = s.status | (ok ? 0u : BRX_RS_BAND);
+            o->n_cols = ncols; o->n_match = nmatch;
+            uint64_t *ck = clk + (uint64_t)r * 8;
+            ck[3] = __builtin_amdgcn_s_memtime() - t_begin; ck[7] = (uint64_t)(s.klass & 0xFFFFu);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);                      /* the slab is written again by the next group */
     }
 }
 

@@ -280,7 +280,8 @@ enum { BRX_KERN_PLAN = 0,        /* k_plan_count + k_scan_plan + k_plan_fill    
        BRX_KERN_FIN_ALIGN16 = 10,/* k_fin_align<16,8,65535>: 8 or more band words per lane                  */
        BRX_KERN_FIN_QSCORE = 11,
        BRX_KERN_EMIT = 12,       /* k_recsize + k_scan_rec + k_emit + k_stats                                  */
-       BRX_KERN_COUNT = 13 };
+       BRX_KERN_FIN_LANES = 13,  /* k_fin_lanes: final alignments with a band of up to four blocks, one read per lane */
+       BRX_KERN_COUNT = 14 };
 typedef struct {
     uint32_t launches;
     float ms;                  /* sum of the launches' event durations                                          */

@@ -82,6 +82,7 @@ ROUTES = [
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
     {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0, 'BRX_WAVES_PER_CU': 2},       # lane passes; four slab-owning waves per band class reuse their slabs
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_FIN_SPREAD': 0},       # the bulk set's band classes one after the other on its own stream
+    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_FIN_LANES': 0},        # no read aligned by lane in the final stage (short nanopore reads are, by default)
     {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 0},       # pass waves never stage a read in LDS: 2-bit codes from global memory, changed test on repl[]
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 120},   # a slice of 120 words: reads up to 1.2 kb staged, longer ones beside them from global memory
 ]
@@ -208,6 +209,26 @@ def _window_overflow(tmp_path):
     return eng
 
 
+@pytest.mark.parametrize('lanes', [1, 0])
+def test_narrow_bands_one_read_per_lane(lanes, monkeypatch):
+    """BASELINE.json configs[4] in small: pacbio2021 models, identities around Q30 -- a read differs from its fragment in a few
+    dozen places, the band of its final alignment is two or three blocks, and k_fin_lanes aligns 64 such reads per wave, one per
+    lane (csrc/brx_finlanes.h), writing the ops k_fin_qscore reads.  Same bytes and statistics as the oracle, and as the wave-systolic
+    aligner (BRX_FIN_LANES=0) that k_fin_lanes takes these reads from."""
+    pref, _ = H.small_reference()
+    p = SimParams(frag_mean=1500, frag_stdev=900, identity_mode=2, id_a=30.0, id_b=3.0, id_max=1.0)
+    orc = H.configure(H.oracle_engine(), pref, 'pacbio2021', 'pacbio2021', p)
+    eng = H.configure(emu_engine(monkeypatch, BRX_FIN_LANES=lanes), pref, 'pacbio2021', 'pacbio2021', p)
+    eng.set_kernel_timing(True)                                     # per-class launch and base counts (brx_last_kernel_stats)
+    out_o, st_o = orc.simulate_batch(8, 0, 80)
+    out_h, st_h = eng.simulate_batch(8, 0, 80)
+    for f in STAT_FIELDS:
+        assert (st_h[f] == st_o[f]).all(), f
+    assert H.first_diff(out_h, out_o) < 0
+    by_lane = eng.kernel_stats()['k_fin_lanes'][2]                  # bases of the reads the class handled
+    assert (by_lane > 0.8 * float(st_h['frag_len'].sum())) if lanes else by_lane == 0
+
+
 def test_final_stage_with_fewer_slabs_than_reads(monkeypatch):
     """The traceback stores of the final stage are slabs owned by the waves of the align kernels, sized by queue position
     (brx_hip.hip, launch_final_phase).  An arena that holds the largest store but not one slab per read: the set runs with
@@ -218,7 +239,7 @@ def test_final_stage_with_fewer_slabs_than_reads(monkeypatch):
     out_o, st_o = orc.simulate_batch(8, 0, 28)
     slabs = []
     for scratch in (1 << 29, 20 << 20):
-        eng = H.configure(emu_engine(monkeypatch, scratch=scratch, BRX_TB_WINDOW=0, BRX_WIN_KB=128), pref, 'nanopore2023', 'nanopore2023', p)
+        eng = H.configure(emu_engine(monkeypatch, scratch=scratch, BRX_TB_WINDOW=0, BRX_WIN_KB=128, BRX_FIN_LANES=0), pref, 'nanopore2023', 'nanopore2023', p)
         out_h, st_h = eng.simulate_batch(8, 0, 28)
         slabs.append(eng.final_launches())
         for f in STAT_FIELDS:

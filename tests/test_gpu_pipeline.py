@@ -94,6 +94,7 @@ def test_sequence_fragments_matches_oracle():
                                  {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1', 'BRX_WIDE_STREAM': '0'},
                                  {'BRX_TAIL_READS': '16', 'BRX_LANE_THRESHOLD': '100', 'BRX_FIN_HEAD_READS': '64'},   # lane passes, then packed passes, then the tail
                                  {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_FIN_SPREAD': '0'},                              # bulk band classes on one stream
+                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_FIN_LANES': '0'},                               # no final alignment by lane
                                  {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0', 'BRX_STAGE_WORDS': '0'},    # pass waves never stage a read in LDS
                                  {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_STAGE_WORDS': '500'},   # short reads staged, long ones not
                                  {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0', 'BRX_WAVES_PER_CU': '1'}])     # 256 slab-owning waves per band class

@@ -23,6 +23,7 @@ ROUTES = [{}, {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '0'}, {'BRX_TAIL_REA
           {'BRX_TB_WINDOW': '-1'}, {'BRX_TB_WINDOW': '0'}, {'BRX_TB_WINDOW': '1'}, {'BRX_MUTATE_INLINE': '1'},
           {'BRX_TAIL_READS': '3'}, {'BRX_WAVES_PER_CU': '1'}, {'BRX_WAVES_PER_CU': '2', 'BRX_TB_WINDOW': '-1'},      # few slabs per band class
           {'BRX_LANE_WAVES': '1', 'BRX_TAIL_READS': '0', 'BRX_HEAD_READS': '0', 'BRX_LANE_THRESHOLD': '0'},
+          {'BRX_FIN_LANES': '0'}, {'BRX_TAIL_READS': '2', 'BRX_HEAD_READS': '2', 'BRX_FIN_LANES': '0'},
           {'BRX_TAIL_READS': '0', 'BRX_HEAD_READS': '0', 'BRX_STAGE_WORDS': '0'},                                   # pass waves never stage a read in LDS
           {'BRX_TAIL_READS': '2', 'BRX_HEAD_READS': '3', 'BRX_STAGE_WORDS': '60'},           # short reads staged, the others beside them
           {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '0', 'BRX_STAGE_WORDS': '2560'}]
