@@ -4,7 +4,6 @@ PAF alignments for the model builders: the reference's `Alignment` / `load_align
 100 aligned bases, identity above 80 %), same messages and exits.  CIGAR parts are kept as (length, letter) pairs,
 reversed for '-' strand alignments (alignment.py:61-64).
 """
-import collections
 import re
 import sys
 
@@ -46,25 +45,37 @@ class Alignment(object):
                 f'{self.ref_name}:{self.ref_start}-{self.ref_end}({self.percent_identity:.3f}%)')
 
 
-def load_alignments(filename, max_alignments=None, output=sys.stderr, dot_interval=1000):
-    print('Loading alignments', end='', file=output, flush=True)
-    by_read = collections.defaultdict(list)
+def _paf_records(filename, limit):
+    """Alignment objects of the first `limit` PAF lines (all of them when limit is None)."""
     with get_open_func(filename)(filename, 'rt') as paf:
-        for i, line in enumerate(paf, 1):
-            a = Alignment(line)
-            by_read[a.read_name].append(a)
-            if i % dot_interval == 0:
-                print('.', end='', file=output, flush=True)
-            if i == max_alignments:
-                break
+        for n, line in enumerate(paf):
+            if limit is not None and limit > 0 and n >= limit:
+                return
+            yield Alignment(line)
+
+
+def load_alignments(filename, max_alignments=None, output=sys.stderr, dot_interval=1000):
+    """One alignment per read -- its highest AS:i, the LAST of equals (the reference sorts a read's alignments by score and
+    takes the final one, alignment.py:89) -- in order of the reads' first appearance, filtered like alignment.py:90.  The PAF is
+    streamed: a read keeps one candidate at a time instead of the list of all its alignments."""
+    def progress(count):
+        if count % dot_interval == 0:
+            print('.', end='', file=output, flush=True)
+
+    print('Loading alignments', end='', file=output, flush=True)
+    candidate = {}                                        # read name -> best so far; dicts keep first-insertion order
+    for seen, a in enumerate(_paf_records(filename, max_alignments), 1):
+        held = candidate.get(a.read_name)
+        if held is None or a.alignment_score >= held.alignment_score:
+            candidate[a.read_name] = a
+        progress(seen)
     print('', file=output, flush=True)
     print('Choosing best alignment per read', end='', file=output, flush=True)
-    best = []
-    for alignments in by_read.values():
-        top = sorted(alignments, key=lambda x: x.alignment_score)[-1]
-        if top.num_bases > 100 and top.percent_identity > 80.0:
-            best.append(top)
-            if len(best) % dot_interval == 0:
-                print('.', end='', file=output, flush=True)
+    kept = []
+    for a in candidate.values():
+        if a.num_bases <= 100 or a.percent_identity <= 80.0:
+            continue
+        kept.append(a)
+        progress(len(kept))
     print('', file=output, flush=True)
-    return best
+    return kept
