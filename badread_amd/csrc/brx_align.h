@@ -57,6 +57,8 @@ struct BrxGeom {
     int G, R;          /* words per lane, rows per superblock (32*G)              */
     int NS, NW;        /* superblocks, 32-row words                               */
     int WSp;           /* band slots per time step in the traceback store         */
+    int WSrow, slot0;  /* slots of a whole store row and the first slot of THIS alignment in it: WSp and 0 when the store holds one
+                          alignment; brx_quad.h lays the rows of four alignments side by side (4 x WSp, row x WSp)          */
     int K;             /* time skew between neighbouring superblocks: superblock s handles column j at time j + K*s (1) */
     int U;             /* columns per loop trip of the forward pass (BRX_U1 for G = 1, else 1): the windowed store is decided per trip */
     int t_end;         /* last traceback row = T + NS - 1 (G = 1: rounded up to whole trips) */
@@ -86,7 +88,9 @@ __host__ __device__ inline uint32_t brx_isqrt(uint32_t v) {
  * nanopore2023 reads of 2-60 kb), so with H = hmul sqrt(k) + 24, hmul = 2 (BRX_TB_WINDOW; measured on configs[3]: 4 -> 2.84, 3 -> 2.92, 2 -> 2.98 Gbases/s with no miss, 1 -> 2.9 with 110 misses per 295 k reads), the traceback practically never asks
  * for a cell that was not stored (hmul < 0: H = 8, a test setting that makes most reads miss); when it does, the alignment reports failure and the caller repeats it with the full
  * store.  A traceback that succeeds read exactly the bits the full store would have held: same result. */
-__host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul = 0) {
+/* span / maxg: the band may cover `span` superblocks (56 of the 64 lanes of a wave; BRX_QUAD_SPAN of the 16 lanes of a row,
+   brx_quad.h) of at most maxg words each */
+__host__ __device__ inline BrxGeom brx_make_geom_span(int Q, int T, int k, int hmul, int span, int maxg) {
     BrxGeom g;
     g.Q = Q; g.T = T;
     int dend = Q - T;
@@ -97,8 +101,8 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul =
     g.dhi = (dend > 0 ? dend : 0) + half;
     int bw = g.dhi - g.dlo + 1;
     int G = 1;
-    while (G <= BRX_GEOM_MAXG && (long long)bw > 56ll * 32ll * G) G *= 2;
-    if (G > BRX_GEOM_MAXG) { g.G = 0; g.R = 0; g.NS = 0; g.NW = 0; g.WSp = 0; g.K = 1; g.U = 1; g.t_end = 0; return g; }
+    while (G <= maxg && (long long)bw > (long long)span * 32ll * G) G *= 2;
+    if (G > maxg) { g.G = 0; g.R = 0; g.NS = 0; g.NW = 0; g.WSp = 0; g.WSrow = 0; g.slot0 = 0; g.K = 1; g.U = 1; g.t_end = 0; g.H = BRX_H_ALL; g.slope = 0; return g; }
     g.G = G; g.R = 32 * G;
     g.NW = (Q + 31) / 32;
     g.NS = (Q + g.R - 1) / g.R;
@@ -114,8 +118,10 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul =
         const int slots = (2 * H + g.R - 1) / g.R + 1;      /* superblocks that can meet the window in one store row */
         if (slots < g.WSp) { g.WSp = slots; g.H = H; g.slope = (uint32_t)(((uint64_t)Q << 20) / (uint64_t)T); }
     }
+    g.WSrow = g.WSp; g.slot0 = 0;
     return g;
 }
+__host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul = 0) { return brx_make_geom_span(Q, T, k, hmul, 56, BRX_GEOM_MAXG); }
 
 /* Is superblock s written for the column group represented by column jrep?  (jrep = the column itself when
  * K = 1; the column in the middle of its trip otherwise: brx_jrep.)  For a fixed store row the rows
@@ -136,7 +142,7 @@ __host__ __device__ __forceinline__ int brx_jrep(const BrxGeom &g, int s, int j)
 
 /* 8-byte units of traceback storage an alignment needs */
 __host__ __device__ inline uint64_t brx_tb_units(const BrxGeom &g) {
-    return (uint64_t)(g.t_end + 1) * (uint64_t)g.WSp * (uint64_t)g.G;
+    return (uint64_t)(g.t_end + 1) * (uint64_t)g.WSrow * (uint64_t)g.G;
 }
 /* lanes holding more than BRX_REGPEQ_MAXG words read their equality masks from a table
    [5][NW] (u32) that the wave builds behind the traceback store */
@@ -431,7 +437,7 @@ __device__ inline bool brx_align_traceback(const uint8_t *__restrict__ Qs, const
                 const int s = (ci - 1) >> shiftR;
                 if (cj >= brx_jfirst(g, s) && cj <= brx_jlast(g, s) && brx_stored(g, s, brx_jrep(g, s, cj))) {
                     const int x = ((ci - 1) & (g.R - 1)) >> 5;
-                    const uint2 v = tb[((size_t)(cj + g.K * s) * (size_t)g.WSp + (size_t)(s % g.WSp)) * (size_t)g.G + (size_t)x];
+                    const uint2 v = tb[((size_t)(cj + g.K * s) * (size_t)g.WSrow + (size_t)(g.slot0 + s % g.WSp)) * (size_t)g.G + (size_t)x];
                     w_pv = v.x; w_ph = v.y; tag_word = (ci - 1) >> 5; tag_col = cj;
                 }
                 qch = Qs[ci - 1]; tch = Ts[cj - 1]; q_row = ci;

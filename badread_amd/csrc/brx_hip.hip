@@ -54,7 +54,9 @@ struct brx_ctx {
     hipEvent_t ev_fork2[2], ev_join2[2], ev_head_mut;
     hipEvent_t ev_fork3, ev_join3[2];   /* the bulk set's band classes on the head chain's streams */
     int fin_spread;                      /* BRX_FIN_SPREAD (default 1) */
+    uint32_t quad_wpc;                   /* BRX_QUAD_WAVES_PER_CU (default 4): most waves per CU of one k_fin_quad launch (four reads each) */
     int fin_lanes;                       /* BRX_FIN_LANES (default 1): narrow-band final alignments one read per lane (k_fin_lanes) */
+    int fin_quad;                        /* BRX_FIN_QUAD (default 3): final alignments four per wave (k_fin_quad); bit 0: one-word bands, bit 1: two-word bands */
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
                                     three wide classes: a stream per class measured 30 % slower, r01d) */
     hipEvent_t ev_fork, ev_join;
@@ -170,7 +172,9 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         (e = hipEventCreateWithFlags(&c->ev_join3[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_join3[1], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *v = getenv("BRX_FIN_SPREAD"); c->fin_spread = v ? atoi(v) : 1; }
+    { const char *v = getenv("BRX_QUAD_WAVES_PER_CU"); c->quad_wpc = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 4u; }
     { const char *v = getenv("BRX_FIN_LANES"); c->fin_lanes = v ? atoi(v) : 1; }
+    { const char *v = getenv("BRX_FIN_QUAD"); c->fin_quad = v ? (atoi(v) & 3) : 3; }
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 512u; }
     { const char *v = getenv("BRX_STAGE_WORDS"); c->stage_words = v ? std::min<uint32_t>((uint32_t)atoi(v), (uint32_t)BRX_STAGE_WORDS) : (uint32_t)BRX_STAGE_WORDS; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
@@ -480,20 +484,20 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         int id;                        /* 0 head, 1 bulk: selects counter slots and events */
         bool launched, wide_forked;
         size_t tb_at, tb_cap, col_bytes;   /* the set's region of the arena: col_of[] of its reads, then the slabs of its align kernels */
-        uint64_t bases_by_class[6];    /* G = 1, 2, 4, 8+, all, narrow band one read per lane */
+        uint64_t bases_by_class[8];    /* G = 1, 2, 4, 8+, all, narrow band one read per lane, four reads per wave with one / two words per lane */
     };
     /* (Round 4 also ran THREE sets -- the reads with the fewest expected changes as an EARLY set whose final stage started
        during the passes on the head chain's idle stream, every early read counting itself when its loop was done.  It overlapped
        as designed -- final stage behind the mutate stage 250 -> 205 ms -- and the passes it ran beside slowed down by as much:
        5.16-5.18 against 5.22-5.26 Gbases/s without it, six batches in flight; removed.  profiles/r04i, r04j.) */
     FinalSet sets[2];
-    sets[0] = FinalSet{0, n_head, s_head, (c->wide_stream && n_bulk) ? c->side2 : s_head, 0, false, false, 0, 0, 0, {0, 0, 0, 0, 0, 0}};
-    sets[1] = FinalSet{n_head, n_reads, st, st, 1, false, false, 0, 0, 0, {0, 0, 0, 0, 0, 0}};
+    sets[0] = FinalSet{0, n_head, s_head, (c->wide_stream && n_bulk) ? c->side2 : s_head, 0, false, false, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
+    sets[1] = FinalSet{n_head, n_reads, st, st, 1, false, false, 0, 0, 0, {0, 0, 0, 0, 0, 0, 0, 0}};
     uint64_t *set_tboff = tboff_sorted;       /* staging array of the col_of[] offsets, indexed by order position */
     uint64_t *fin_slabs = units_sorted;        /* slab offset tables of the sets' align kernels (n_reads + 16 words) */
     std::vector<uint64_t> h_tboff(n_reads);
     /* counters: [0],[3] join queues of head / bulk; [1] flags; [2],[4] window misses of head / bulk;
-       [16 + 16 x (set x 2 + phase)] final-stage queue heads (four 64-bit class counters, two qscore counters) */
+       [16 + 32 x (set x 2 + phase)] final-stage queue heads (64-bit class counters, qscore counters) */
     auto set_counter = [&](const FinalSet &S, int which) -> uint32_t * { return counters + (which == 0 ? (S.id ? 3 : 0) : (S.id ? 4 : 2)); };
     bool legacy_handled = false;       /* the whole-read fallback already ran for every read (no separate mutate head chain) */
     uint64_t tail_bases = 0;           /* kernel statistics: bases of the bulk reads that finished in the in-place tail */
@@ -512,8 +516,10 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
      * col_of[] (k_fin_qscore: 4 bytes per read base) stays per read, in front of the slabs. */
     auto launch_final_phase = [&](FinalSet &S, int phase) -> int {
         const uint32_t ns = S.e - S.b;
-        std::vector<uint32_t> cls_list[5];          /* [4]: the narrow-band class (k_fin_lanes), its units are per GROUP of 64 reads */
-        std::vector<uint64_t> cls_units[5];
+        constexpr int NCLS = 7;                     /* [4]: the narrow-band class (k_fin_lanes), its units are per GROUP of 64 reads; [5], [6]: four
+                                                       reads per wave with one / two words per lane (k_fin_quad), units per GROUP of 4 */
+        std::vector<uint32_t> cls_list[NCLS];
+        std::vector<uint64_t> cls_units[NCLS];
         uint64_t col_total = 0;
         for (uint32_t i = S.b; i < S.e; ++i) {
             const RS &r = h_rs[h_order[i]];
@@ -531,6 +537,13 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 cls_units[4].push_back(((uint64_t)r.n << 8) | (uint64_t)brx_finl_blocks(r.m, r.n, r.ub));     /* sorted by fragment length below; units per group follow */
                 continue;
             }
+            if ((r.klass & BRX_KL_QUAD) && phase == 0) {     /* a miss is repeated by k_fin_align (k_fin_quad clears the flag) */
+                const BrxGeom gq = brx_make_geom_quad((int)r.m, (int)r.n, (int)r.ub, (r.klass & BRX_KL_FULL) ? 0 : c->tb_hmul);
+                const int kq = gq.G == 2 ? 6 : 5;
+                cls_list[kq].push_back(h_order[i]);
+                cls_units[kq].push_back(brx_align_units(gq));       /* sorted by the read's own store below; units per group follow */
+                continue;
+            }
             const int k = kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3;
             cls_list[k].push_back(h_order[i]);
             cls_units[k].push_back((u + 31) & ~31ull);
@@ -540,12 +553,13 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
            store grows with length x band width, and so does the work: the order is also longest-processing-time first), so the
            suffix maximum at position t is the t-th largest store and W waves hold the W largest stores of the class. */
         const uint32_t wpc = (uint32_t)c->waves_per_cu;
-        const uint32_t limit[5] = {(uint32_t)c->n_cu * std::max(wpc / 2u, 1u), (uint32_t)c->n_cu * std::max(wpc / 4u, 1u),
-                                   (uint32_t)c->n_cu * std::max(wpc / 8u, 1u), (uint32_t)c->n_cu * std::max(wpc / 16u, 1u),
-                                   (uint32_t)c->n_cu * std::max(wpc / 4u, 1u)};
-        uint32_t grid[5];
-        std::vector<uint64_t> sufmax[5];
-        for (int k = 0; k < 5; ++k) {
+        const uint32_t limit[NCLS] = {(uint32_t)c->n_cu * std::max(wpc / 2u, 1u), (uint32_t)c->n_cu * std::max(wpc / 4u, 1u),
+                                      (uint32_t)c->n_cu * std::max(wpc / 8u, 1u), (uint32_t)c->n_cu * std::max(wpc / 16u, 1u),
+                                      (uint32_t)c->n_cu * std::max(wpc / 4u, 1u), (uint32_t)c->n_cu * std::max(c->quad_wpc, 1u),
+                                      (uint32_t)c->n_cu * std::max(c->quad_wpc, 1u)};
+        uint32_t grid[NCLS];
+        std::vector<uint64_t> sufmax[NCLS];
+        for (int k = 0; k < NCLS; ++k) {
             {
                 std::vector<uint32_t> idx(cls_list[k].size());
                 for (size_t x = 0; x < idx.size(); ++x) idx[x] = (uint32_t)x;
@@ -564,13 +578,26 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 }
                 cls_units[4].swap(gu);
             }
+            if (k >= 5) {                             /* groups of four reads: rows for the longest of them, slots for the widest window */
+                const size_t ng = (cls_list[k].size() + 3) / 4;
+                std::vector<uint64_t> gu(ng);
+                for (size_t gidx = 0; gidx < ng; ++gidx) {
+                    BrxGeom g4[4]; int n4 = 0;
+                    for (size_t x = gidx * 4; x < std::min(cls_list[k].size(), gidx * 4 + 4); ++x) {
+                        const RS &q = h_rs[cls_list[k][x]];
+                        g4[n4++] = brx_make_geom_quad((int)q.m, (int)q.n, (int)q.ub, (q.klass & BRX_KL_FULL) ? 0 : c->tb_hmul);
+                    }
+                    gu[gidx] = (brx_quad_units(g4, n4) + 31) & ~31ull;
+                }
+                cls_units[k].swap(gu);
+            }
             const size_t n = cls_units[k].size();      /* entries the class's waves pop: reads, or groups of reads */
             sufmax[k].assign(n + 1, 0);
             for (size_t x = n; x-- > 0;) sufmax[k][x] = std::max(sufmax[k][x + 1], cls_units[k][x]);
             grid[k] = (uint32_t)std::min<size_t>(n, limit[k]);
         }
         auto slab_units = [&](int k) { uint64_t t = 0; for (uint32_t w = 0; w < grid[k]; ++w) t += sufmax[k][w]; return t; };
-        auto need = [&]() { uint64_t t = (phase == 0 ? col_total : 0) + 512; for (int k = 0; k < 5; ++k) t += slab_units(k); return t * 8; };
+        auto need = [&]() { uint64_t t = (phase == 0 ? col_total : 0) + 512; for (int k = 0; k < NCLS; ++k) t += slab_units(k); return t * 8; };
         size_t at = (A.used + 255) & ~(size_t)255;
         size_t left = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
         if (phase == 0) {
@@ -590,13 +617,13 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         } else if (S.tb_cap > left) { at = S.tb_at + S.col_bytes; left = S.tb_cap - S.col_bytes; }      /* the set's own slab area is free again */
         for (int guard = 0; need() > left && guard < 96; ++guard) {
             int big = -1;
-            for (int k = 0; k < 5; ++k) if (grid[k] > 1 && (big < 0 || slab_units(k) > slab_units(big))) big = k;
+            for (int k = 0; k < NCLS; ++k) if (grid[k] > 1 && (big < 0 || slab_units(k) > slab_units(big))) big = k;
             if (big < 0) break;
             grid[big] = (grid[big] + 1) / 2;
         }
-        DBG("final set %d phase %d: %u reads, classes %zu/%zu/%zu/%zu + %zu by lane, slabs %u/%u/%u/%u + %u, need %.2f GB, left %.2f GB, arena used %.2f GB", S.id, phase, ns,
-            cls_list[0].size(), cls_list[1].size(), cls_list[2].size(), cls_list[3].size(), cls_list[4].size(), grid[0], grid[1], grid[2], grid[3], grid[4],
-            (double)need() / 1e9, (double)left / 1e9, (double)A.used / 1e9);
+        DBG("final set %d phase %d: %u reads, classes %zu/%zu/%zu/%zu + %zu by lane + %zu/%zu four per wave, slabs %u/%u/%u/%u + %u + %u/%u, need %.2f GB, left %.2f GB, arena used %.2f GB", S.id, phase, ns,
+            cls_list[0].size(), cls_list[1].size(), cls_list[2].size(), cls_list[3].size(), cls_list[4].size(), cls_list[5].size(), cls_list[6].size(),
+            grid[0], grid[1], grid[2], grid[3], grid[4], grid[5], grid[6], (double)need() / 1e9, (double)left / 1e9, (double)A.used / 1e9);
         if (need() > left) return scratch_short(c, c->scratch_bytes + (size_t)(need() - left) + ((size_t)1 << 28));
         uint8_t *region = c->scratch + at;
         if (phase == 0) { S.tb_at = at; S.tb_cap = (size_t)need(); S.col_bytes = (size_t)col_total * 8; (void)A.take(S.tb_cap); }
@@ -606,15 +633,15 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         /* device tables, in the set's share [S.b, S.e) of the staging arrays: read lists (u32) and slab offsets (u64, in units) */
         std::vector<uint32_t> h_lists; h_lists.reserve(ns + 8);
         std::vector<uint64_t> h_slabs; h_slabs.reserve(ns + 16);
-        uint32_t list_at[5], slab_at[5];
+        uint32_t list_at[NCLS], slab_at[NCLS];
         uint64_t run = 0;
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < NCLS; ++k) {
             list_at[k] = (uint32_t)h_lists.size(); slab_at[k] = (uint32_t)h_slabs.size();
             h_lists.insert(h_lists.end(), cls_list[k].begin(), cls_list[k].end());
             for (uint32_t w = 0; w < grid[k]; ++w) { h_slabs.push_back(run); run += sufmax[k][w]; }
             h_slabs.push_back(run);                                 /* end of the class's last slab */
         }
-        if (h_slabs.size() > (size_t)ns + 8) return fail(c, BRX_E_INTERNAL, "final stage: slab table larger than its staging area");
+        if (h_slabs.size() > (size_t)ns + 8 || h_lists.size() > (size_t)ns) return fail(c, BRX_E_INTERNAL, "final stage: slab table larger than its staging area");
         uint32_t *d_lists = fin_lists + S.b;
         uint64_t *d_slabs = fin_slabs + S.b + 8 * (size_t)S.id;
         if (!h_lists.empty()) HIPCHK(c, hipMemcpyAsync(d_lists, h_lists.data(), h_lists.size() * 4, hipMemcpyHostToDevice, S.st));
@@ -626,10 +653,10 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         { int rcw_ = wait_stream(c, S.st, "final stage tables"); if (rcw_) return rcw_; }     /* the host vectors above go out of scope */
         const uint32_t b = S.b, e = S.e;
         const uint32_t waves = std::min<uint64_t>(e - b, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
-        uint32_t *cq = counters + 16 + 16 * (((size_t)S.id * 2 + (size_t)phase));      /* queue heads of this set and phase: [0..7] four 64-bit class counters, [8], [9] qscore */
+        uint32_t *cq = counters + 16 + 32 * (((size_t)S.id * 2 + (size_t)phase));      /* queue heads of this set and phase: [0..7] four 64-bit class counters, [8]..[11], [14] qscore, [12] by lane, [16], [18] four per wave, [20], [21] their qscore */
         uint32_t *misses = set_counter(S, 1);
-        const uint32_t cnt[5] = {(uint32_t)cls_list[0].size(), (uint32_t)cls_list[1].size(), (uint32_t)cls_list[2].size(), (uint32_t)cls_list[3].size(),
-                                 (uint32_t)cls_list[4].size()};
+        const uint32_t cnt[NCLS] = {(uint32_t)cls_list[0].size(), (uint32_t)cls_list[1].size(), (uint32_t)cls_list[2].size(), (uint32_t)cls_list[3].size(),
+                                    (uint32_t)cls_list[4].size(), (uint32_t)cls_list[5].size(), (uint32_t)cls_list[6].size()};
         /* The widest bands (8+ words per lane: a few dozen reads, each a chain of ~100 k column steps of ~2 us) go first, on
            the set's wide stream when it has one; then the 4-, 2- and 1-word classes on the set's own stream, each scored
            (k_fin_qscore) as soon as its class is aligned. */
@@ -672,11 +699,23 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                                  reinterpret_cast<unsigned long long *>(cq + 2), d_slabs + slab_at[1], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk); }
             score_class(1, cls_stream[1], cq + 10);
         }
+        if (cnt[6]) {                                 /* bands of 14-26 superblocks of 32 rows, as two-word superblocks four reads per wave */
+            { KTIMED(BRX_KERN_FIN_QUAD2, cls_stream[1]);
+              hipLaunchKernelGGL((k_fin_quad<2>), dim3(grid[6]), dim3(64), 0, cls_stream[1], dev, rs, d_lists + list_at[6], cnt[6],
+                                 reinterpret_cast<unsigned long long *>(cq + 18), d_slabs + slab_at[6], misses, Fbuf, c->scratch, c->scratch, slab_base, clk); }
+            score_class(6, cls_stream[1], cq + 21);
+        }
         if (cnt[4]) {                                 /* the narrow-band class, one read per lane: with pacbio2021 / --identity 30,3 nearly every read */
             { KTIMED(BRX_KERN_FIN_LANES, cls_stream[0]);
               hipLaunchKernelGGL(k_fin_lanes, dim3(grid[4]), dim3(64), 0, cls_stream[0], dev, rs, d_lists + list_at[4], cnt[4],
                                  reinterpret_cast<unsigned long long *>(cq + 12), d_slabs + slab_at[4], Fbuf, c->scratch, c->scratch, slab_base, clk); }
             score_class(4, cls_stream[0], cq + 14);
+        }
+        if (cnt[5]) {                                 /* bands of up to 13 superblocks, four reads per wave */
+            { KTIMED(BRX_KERN_FIN_QUAD1, cls_stream[0]);
+              hipLaunchKernelGGL((k_fin_quad<1>), dim3(grid[5]), dim3(64), 0, cls_stream[0], dev, rs, d_lists + list_at[5], cnt[5],
+                                 reinterpret_cast<unsigned long long *>(cq + 16), d_slabs + slab_at[5], misses, Fbuf, c->scratch, c->scratch, slab_base, clk); }
+            score_class(5, cls_stream[0], cq + 20);
         }
         if (cnt[0]) {
             { KTIMED(BRX_KERN_FIN_ALIGN1, cls_stream[0]);
@@ -696,7 +735,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
                                cq + 9, phase, 5, 0xFFFF, c->scratch, c->scratch, col_base, clk);
         }
-        if (phase == 0) c->final_launches += grid[0] + grid[1] + grid[2] + grid[3] + grid[4];     /* slabs = waves of the set's align kernels */
+        if (phase == 0) c->final_launches += grid[0] + grid[1] + grid[2] + grid[3] + grid[4] + grid[5] + grid[6];     /* slabs = waves of the set's align kernels */
         return BRX_OK;
     };
 
@@ -741,7 +780,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             KTIMED(BRX_KERN_FIN_JOIN, S.st);
             hipLaunchKernelGGL(k_fin_join, dim3(std::min<uint64_t>(ns, (uint64_t)c->n_cu * 16u)), dim3(64), 0, S.st, dev, rs, order, S.b, S.e,
                                set_counter(S, 0), (uint64_t)(seqbuf - c->scratch), (uint64_t)(opsbuf - c->scratch), Fbuf, repl, pieces, c->scratch,
-                               F2buf, c->fin_lanes);
+                               F2buf, c->fin_lanes, c->fin_quad);
         }
         HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, S.st));
         { int rcw = wait_stream(c, S.st, "k_fin_join"); if (rcw) return rcw; }
@@ -749,7 +788,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             const RS &r = h_rs[h_order[i]];
             if (!r.n) continue;
             const uint32_t kl = r.klass & 0xFFFFu;
-            S.bases_by_class[(r.klass & BRX_KL_LANES) ? 5 : kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3] += r.n;
+            S.bases_by_class[(r.klass & BRX_KL_LANES) ? 5 : (r.klass & BRX_KL_QUAD) ? (brx_quad_words(r.m, r.n, r.ub) == 2 ? 7 : 6) : kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3] += r.n;
             S.bases_by_class[4] += r.n;
         }
         return launch_final_phase(S, 0);
@@ -969,6 +1008,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         c->kstat[BRX_KERN_FIN_ALIGN1].bases = by_class[0]; c->kstat[BRX_KERN_FIN_ALIGN2].bases = by_class[1];
         c->kstat[BRX_KERN_FIN_ALIGN4].bases = by_class[2]; c->kstat[BRX_KERN_FIN_ALIGN16].bases = by_class[3];
         c->kstat[BRX_KERN_FIN_LANES].bases = (double)(sets[0].bases_by_class[5] + sets[1].bases_by_class[5]);
+        c->kstat[BRX_KERN_FIN_QUAD1].bases = (double)(sets[0].bases_by_class[6] + sets[1].bases_by_class[6]);
+        c->kstat[BRX_KERN_FIN_QUAD2].bases = (double)(sets[0].bases_by_class[7] + sets[1].bases_by_class[7]);
         /* compatibility: the two per-launch stage entries of brx_last_stage_ms */
         if (c->kstat[BRX_KERN_FIN_ALIGN1].launches) c->stage_ms[BRX_STAGE_ALIGN1] = c->kstat[BRX_KERN_FIN_ALIGN1].ms / (float)c->kstat[BRX_KERN_FIN_ALIGN1].launches;
         if (c->kstat[BRX_KERN_FIN_QSCORE].launches) c->stage_ms[BRX_STAGE_QSCORE] = c->kstat[BRX_KERN_FIN_QSCORE].ms / (float)c->kstat[BRX_KERN_FIN_QSCORE].launches;

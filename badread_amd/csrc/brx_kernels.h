@@ -920,13 +920,15 @@ __device__ inline int64_t qs_lookup(const brx_qscore_model &qm, uint64_t key) {
 #define BRX_KL_FULL 0x20000u      /* never windowed: the read holds a junk piece (low-complexity repeats, where
                                      the canonical traceback collects every indel at one end of the repeat) */
 #define BRX_KL_LANES 0x40000u     /* narrow band, ACGT only: aligned one read per lane (brx_finlanes.h, k_fin_lanes) */
+#define BRX_KL_QUAD 0x80000u      /* band of up to 13 superblocks of one or two words, ACGT only: four reads per wave (brx_quad.h, k_fin_quad) */
 #include "brx_finlanes.h"
+#include "brx_quad.h"
 
 /* One set of reads (order[q_begin..q_end)).  seq_base / ops_base: where the set's seq and ops buffers start in the
    arena; from here on RS.seq_off / RS.ops_off are offsets from the arena base (`arena`), whichever set a read is in. */
 __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_t *order, uint32_t q_begin, uint32_t q_end, uint32_t *queue,
                                                   uint64_t seq_base, uint64_t ops_base, const uint8_t *Fbuf, const uint32_t *repl,
-                                                  const PPiece *pieces, uint8_t *arena, const uint32_t *F2buf, int fin_lanes) {
+                                                  const PPiece *pieces, uint8_t *arena, const uint32_t *F2buf, int fin_lanes, int fin_quad) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     for (;;) {
@@ -949,8 +951,11 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
             o->seq_off = seq_base + s.seq_off; o->ops_off = ops_base + s.ops_off;
             /* a band of up to four blocks between strings of ACGT only (the read inherits every symbol outside ACGT from its
                fragment: F2's flag word says whether there is one) is aligned one read per lane */
-            const bool lanes = fin_lanes && !junk && brx_finl_blocks(s.m, s.n, s.ub) > 0 && F2buf[(s.F_off >> 4) + ((s.n + 15u) >> 4)] == 0u;
-            o->klass = (g.G ? (uint32_t)g.G : 0xFFFFu) | (junk ? BRX_KL_FULL : 0u) | (lanes ? BRX_KL_LANES : 0u);
+            const bool acgt = F2buf[(s.F_off >> 4) + ((s.n + 15u) >> 4)] == 0u;
+            const bool lanes = fin_lanes && !junk && acgt && brx_finl_blocks(s.m, s.n, s.ub) > 0;
+            /* ... and a band of up to 13 superblocks of one or two words four reads per wave, a row of 16 lanes each */
+            const bool quad = fin_quad && !lanes && acgt && g.G == 1 && (brx_quad_words(s.m, s.n, s.ub) & fin_quad) != 0;
+            o->klass = (g.G ? (uint32_t)g.G : 0xFFFFu) | (junk ? BRX_KL_FULL : 0u) | (lanes ? BRX_KL_LANES : 0u) | (quad ? BRX_KL_QUAD : 0u);
             o->units = brx_final_units(s.m, s.n, s.ub, junk ? 0 : d.tb_hmul, &too_wide);     /* traceback store + col_of[] */
             if (too_wide) o->status = s.status | BRX_RS_BAND;
         }
@@ -993,6 +998,55 @@ __global__ void __launch_bounds__(64, 4) k_fin_lanes(BrxDev d, RS *rs, const uin
             o->n_cols = ncols; o->n_match = nmatch;
             uint64_t *ck = clk + (uint64_t)r * 8;
             ck[3] = __builtin_amdgcn_s_memtime() - t_begin; ck[7] = (uint64_t)(s.klass & 0xFFFFu);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);                      /* the slab is written again by the next group */
+    }
+}
+
+/* The reads of one set whose band takes at most 13 superblocks of G words, FOUR per wave (brx_quad.h): `list` holds them by
+   store size, largest first, a GROUP is four consecutive entries -- one per row of 16 lanes --; `ctr` / `slabs` as for k_fin_align
+   below, counted in groups.  A read whose traceback leaves the stored window (or whose group does not fit its slab: a bug) is
+   repeated by k_fin_align in the second phase, with the full store. */
+template <int G>
+__global__ void __launch_bounds__(64, 4) k_fin_quad(BrxDev d, RS *rs, const uint32_t *list, uint32_t n_list, unsigned long long *ctr,
+                                                     const uint64_t *slabs, uint32_t *retries, const uint8_t *Fbuf, uint8_t *seqbuf,
+                                                     uint8_t *opsbuf, uint8_t *slab_base, uint64_t *clk) {
+    const int lane = lane_id();
+    const int row = lane >> 4;
+    const uint32_t n_groups = (n_list + 3u) >> 2;
+    const uint64_t first = uni((uint64_t)atomicAdd(ctr, lane == 0 ? ((1ull << 32) | 1ull) : 0ull));
+    uint32_t gi = (uint32_t)first;
+    if (gi >= n_groups) return;
+    const uint32_t ticket = (uint32_t)(first >> 32);
+    const uint64_t slab_at = slabs[ticket], tb_cap = slabs[ticket + 1] - slab_at;
+    uint2 *tb = reinterpret_cast<uint2 *>(slab_base) + slab_at;
+    for (; gi < n_groups; gi = (uint32_t)uni((uint64_t)atomicAdd(ctr, lane == 0 ? 1ull : 0ull))) {
+        const uint32_t idx = gi * 4u + (uint32_t)row;
+        const bool valid = idx < n_list;
+        const uint32_t r = valid ? list[idx] : 0u;
+        RS s;
+        if (valid) s = rs[r];
+        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        const uint32_t n = valid ? s.n : 0u, m = valid ? s.m : 0u;
+        const uint8_t *F = Fbuf + (valid ? s.F_off : 0ull);
+        const uint8_t *seq = seqbuf + (valid ? s.seq_off : 0ull);
+        uint8_t *ops_end = opsbuf + (valid ? s.ops_off + (uint64_t)n + (uint64_t)m : 0ull);
+        int ncols = 0, nmatch = 0, st = 1;
+        brx_quad_align<G>(valid && m > 0 && n > 0, seq, (int)m, F, (int)n, valid ? (int)s.ub : 0,
+                          (valid && !(s.klass & BRX_KL_FULL)) ? d.tb_hmul : 0, tb, tb_cap, ops_end, &ncols, &nmatch, &st);
+        if (valid && (lane & 15) == 0) {
+            RS *o = &rs[r];
+            if (st != 0) {                                      /* window miss: k_fin_align repeats the read with the full store */
+                o->klass = (s.klass & ~BRX_KL_QUAD) | BRX_KL_RETRY;
+                atomicAdd(retries, 1u);
+                clk[(uint64_t)r * 8 + 2] = 1;
+            } else {
+                o->status = s.status;
+                o->n_cols = (uint32_t)ncols; o->n_match = (uint32_t)nmatch;
+            }
+            uint64_t *ck = clk + (uint64_t)r * 8;
+            ck[3] = __builtin_amdgcn_s_memtime() - t_begin; ck[7] = (uint64_t)(s.klass & 0xFFFFu) | 0x10000u;     /* bit 16: aligned as one of four */
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);                      /* the slab is written again by the next group */

@@ -281,7 +281,9 @@ enum { BRX_KERN_PLAN = 0,        /* k_plan_count + k_scan_plan + k_plan_fill    
        BRX_KERN_FIN_QSCORE = 11,
        BRX_KERN_EMIT = 12,       /* k_recsize + k_scan_rec + k_emit + k_stats                                  */
        BRX_KERN_FIN_LANES = 13,  /* k_fin_lanes: final alignments with a band of up to four blocks, one read per lane */
-       BRX_KERN_COUNT = 14 };
+       BRX_KERN_FIN_QUAD1 = 14,  /* k_fin_quad<1>: bands of up to 13 superblocks of one word, four reads per wave      */
+       BRX_KERN_FIN_QUAD2 = 15,  /* k_fin_quad<2>: ... of two words                                                    */
+       BRX_KERN_COUNT = 16 };
 typedef struct {
     uint32_t launches;
     float ms;                  /* sum of the launches' event durations                                          */

@@ -47,6 +47,7 @@ struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned 
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 v; v.x = x; v.y = y; return v; }
 struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
 
 namespace emu {
 
@@ -255,6 +256,9 @@ inline int readfirstlane(int v) {
 /* A fence is where the kernels publish one lane's stores to the other lanes of the wave (the hardware runs the lanes in
    lockstep; here a lane runs ahead until its next cross-lane operation), so the fence is a rendezvous. */
 #define __builtin_amdgcn_fence(order, scope) ((void)emu::exchange(0))
+/* a scheduling barrier of the compiler on the hardware (LDS operations of a wave run in order); here the point where the lanes
+   that wrote LDS entries and the lanes that read them meet */
+#define __builtin_amdgcn_wave_barrier() ((void)emu::exchange(0))
 #define __builtin_amdgcn_s_memtime() (++emu::S().clock)
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(ptr, val, order, scope) (*(ptr) = (val))
