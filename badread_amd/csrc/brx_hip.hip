@@ -33,7 +33,13 @@ struct brx_ctx {
     size_t scratch_bytes;
     size_t scratch_needed, output_needed;
     uint64_t win_bytes;
-    uint64_t *h_totals;          /* pinned, 16 x u64 followed by 64 x u32 debug progress words */
+    uint64_t *h_totals;          /* pinned, 16 x u64 followed by 64 x u32 debug progress words and 16 x u32 of small read-backs */
+    uint8_t *d_totals_alias;     /* the same block as the device sees it (hipHostMallocMapped) */
+    uint8_t *h_stage, *d_stage;  /* pinned + mapped staging block of the batch: read states, orders, the final stage's tables.  Kernels copy
+                                    to and from it (k_copy_words) -- a hipMemcpyAsync of a few bytes is a blit kernel of the runtime that
+                                    waited 3.6 ms on average behind the resident waves of six batches, ~50 times per batch */
+    size_t stage_bytes;
+    int blit;                    /* BRX_BLIT=1: the runtime's copies instead (A/B) */
     uint32_t *h_prog, *d_prog;   /* host / device views of the progress words */
     hipEvent_t ev_b[BRX_STAGE_COUNT], ev_e[BRX_STAGE_COUNT];   /* begin / end of each stage on the launch stream */
     float stage_ms[BRX_STAGE_COUNT];
@@ -125,6 +131,7 @@ static void release(brx_ctx *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
     if (c->h_totals) (void)hipHostFree(c->h_totals);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     free(c);
 }
 
@@ -151,13 +158,15 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     if (c->waves_per_cu < 1) c->waves_per_cu = 1;
     const char *wb = getenv("BRX_WIN_KB");
     c->win_bytes = (uint64_t)(wb ? atoi(wb) : 512) << 10;      /* 512 KB: a 1000 x 1900 window with the whole matrix in the band (reads inside N runs: every draw changes a base) */
-    if ((e = hipHostMalloc((void **)&c->h_totals, 16 * sizeof(uint64_t) + 64 * sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess)
+    if ((e = hipHostMalloc((void **)&c->h_totals, 16 * sizeof(uint64_t) + 80 * sizeof(uint32_t), hipHostMallocMapped)) != hipSuccess)
         return create_fail(c, "hipHostMalloc", e);
     c->h_prog = (uint32_t *)(c->h_totals + 16);
-    memset(c->h_prog, 0, 64 * sizeof(uint32_t));
+    memset(c->h_prog, 0, 80 * sizeof(uint32_t));
     void *dp = nullptr;
-    if ((e = hipHostGetDevicePointer(&dp, c->h_prog, 0)) != hipSuccess) return create_fail(c, "hipHostGetDevicePointer", e);
-    c->d_prog = (uint32_t *)dp;
+    if ((e = hipHostGetDevicePointer(&dp, c->h_totals, 0)) != hipSuccess) return create_fail(c, "hipHostGetDevicePointer", e);
+    c->d_totals_alias = (uint8_t *)dp;
+    c->d_prog = (uint32_t *)(c->d_totals_alias + 16 * sizeof(uint64_t));
+    { const char *v = getenv("BRX_BLIT"); c->blit = v ? atoi(v) : 0; }
     for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
         if ((e = hipEventCreate(&c->ev_b[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
         if ((e = hipEventCreate(&c->ev_e[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
@@ -316,8 +325,49 @@ extern "C" uint32_t brx_last_mutate_passes(const brx_ctx *c) { return c ? c->mut
 extern "C" uint32_t brx_last_final_launches(const brx_ctx *c) { return c ? c->final_launches : 0; }
 extern "C" uint32_t brx_last_window_misses(const brx_ctx *c) { return c ? c->window_misses : 0; }
 
+/* Small transfers between the arena and the context's pinned blocks, as a kernel on the stream: one wave for a few words, a few
+   dozen for the read states.  (The runtime's copy is a blit kernel with its own launch geometry; VERDICT r4: 1495 dispatches,
+   10.8 % of the summed kernel time of the bench, 3.65 ms each in the six-batch mix against 15 us alone.) */
+__global__ void __launch_bounds__(64) k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (size_t)gridDim.x * 64) dst[i] = src[i];
+}
+static uint8_t *pinned_alias(brx_ctx *c, const void *h) {        /* device view of an address inside h_totals or h_stage, nullptr otherwise */
+    const uint8_t *p = (const uint8_t *)h;
+    const uint8_t *t = (const uint8_t *)c->h_totals;
+    if (p >= t && p < t + 16 * sizeof(uint64_t) + 80 * sizeof(uint32_t)) return c->d_totals_alias + (p - t);
+    if (c->h_stage && p >= c->h_stage && p < c->h_stage + c->stage_bytes) return c->d_stage + (p - c->h_stage);
+    return nullptr;
+}
+/* device -> pinned host (bytes a multiple of 4); the host reads the block after waiting for the stream */
+static int to_host(brx_ctx *c, hipStream_t st, void *h_dst, const void *d_src, size_t bytes) {
+    uint8_t *alias = c->blit ? nullptr : pinned_alias(c, h_dst);
+    if (!alias || (bytes & 3)) { HIPCHK(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st)); return BRX_OK; }
+    const size_t n = bytes / 4;
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n + 255) / 256, 128)), dim3(64), 0, st, (uint32_t *)alias, (const uint32_t *)d_src, n);
+    return BRX_OK;
+}
+/* pinned host -> device; the host block must not change until the stream has been waited for */
+static int to_device(brx_ctx *c, hipStream_t st, void *d_dst, const void *h_src, size_t bytes) {
+    uint8_t *alias = c->blit ? nullptr : pinned_alias(c, h_src);
+    if (!alias || (bytes & 3)) { HIPCHK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st)); return BRX_OK; }
+    const size_t n = bytes / 4;
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n + 255) / 256, 128)), dim3(64), 0, st, (uint32_t *)d_dst, (const uint32_t *)alias, n);
+    return BRX_OK;
+}
+/* the staging block holds at least `bytes` (grown between batches only: nothing of the context is in flight) */
+static int stage_reserve(brx_ctx *c, size_t bytes) {
+    if (c->stage_bytes >= bytes) return BRX_OK;
+    if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->d_stage = nullptr; c->stage_bytes = 0; }
+    bytes = (bytes + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+    HIPCHK(c, hipHostMalloc((void **)&c->h_stage, bytes, hipHostMallocMapped));
+    void *dp = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer(&dp, c->h_stage, 0));
+    c->d_stage = (uint8_t *)dp; c->stage_bytes = bytes;
+    return BRX_OK;
+}
+
 static int read_totals(brx_ctx *c, hipStream_t st, const uint64_t *d_totals, int n) {
-    HIPCHK(c, hipMemcpyAsync(c->h_totals, d_totals, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    { int rc_ = to_host(c, st, c->h_totals, d_totals, (size_t)n * sizeof(uint64_t)); if (rc_) return rc_; }
     return wait_stream(c, st, "pipeline stage");
 }
 
@@ -364,6 +414,11 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     const uint32_t nb64 = (n_reads + 63) / 64;
     const uint32_t n_waves = std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
 
+    /* pinned staging: read states, order, and the final stage's tables (read lists, col_of[] offsets, slab tables) of one set at a time */
+    const size_t stg_rs = 0, stg_order = stg_rs + (((size_t)n_reads * sizeof(RS) + 255) & ~(size_t)255), stg_lists = stg_order + (((size_t)n_reads * 4 + 255) & ~(size_t)255),
+                 stg_tboff = stg_lists + (((size_t)n_reads * 4 + 255) & ~(size_t)255), stg_slabs = stg_tboff + (((size_t)n_reads * 8 + 255) & ~(size_t)255),
+                 stg_aux = stg_slabs + (((size_t)n_reads + 64) * 8 + 255 & ~(size_t)255), stg_end = stg_aux + 4096;
+    { int rcs_ = stage_reserve(c, stg_end); if (rcs_) return rcs_; }
     RS *rs = (RS *)A.take((size_t)n_reads * sizeof(RS));
     uint64_t *totals = (uint64_t *)A.take(16 * sizeof(uint64_t));
     uint32_t *order = (uint32_t *)A.take((size_t)n_reads * 4);
@@ -392,10 +447,11 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         else hipLaunchKernelGGL(k_plan_count, dim3(nb64), dim3(64), 0, st, dev, rs);
         hipLaunchKernelGGL(k_scan_plan, dim3(1), dim3(64), 0, st, n_reads, rs, totals);
     }
-    uint32_t h_ovf = 0;
-    HIPCHK(c, hipMemcpyAsync(&h_ovf, counters + 5, 4, hipMemcpyDeviceToHost, st));
+    uint32_t *h_small = c->h_prog + 64;                 /* 16 pinned words for one-word read-backs */
+    { int rc_ = to_host(c, st, h_small, counters + 5, 4); if (rc_) return rc_; }
     int rc = read_totals(c, st, totals, 3);
     if (rc) return rc;
+    const uint32_t h_ovf = h_small[0];
     if (h_ovf > BRX_OVF_LISTS)       /* the sizing pass ran out of overflow lists: the fill pass could overflow OTHER reads */
         return fail(c, BRX_E_INTERNAL, "%u reads of one batch have more than %d base segments (chimera joins): only %d overflow lists",
                     h_ovf, BRX_MAX_BASE_SEGS, BRX_OVF_LISTS);
@@ -451,8 +507,9 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
      * (n_reads <= BRX_TAIL_READS) or BRX_MUTATE_INLINE=1 is all head.  (Round 1 ran the sets one after the other:
      * bulk passes, THEN the in-place tail, THEN all final kernels -- 930 ms per batch with 8 batches in flight, of
      * which 230 ms tail and 270 ms wide-band alignments during which the batch used a few dozen waves.) */
-    std::vector<uint32_t> h_order(n_reads);
-    std::vector<RS> h_rs(n_reads);
+    uint32_t *const h_order = reinterpret_cast<uint32_t *>(c->h_stage + stg_order);      /* pinned: filled by k_copy_words */
+    RS *const h_rs = reinterpret_cast<RS *>(c->h_stage + stg_rs);
+    auto fetch_rs = [&](hipStream_t s_) -> int { return to_host(c, s_, h_rs, rs, (size_t)n_reads * sizeof(RS)); };
     c->final_launches = 0;
     c->window_misses = 0;
     /* n_mh: reads the mutate HEAD chain takes (BRX_HEAD_READS, default 1024; 0 = every read goes through the passes);
@@ -471,11 +528,11 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
     } else win_head = win;
     hipStream_t s_head = n_bulk ? c->side : st;            /* an all-head batch stays on the caller's stream */
-    MutAux h_aux[2];                                       /* lives until the call returns: the copy below is waited for with the mutate counters */
+    MutAux *const h_aux = reinterpret_cast<MutAux *>(c->h_stage + stg_aux);      /* pinned; the copy below is waited for with the mutate counters */
     {
         h_aux[0] = MutAux{req_easy, req_hard, req_legacy, mctr + 3 * MC_WORDS, winbuf, clk, win, (uint64_t)c->win_bytes, counters + 1, phase};
         h_aux[1] = MutAux{req_easy, req_hard, req_legacy_head, mctr + 5 * MC_WORDS, winbuf, clk, win_head, (uint64_t)c->win_bytes, counters + 1, phase};
-        HIPCHK(c, hipMemcpyAsync(aux_dev, h_aux, sizeof(h_aux), hipMemcpyHostToDevice, st));
+        { int rc_ = to_device(c, st, aux_dev, h_aux, 2 * sizeof(MutAux)); if (rc_) return rc_; }
     }
 
     struct FinalSet {
@@ -644,10 +701,16 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         if (h_slabs.size() > (size_t)ns + 8 || h_lists.size() > (size_t)ns) return fail(c, BRX_E_INTERNAL, "final stage: slab table larger than its staging area");
         uint32_t *d_lists = fin_lists + S.b;
         uint64_t *d_slabs = fin_slabs + S.b + 8 * (size_t)S.id;
-        if (!h_lists.empty()) HIPCHK(c, hipMemcpyAsync(d_lists, h_lists.data(), h_lists.size() * 4, hipMemcpyHostToDevice, S.st));
-        HIPCHK(c, hipMemcpyAsync(d_slabs, h_slabs.data(), h_slabs.size() * 8, hipMemcpyHostToDevice, S.st));
+        /* through the pinned staging block (one set at a time: the wait below ends before the next set's tables are written) */
+        if (!h_lists.empty()) {
+            memcpy(c->h_stage + stg_lists, h_lists.data(), h_lists.size() * 4);
+            int rc_ = to_device(c, S.st, d_lists, c->h_stage + stg_lists, h_lists.size() * 4); if (rc_) return rc_;
+        }
+        memcpy(c->h_stage + stg_slabs, h_slabs.data(), h_slabs.size() * 8);
+        { int rc_ = to_device(c, S.st, d_slabs, c->h_stage + stg_slabs, h_slabs.size() * 8); if (rc_) return rc_; }
         if (phase == 0) {
-            HIPCHK(c, hipMemcpyAsync(set_tboff + S.b, h_tboff.data() + S.b, (size_t)ns * 8, hipMemcpyHostToDevice, S.st));
+            memcpy(c->h_stage + stg_tboff, h_tboff.data() + S.b, (size_t)ns * 8);
+            { int rc_ = to_device(c, S.st, set_tboff + S.b, c->h_stage + stg_tboff, (size_t)ns * 8); if (rc_) return rc_; }
             hipLaunchKernelGGL(k_set_tboff, dim3((ns + 63) / 64), dim3(64), 0, S.st, ns, rs, order + S.b, set_tboff + S.b, (uint64_t *)nullptr);
         }
         { int rcw_ = wait_stream(c, S.st, "final stage tables"); if (rcw_) return rcw_; }     /* the host vectors above go out of scope */
@@ -747,8 +810,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         uint32_t *legacy = mctr + (S.id ? 3 : 5) * MC_WORDS;                       /* [0] count, [1] queue */
         const int tot_dev = S.id ? 3 : 8, tot_host = S.id ? 3 : 6;                 /* two words of `totals` (k_scan_mut) and of the pinned h_totals per set */
-        HIPCHK(c, hipMemcpyAsync(h_ctr, legacy, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, S.st));
-        HIPCHK(c, hipMemcpyAsync(h_ctr + 2, counters + 1, 4, hipMemcpyDeviceToHost, S.st));
+        { int rc_ = to_host(c, S.st, h_ctr, legacy, 2 * sizeof(uint32_t)); if (rc_) return rc_; }
+        { int rc_ = to_host(c, S.st, h_ctr + 2, counters + 1, 4); if (rc_) return rc_; }
         { int rcw = wait_stream(c, S.st, S.id ? "mutate stage (bulk)" : "mutate stage (head)"); if (rcw) return rcw; }
         if (h_ctr[2] & 1u) {                              /* an in-loop alignment did not fit its window scratch */
             uint32_t w4[4] = {0, 0, 0, 0};
@@ -765,8 +828,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                                S.id ? req_legacy : req_legacy_head, legacy, legacy + 1, Fbuf, repl, S.id ? win : win_head,
                                (uint64_t)c->win_bytes, counters + 1, clk);
         hipLaunchKernelGGL(k_scan_mut, dim3(1), dim3(64), 0, S.st, ns, rs, order + S.b, totals + tot_dev);
-        HIPCHK(c, hipMemcpyAsync(c->h_totals + tot_host, totals + tot_dev, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, S.st));
-        HIPCHK(c, hipMemcpyAsync(h_ctr + 2, counters + 1, 4, hipMemcpyDeviceToHost, S.st));
+        { int rc_ = to_host(c, S.st, c->h_totals + tot_host, totals + tot_dev, 2 * sizeof(uint64_t)); if (rc_) return rc_; }
+        { int rc_ = to_host(c, S.st, h_ctr + 2, counters + 1, 4); if (rc_) return rc_; }
         { int rcw = wait_stream(c, S.st, "k_scan_mut"); if (rcw) return rcw; }
         if (h_ctr[2] & 1u) {                              /* ... nor did an alignment of the whole-read kernel */
             c->win_bytes *= 4;
@@ -782,7 +845,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                                set_counter(S, 0), (uint64_t)(seqbuf - c->scratch), (uint64_t)(opsbuf - c->scratch), Fbuf, repl, pieces, c->scratch,
                                F2buf, c->fin_lanes, c->fin_quad);
         }
-        HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, S.st));
+        { int rc_ = fetch_rs(S.st); if (rc_) return rc_; }
         { int rcw = wait_stream(c, S.st, "k_fin_join"); if (rcw) return rcw; }
         for (uint32_t i = S.b; i < S.e; ++i) {
             const RS &r = h_rs[h_order[i]];
@@ -798,19 +861,19 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     auto finish_final = [&](FinalSet &S) -> int {
         if (S.e == S.b) return BRX_OK;
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);
-        HIPCHK(c, hipMemcpyAsync(h_ctr, set_counter(S, 1), 4, hipMemcpyDeviceToHost, S.st));
+        { int rc_ = to_host(c, S.st, h_ctr, set_counter(S, 1), 4); if (rc_) return rc_; }
         { int rcw = wait_stream(c, S.st, S.id ? "final stage (bulk)" : "final stage (head)"); if (rcw) return rcw; }
         const uint32_t misses = h_ctr[0];
         c->window_misses += misses;
         if (!misses) return BRX_OK;
-        HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, S.st));
+        { int rc_ = fetch_rs(S.st); if (rc_) return rc_; }
         { int rcw_ = wait_stream(c, S.st, "final stage, misses"); if (rcw_) return rcw_; }
         int rcp = launch_final_phase(S, 1);
         if (rcp) return rcp;
         return wait_stream(c, S.st, "final stage, second phase");
     };
 
-    HIPCHK(c, hipMemcpyAsync(h_order.data(), order, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    { int rc_ = to_host(c, st, h_order, order, (size_t)n_reads * 4); if (rc_) return rc_; }
     HIPCHK(c, hipMemsetAsync(msv, 0, (size_t)n_reads * sizeof(MS), st));
     HIPCHK(c, hipMemsetAsync(mctr, 0, 8 * MC_WORDS * sizeof(uint32_t), st));
     HIPCHK(c, hipMemsetAsync(lane_cls, 0, 2 * MC_WORDS * sizeof(uint32_t), st));
@@ -819,8 +882,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         memset(h_ctr, 0, 2 * MC_WORDS * sizeof(uint32_t));
         h_ctr[MC_OUT] = n_mb;                      /* block 2: "previous pass" of the first bulk pass */
         h_ctr[MC_WORDS + MC_OUT] = n_mh;           /* block 4 (copied below): the head launch's input count */
-        HIPCHK(c, hipMemcpyAsync(mctr + 2 * MC_WORDS, h_ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(mctr + 4 * MC_WORDS, h_ctr + MC_WORDS, MC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        { int rc_ = to_device(c, st, mctr + 2 * MC_WORDS, h_ctr, MC_WORDS * sizeof(uint32_t)); if (rc_) return rc_; }
+        { int rc_ = to_device(c, st, mctr + 4 * MC_WORDS, h_ctr + MC_WORDS, MC_WORDS * sizeof(uint32_t)); if (rc_) return rc_; }
         { int rcw_ = wait_stream(c, st, "mutate counters"); if (rcw_) return rcw_; }
     }
     const uint32_t lane_threshold = c->lane_threshold;   /* fewer active reads than this: one wave per window (lower latency) */
@@ -859,7 +922,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         uint32_t n_up = n_mb, pass = 0;
         const uint32_t tail_reads = tail_eff;   /* this few reads left: run them to completion in place (no host round trips) */
         auto read_counts = [&](uint32_t *ctr) -> int {
-            HIPCHK(c, hipMemcpyAsync(h_ctr, ctr, MC_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            { int rc_ = to_host(c, st, h_ctr, ctr, MC_WORDS * sizeof(uint32_t)); if (rc_) return rc_; }
             return wait_stream(c, st, "mutate pass");
         };
         auto poll_head = [&]() -> int {      /* the head set's final stage starts as soon as its reads are mutated */
@@ -875,7 +938,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 if (c->ktiming) {
                     std::vector<uint32_t> h_act(n_up);
                     HIPCHK(c, hipMemcpyAsync(h_act.data(), act_in, (size_t)n_up * 4, hipMemcpyDeviceToHost, st));
-                    HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, st));
+                    { int rc_ = fetch_rs(st); if (rc_) return rc_; }
                     HIPCHK(c, hipStreamSynchronize(st));
                     for (uint32_t x : h_act) if (x < n_reads) tail_bases += h_rs[x].n;
                 }
@@ -934,7 +997,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
            final sets, and the head set's side stream waits for the whole mutate stage */
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;
-        HIPCHK(c, hipMemcpyAsync(h_ctr, legacy_ctr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        { int rc_ = to_host(c, st, h_ctr, legacy_ctr, 2 * sizeof(uint32_t)); if (rc_) return rc_; }
         { int rcw = wait_stream(c, st, "mutate stage"); if (rcw) return rcw; }
         if (h_ctr[0] > 0)
             hipLaunchKernelGGL(k_mutate, dim3(std::min(side_waves, h_ctr[0])), dim3(64), 0, st, dev, rs, req_legacy, legacy_ctr,
@@ -1017,7 +1080,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     if (out_bytes) *out_bytes = (size_t)rec_bytes;
     /* a read that exhausted its 1000 tries is fatal in the reference (simulate.py:164) */
     if (!raw) {
-        HIPCHK(c, hipMemcpyAsync(h_rs.data(), rs, (size_t)n_reads * sizeof(RS), hipMemcpyDeviceToHost, st));
+        { int rc_ = fetch_rs(st); if (rc_) return rc_; }
         { int rcw_ = wait_stream(c, st, "read status"); if (rcw_) return rcw_; }
         for (uint32_t i = 0; i < n_reads; ++i) if (h_rs[i].status & BRX_RS_NOFRAG) {
             snprintf(c->err, sizeof(c->err), "read %llu failed to generate a sequence fragment", (unsigned long long)(first_read + i));

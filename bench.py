@@ -73,6 +73,13 @@ WORKLOADS = {
     'kpn': dict(ref='kpn', em='nanopore2023', qm='nanopore2023', identity=(95.0, 99.0, 2.5),
                 text='configs[1]: 5.5 Mb K. pneumoniae-like synthetic reference (3 circular contigs), nanopore2023 '
                      'error+qscore models, default badread simulate parameters, seed 42'),
+    # parity workloads (tests/test_gpu_fullsize.py), not bench lines: parameter sets that move the reads out of the default band classes
+    'rough': dict(ref='grch38', em='nanopore2023', qm='nanopore2023', identity=(85.0, 95.0, 5.0), chimeras=25.0, glitches=(1000.0, 100.0, 100.0),
+                  text='configs[3] reference with --identity 85,95,5 --chimeras 25 --glitches 1000,100,100: most bases in the 2-, 4- and '
+                       '8+-word band classes of the final aligner'),
+    'wide': dict(ref='kpn', em='nanopore2023', qm='nanopore2023', identity=(60.0, 75.0, 8.0), length=(40000.0, 35000.0),
+                 text='configs[1] reference with --identity 60,75,8 --length 40000,35000: reads of 150+ kb at 60 % identity, whose final '
+                      'band is beyond 16 words per lane (the memory-resident wide path)'),
 }
 
 
@@ -129,13 +136,19 @@ def build_workload(io_null, workload='kpn', ref_dir=None, scale=1.0, timing=None
     from badread_amd.simulate import adjust_depths
     w = WORKLOADS[workload]
     pref = load_reference(w['ref'], ref_dir or default_ref_dir(), scale, timing)
-    frag = FragmentLengths(15000, 13000, io_null)
+    frag_mean, frag_stdev = w.get('length', (15000.0, 13000.0))
+    frag = FragmentLengths(frag_mean, frag_stdev, io_null)
     mean, mx, sd = w['identity']
     ident = Identities(mean, sd, mx, io_null)
     depths = adjust_depths(pref, frag, False, np.random.RandomState(SEED))
     _, cum = pref.contig_weights(depths)
     mode, a, b, mx_ = ident.device_mode()
-    params = SimParams(frag_mean=15000, frag_stdev=13000, identity_mode=mode, id_a=a, id_b=b, id_max=mx_)
+    extra = {}
+    if 'chimeras' in w:
+        extra['chimera_rate'] = w['chimeras'] / 100.0                       # --chimeras is a percentage (simulate.py:101)
+    if 'glitches' in w:
+        extra.update(glitch_rate=w['glitches'][0], glitch_size=w['glitches'][1], glitch_skip=w['glitches'][2])
+    params = SimParams(frag_mean=frag_mean, frag_stdev=frag_stdev, identity_mode=mode, id_a=a, id_b=b, id_max=mx_, **extra)
     em = ErrorModel(w['em'], io_null).tables()
     qm = QScoreModel(w['qm'], io_null).tables()
     return pref, cum, em, qm, params
@@ -228,7 +241,9 @@ def aligner_lane_model(stats):
     """Share of the final aligner's lane-words that hold band cells, from the geometry of every read of a batch (a model, not a
     counter): a column of a read costs one trip-slot on all 64 lanes x G words, of which (band width) / 32 words are inside
     the Ukkonen band.  Band width ~ distance of the alignment + 1 (the kernels use the proven bound, a few percent more);
-    G = words per lane of the band class (1 up to 56 x 32 diagonals, then doubling).  Returns (useful, issued) word-columns."""
+    G = words per lane of the band class (1 up to 56 x 32 diagonals, then doubling); reads that k_fin_quad takes are issued for the
+    16 lanes of their row.  (The one-read-per-lane class of short reads is counted at 64 lanes: an underestimate of the useful share.)
+    Returns (useful, issued) word-columns."""
     n = stats['frag_len'].astype(np.float64) + 14.0
     d = np.maximum(stats['n_cols'].astype(np.float64) - stats['n_match'], 0.0)
     live = stats['n_cols'] > 0
@@ -236,8 +251,15 @@ def aligner_lane_model(stats):
     g = np.ones_like(bw)
     for _ in range(12):
         g = np.where(bw > 56.0 * 32.0 * g, g * 2.0, g)
+    lanes = np.full_like(bw, 64.0)
+    if os.environ.get('BRX_FIN_QUAD', '3') != '0':
+        # four reads per wave (k_fin_quad, csrc/brx_quad.h): a row of 16 lanes x 1 word up to 13 x 32 diagonals, x 2 words up to 13 x 64
+        # (reads with symbols outside ACGT keep to the whole wave: not visible in the statistics, a few per thousand)
+        quad1, quad2 = bw <= 13.0 * 32.0, (bw > 13.0 * 32.0) & (bw <= 13.0 * 64.0)
+        lanes = np.where(quad1 | quad2, 16.0, lanes)
+        g = np.where(quad2, 2.0, g)
     useful = float((n * bw / 32.0)[live].sum())
-    issued = float((n * 64.0 * g)[live].sum())
+    issued = float((n * lanes * g)[live].sum())
     return useful, issued
 
 

@@ -85,6 +85,9 @@ ROUTES = [
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_FIN_LANES': 0},        # no read aligned by lane in the final stage (short nanopore reads are, by default)
     {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 0},       # pass waves never stage a read in LDS: 2-bit codes from global memory, changed test on repl[]
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 120},   # a slice of 120 words: reads up to 1.2 kb staged, longer ones beside them from global memory
+    {'BRX_FIN_LANES': 0},                                      # narrow bands too go four per wave, a row of 16 lanes each (k_fin_quad), instead of one read per lane
+    {'BRX_FIN_LANES': 0, 'BRX_TB_WINDOW': -1},                 # ... and the misses of an 8-row traceback window are repeated by k_fin_align with the full store
+    {'BRX_FIN_QUAD': 0, 'BRX_FIN_LANES': 0},                   # every final alignment on a whole wave
 ]
 
 
@@ -229,17 +232,42 @@ def test_narrow_bands_one_read_per_lane(lanes, monkeypatch):
     assert (by_lane > 0.8 * float(st_h['frag_len'].sum())) if lanes else by_lane == 0
 
 
-def test_final_stage_with_fewer_slabs_than_reads(monkeypatch):
+@pytest.mark.parametrize('case', ['one_word', 'two_words', 'long'])
+def test_four_final_alignments_per_wave(case, monkeypatch):
+    """k_fin_quad (csrc/brx_quad.h): reads whose band is at most 13 superblocks -- of one word for up to 416 diagonals, of two for
+    up to 832 -- are aligned four per wave, one per row of 16 lanes, from LDS rings of target bytes and query planes that are
+    refilled every 32 loop trips.  Same bytes and statistics as the oracle; the class really takes the reads; the reads are long
+    enough for several refills per ring (a ring holds 1024 target bytes / 64 query words)."""
+    pref, _ = H.small_reference(with_n=False)
+    p, n, kern = {'one_word': (SimParams(frag_mean=2500, frag_stdev=1500, identity_mode=1, id_a=20.0, id_b=2.0, id_max=0.98), 16, 'k_fin_quad<1>'),
+                  'two_words': (SimParams(frag_mean=3000, frag_stdev=1000, identity_mode=0, id_max=0.80), 10, 'k_fin_quad<2>'),
+                  'long': (SimParams(frag_mean=9000, frag_stdev=500, identity_mode=0, id_max=0.97), 5, 'k_fin_quad<1>')}[case]
+    orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
+    eng = H.configure(emu_engine(monkeypatch, BRX_FIN_LANES=0 if case == 'one_word' else 1), pref, 'nanopore2023', 'nanopore2023', p)
+    eng.set_kernel_timing(True)
+    out_o, st_o = orc.simulate_batch(5, 0, n)
+    out_h, st_h = eng.simulate_batch(5, 0, n)
+    for f in STAT_FIELDS:
+        assert (st_h[f] == st_o[f]).all(), f
+    assert H.first_diff(out_h, out_o) < 0
+    assert eng.kernel_stats()[kern][2] > 0.5 * float(st_h['frag_len'].sum())
+
+
+@pytest.mark.parametrize('quad,small', [(0, 20 << 20), (3, 0)])
+def test_final_stage_with_fewer_slabs_than_reads(quad, small, monkeypatch):
     """The traceback stores of the final stage are slabs owned by the waves of the align kernels, sized by queue position
-    (brx_hip.hip, launch_final_phase).  An arena that holds the largest store but not one slab per read: the set runs with
-    fewer waves, every wave reusing its slab for several reads; same bytes."""
+    (brx_hip.hip, launch_final_phase).  An arena that holds the largest store but not one slab per read (per group of four reads
+    with k_fin_quad): the set runs with fewer waves, every wave reusing its slab for several reads; same bytes."""
     pref, _ = H.small_reference()
     p = SimParams(frag_mean=3200, frag_stdev=1300)
     orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
     out_o, st_o = orc.simulate_batch(8, 0, 28)
     slabs = []
-    for scratch in (1 << 29, 20 << 20):
-        eng = H.configure(emu_engine(monkeypatch, scratch=scratch, BRX_TB_WINDOW=0, BRX_WIN_KB=128, BRX_FIN_LANES=0), pref, 'nanopore2023', 'nanopore2023', p)
+    for scratch in (1 << 29, small):
+        # (with four reads per wave the slabs fit any arena that holds the rest of the batch: there the second engine is limited to
+        #  one slab-owning wave per CU of the two-CU interpreted chip instead)
+        eng = H.configure(emu_engine(monkeypatch, scratch=scratch or 1 << 29, BRX_TB_WINDOW=0, BRX_WIN_KB=128, BRX_FIN_LANES=0, BRX_FIN_QUAD=quad,
+                                     BRX_QUAD_WAVES_PER_CU=4 if scratch else 1), pref, 'nanopore2023', 'nanopore2023', p)
         out_h, st_h = eng.simulate_batch(8, 0, 28)
         slabs.append(eng.final_launches())
         for f in STAT_FIELDS:

@@ -214,16 +214,47 @@ def test_pinned_reads_on_the_rare_routes_of_the_final_stage(pin, tmp_path):
     import bench
     from badread_amd.engine import HipEngine
     ref_dir = bench.default_ref_dir()
-    wl = bench.build_workload(io.StringIO(), 'human', ref_dir)
-    first = (int(pin['read']) // 64) * 64
+    wlname, nb = pin.get('workload', 'human'), int(pin.get('batch', 64))
+    wl = bench.build_workload(io.StringIO(), wlname, ref_dir)
+    first = (int(pin['read']) // nb) * nb
     eng = bench.configure(HipEngine(0, scratch_bytes=8 << 30), wl)
-    out, st = eng.simulate_batch(SEED, first, 64)
+    out, st = eng.simulate_batch(SEED, first, nb)
     out, st = out.copy(), st.copy()
-    cyc = eng.read_cycles(64)
+    cyc = eng.read_cycles(nb)
     r = int(pin['read']) - first
     if pin['route'] == 'window_miss':
         assert eng.window_misses() >= 1 and cyc[r, 2] != 0
     else:
         assert (int(cyc[r, 7]) & 0xFFFF) > 16
+        assert int(st['n_cols'][r]) - int(st['n_match'][r]) > 57344          # more band rows than 64 lanes x 16 words hold
     eng.close()
-    compare_with_oracle_slices('human', ref_dir, 64, st, out.tobytes(), tmp_path, ALL_FIELDS, base=first)
+    compare_with_oracle_slices(wlname, ref_dir, nb, st, out.tobytes(), tmp_path, ALL_FIELDS, base=first)
+
+
+def test_off_default_parameters_full_batch_equals_the_oracle(tmp_path):
+    """full-size parity away from the default parameters.  One shipped device batch (65536 reads, the bench's
+    arena, default environment) of configs[3]'s reference with --identity 85,95,5 --chimeras 25 --glitches 1000,100,100
+    (bench.py workload 'rough'): three times the edits per base of the defaults, so most bases leave the one-word band class --
+    the 2- and 4-word classes and k_fin_align<16,8,...> carry what is a few percent at the defaults -- and a quarter of the reads
+    are chimeras.  Every read against the oracle; the band classes are asserted from the kernels' own per-read records."""
+    import bench
+    from badread_amd.engine import HipEngine, RS_EMPTY
+    ref_dir = bench.default_ref_dir()
+    wl = bench.build_workload(io.StringIO(), 'rough', ref_dir)
+    eng = bench.configure(HipEngine(0, scratch_bytes=int(bench.SCRATCH_GB_DEFAULT * (1 << 30))), wl)
+    out, st = eng.simulate_batch(SEED, 0, SHIPPED_BATCH)
+    out, st = out.copy(), st.copy()
+    cyc = eng.read_cycles(SHIPPED_BATCH)
+    retries = getattr(eng, 'retries', 0)
+    eng.close()
+    assert (st['status'] & ~np.uint32(RS_EMPTY) == 0).all()
+    words = (cyc[:, 7] & 0xFFFF).astype(np.int64)
+    bases = st['frag_len'].astype(np.float64)
+    share = {g: float(bases[words == g].sum() / bases.sum()) for g in (1, 2, 4, 8, 16)}
+    assert int((words >= 8).sum()) >= 100, share                         # k_fin_align<16,8,...> really carries reads here
+    assert share[1] < 0.5 and share[2] + share[4] > 0.3, share           # ... and the bulk has left the one-word class
+    assert int(((cyc[:, 7] >> 16) & 1).sum()) >= 1000                     # reads aligned four per wave (k_fin_quad) are in the batch too
+    raw = out.tobytes()
+    assert raw.count(b'chimera ') >= 5000                                  # a quarter of the reads join two fragments
+    compare_with_oracle_slices('rough', ref_dir, SHIPPED_BATCH, st, raw, tmp_path, ALL_FIELDS)
+    assert retries == 0, 'the shipped arena must hold a shipped batch of this workload without a retry'

@@ -1,7 +1,7 @@
 """
 Differential fuzzing of the product kernels (interpreted on the CPU, tests/emu_engine.py) against the oracle:
 random simulate parameters, models, references, seeds and kernel routes; every mismatch is logged with the
-arguments that reproduce it.   python tools/fuzz_emulated.py <seconds> <worker id> [log dir]
+arguments that reproduce it.   python tools/fuzz_emulated.py <seconds> <worker id> [log dir] [quad]
 """
 import json
 import os
@@ -27,11 +27,17 @@ ROUTES = [{}, {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '0'}, {'BRX_TAIL_REA
           {'BRX_TAIL_READS': '0', 'BRX_HEAD_READS': '0', 'BRX_STAGE_WORDS': '0'},                                   # pass waves never stage a read in LDS
           {'BRX_TAIL_READS': '2', 'BRX_HEAD_READS': '3', 'BRX_STAGE_WORDS': '60'},           # short reads staged, the others beside them
           {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '0', 'BRX_STAGE_WORDS': '2560'}]
+# routes of the final stage with four alignments per wave (k_fin_quad; on by default): without the one-read-per-lane class so that
+# narrow bands go through it too, one word class only, window misses repeated by k_fin_align, few slabs, and switched off
+QUAD_ROUTES = [{'BRX_FIN_LANES': '0'}, {'BRX_FIN_QUAD': '1'}, {'BRX_FIN_QUAD': '2', 'BRX_FIN_LANES': '0'}, {'BRX_FIN_QUAD': '0'},
+               {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '-1'}, {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '0', 'BRX_QUAD_WAVES_PER_CU': '1', 'BRX_WAVES_PER_CU': '1'},
+               {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '1', 'BRX_TAIL_READS': '2', 'BRX_HEAD_READS': '3'}]
+ROUTES += QUAD_ROUTES
 
 
-def draw_case(rng):
+def draw_case(rng, focus=None):
     mode = int(rng.integers(0, 3))
-    p = dict(frag_mean=float(rng.choice([60, 300, 900, 2500, 4500])), frag_stdev=float(rng.choice([0, 50, 800, 3000])),
+    p = dict(frag_mean=float(rng.choice([60, 300, 900, 2500, 4500] if focus != 'quad' else [900, 2500, 4500, 7000])), frag_stdev=float(rng.choice([0, 50, 800, 3000])),
              identity_mode=mode, start_rate=float(rng.choice([0, 0.5, 0.9, 1.0])), start_amount=float(rng.choice([0.1, 0.6, 1.0])),
              end_rate=float(rng.choice([0, 0.5, 1.0])), end_amount=float(rng.choice([0.2, 0.9, 1.0])),
              start_adapter=str(rng.choice(['', 'AATGTACTTCGTTCAGTTACGTATTGCT', 'ACGT'])),
@@ -50,7 +56,7 @@ def draw_case(rng):
         p.update(id_a=float(rng.choice([10.0, 20.0, 30.0])), id_b=float(rng.choice([1.0, 3.0, 6.0])), id_max=1.0)
     return dict(params=p, em=str(rng.choice(MODELS)), qm=str(rng.choice(QMODELS)), seed=int(rng.integers(0, 2 ** 40)),
                 first=int(rng.integers(0, 10 ** 6)), n=int(rng.choice([1, 7, 16, 30])), with_n=bool(rng.integers(0, 2)),
-                route=dict(ROUTES[int(rng.integers(0, len(ROUTES)))]))
+                route=dict((QUAD_ROUTES if focus == 'quad' else ROUTES)[int(rng.integers(0, len(QUAD_ROUTES if focus == 'quad' else ROUTES)))]))
 
 
 def run_case(case):
@@ -75,12 +81,13 @@ def run_case(case):
 def main():
     seconds, wid = float(sys.argv[1]), int(sys.argv[2])
     logdir = sys.argv[3] if len(sys.argv) > 3 else '/tmp/brx_fuzz'
+    focus = sys.argv[4] if len(sys.argv) > 4 else None          # 'quad': only the k_fin_quad routes, longer reads
     os.makedirs(logdir, exist_ok=True)
     rng = np.random.default_rng(1000 + wid)
     t0, cases, bases, fails = time.time(), 0, 0, 0
     with open(os.path.join(logdir, f'worker{wid}.log'), 'a') as log:
         while time.time() - t0 < seconds:
-            case = draw_case(rng)
+            case = draw_case(rng, focus)
             try:
                 bad, nb = run_case(case)
             except BaseException as ex:           # the library reports, the harness records
