@@ -80,8 +80,10 @@ SIMULATE_OPTIONS = [
                                     'gzip -6 on simulated reads, and the host only copies)')),
         ('--output-shards', dict(type=str, default=None, dest='output_shards', metavar='PREFIX',
                                  help='Multi-GPU runs: every rank writes the records of ITS reads to PREFIX.<rank>.fastq (.fastq.gz with '
-                                      '--gzip / --gzip-device) and the bytes per batch to PREFIX.<rank>.parts, instead of all records '
-                                      'travelling to rank 0 and through one stdout; the same reads, the same stopping point')),
+                                      '--gzip / --gzip-device) and the bytes per batch to PREFIX.<rank>.parts (FASTQ text bytes; with '
+                                      '--gzip-device the compressed bytes; with --gzip the compressed bytes per batch go to '
+                                      'PREFIX.<rank>.zparts beside them), instead of all records travelling to rank 0 and through one '
+                                      'stdout; the same reads, the same stopping point')),
         ('--gpu-streams', dict(type=int, default=None, dest='gpu_streams',
                                help='Device batches in flight per GPU, each on its own HIP stream (default: 6)')),
     ]),

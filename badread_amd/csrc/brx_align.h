@@ -127,17 +127,24 @@ __host__ __device__ inline BrxGeom brx_make_geom(int Q, int T, int k, int hmul =
  * K = 1; the column in the middle of its trip otherwise: brx_jrep.)  For a fixed store row the rows
  * R*s - c(jrep) grow by at least R per superblock, so at most (2H + R - 1)/R + 1 consecutive superblocks
  * pass -- they land in distinct slots s % WSp. */
+/* The test itself, in the form the forward passes keep it (ONE definition for them and for the traceback -- ADVICE r4):
+   keep_base = R s + H + R - 1 (per superblock), keep_lim = 2 H + R - 1, jrep as below. */
+__host__ __device__ __forceinline__ bool brx_keep_trip(uint32_t slope, int keep_base, uint32_t keep_lim, int jrep) {
+    return (uint32_t)(keep_base - (int)(uint32_t)(((uint64_t)(uint32_t)jrep * (uint64_t)slope) >> 20)) <= keep_lim;
+}
 __host__ __device__ __forceinline__ bool brx_stored(const BrxGeom &g, int s, int jrep) {
-    const int c = (int)(((uint64_t)(uint32_t)jrep * (uint64_t)g.slope) >> 20);
-    const int a = g.R * s + g.H + g.R - 1 - c;
-    return (uint32_t)a <= (uint32_t)(2 * g.H + g.R - 1);
+    return brx_keep_trip(g.slope, g.R * s + g.H + g.R - 1, (uint32_t)(2 * g.H + g.R - 1), jrep);
+}
+/* the column that stands for loop trip tau (columns U tau + 1 - s .. U tau + U - s) of superblock s: its middle one, never below 0 */
+__host__ __device__ __forceinline__ int brx_jrep_trip(int U, int tau, int s) {
+    const int jr = U * tau + U / 2 - s;
+    return jr > 0 ? jr : 0;
 }
 /* the column that stands for column j of superblock s in the windowed-store test: the middle one of the loop trip that
    computes it (time j + s), never below 0 */
 __host__ __device__ __forceinline__ int brx_jrep(const BrxGeom &g, int s, int j) {
     if (g.U == 1) return j;
-    const int jr = ((j + s - 1) & ~(g.U - 1)) + g.U / 2 - s;
-    return jr > 0 ? jr : 0;
+    return brx_jrep_trip(g.U, (j + s - 1) / g.U, s);
 }
 
 /* 8-byte units of traceback storage an alignment needs */
@@ -720,9 +727,7 @@ __device__ inline void brx_align_forward_u(const uint8_t *__restrict__ Qs, const
         /* ---- U column updates, straight-line ---- */
         const uint32_t x0 = xn0, x1 = xn1;
         const bool act = (uint32_t)(tau - tf) <= tspan;
-        int jr = U * tau + U / 2 - s;
-        if (jr < 0) jr = 0;
-        const bool keep = (uint32_t)(keep_base - (int)(uint32_t)(((uint64_t)(uint32_t)jr * (uint64_t)g.slope) >> 20)) <= keep_lim;   /* one test per trip */
+        const bool keep = brx_keep_trip(g.slope, keep_base, keep_lim, brx_jrep_trip(U, tau, s));     /* one test per trip: what brx_stored(g, s, brx_jrep(g, s, j)) says for its columns */
         bool rare = tau <= tau_pro;
         if (__builtin_expect(odd != 0u, 0)) {
             bool lr = false;

@@ -589,7 +589,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             const uint64_t raw_cols = ((uint64_t)r.m * 4 + 7) / 8 + 2;
             const uint64_t u = (phase == 1 ? brx_final_units(r.m, r.n, r.ub, 0, &too_wide) : r.units) - raw_cols;     /* the aligner's share */
             const uint32_t kl = r.klass & 0xFFFFu;
-            if (r.klass & BRX_KL_LANES) {              /* never repeats (no windowed store): phase 0 only */
+            if ((r.klass & BRX_KL_LANES) && phase == 0) {      /* no windowed store: a repeat means the lane aligner failed; k_fin_align takes the read then (the flag is cleared) */
                 cls_list[4].push_back(h_order[i]);
                 cls_units[4].push_back(((uint64_t)r.n << 8) | (uint64_t)brx_finl_blocks(r.m, r.n, r.ub));     /* sorted by fragment length below; units per group follow */
                 continue;
@@ -771,7 +771,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         if (cnt[4]) {                                 /* the narrow-band class, one read per lane: with pacbio2021 / --identity 30,3 nearly every read */
             { KTIMED(BRX_KERN_FIN_LANES, cls_stream[0]);
               hipLaunchKernelGGL(k_fin_lanes, dim3(grid[4]), dim3(64), 0, cls_stream[0], dev, rs, d_lists + list_at[4], cnt[4],
-                                 reinterpret_cast<unsigned long long *>(cq + 12), d_slabs + slab_at[4], Fbuf, c->scratch, c->scratch, slab_base, clk); }
+                                 reinterpret_cast<unsigned long long *>(cq + 12), d_slabs + slab_at[4], misses, Fbuf, c->scratch, c->scratch, slab_base, clk); }
             score_class(4, cls_stream[0], cq + 14);
         }
         if (cnt[5]) {                                 /* bands of up to 13 superblocks, four reads per wave */

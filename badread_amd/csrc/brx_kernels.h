@@ -942,7 +942,12 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
         }
         uint8_t *seq = arena + seq_base + s.seq_off;
         wave_join(em, Fbuf + s.F_off, repl + s.F_off, 0, s.n, seq, nullptr);
-        for (uint32_t x = lane; x < 16; x += 64) seq[s.m + x] = 0xFE;        /* the aligner reads up to 16 bytes past the end */
+        /* What the aligners read past the end of a string (values masked or never used: only readability matters): the wave and
+           row aligners up to 16 bytes -- the pad written here and behind F by k_build --, the lane aligner up to 31 (brx_finl_planes32
+           loads 32 bytes at a time).  For the read that stays inside its own area (seq is followed by its qual half of at least 16
+           bytes, k_scan_mut); for the fragment it is the next read's F or the 64 bytes of slack behind Fbuf / the seq buffer
+           (brx_hip.hip: A.take(f_bytes + 64), A.take(seq_bytes + 64)). */
+        for (uint32_t x = lane; x < 16; x += 64) seq[s.m + x] = 0xFE;
         if (lane == 0) {
             const BrxGeom g = brx_make_geom((int)s.m, (int)s.n, (int)s.ub);
             bool junk = false, too_wide;
@@ -966,7 +971,7 @@ __global__ void __launch_bounds__(64) k_fin_join(BrxDev d, RS *rs, const uint32_
    consecutive entries; `ctr` / `slabs` as for k_fin_align below, counted in groups: slab t holds the move codes of the t-th longest
    group and of every group the wave pops after it. */
 __global__ void __launch_bounds__(64, 4) k_fin_lanes(BrxDev d, RS *rs, const uint32_t *list, uint32_t n_list, unsigned long long *ctr,
-                                                      const uint64_t *slabs, const uint8_t *Fbuf, uint8_t *seqbuf, uint8_t *opsbuf,
+                                                      const uint64_t *slabs, uint32_t *retries, const uint8_t *Fbuf, uint8_t *seqbuf, uint8_t *opsbuf,
                                                       uint8_t *slab_base, uint64_t *clk) {
     const int lane = lane_id();
     const uint32_t n_groups = (n_list + 63u) >> 6;
@@ -994,8 +999,14 @@ __global__ void __launch_bounds__(64, 4) k_fin_lanes(BrxDev d, RS *rs, const uin
         brx_lanes_final(valid && fits, seq, (int)m, F, (int)n, valid ? (int)s.ub : 0, tb, ops_end, &ncols, &nmatch, &ok);
         if (valid) {
             RS *o = &rs[r];
-            o->status = s.status | (ok ? 0u : BRX_RS_BAND);
-            o->n_cols = ncols; o->n_match = nmatch;
+            if (!ok) {          /* not fatal here -- the second phase repeats the read with k_fin_align and the full store; only that failing is BRX_RS_BAND */
+                o->klass = (s.klass & ~BRX_KL_LANES) | BRX_KL_RETRY;
+                atomicAdd(retries, 1u);
+                clk[(uint64_t)r * 8 + 2] = 1;
+            } else {
+                o->status = s.status;
+                o->n_cols = ncols; o->n_match = nmatch;
+            }
             uint64_t *ck = clk + (uint64_t)r * 8;
             ck[3] = __builtin_amdgcn_s_memtime() - t_begin; ck[7] = (uint64_t)(s.klass & 0xFFFFu);
         }

@@ -206,9 +206,7 @@ __device__ inline void brx_quad_forward(const bool live, const uint8_t *__restri
         /* ---- U column updates ---- */
         const uint32_t x0 = xn0, x1 = xn1;
         const bool act = (uint32_t)(tau - tf) <= tspan;
-        int jr = U * tau + U / 2 - s;
-        if (jr < 0) jr = 0;
-        const bool keep = (uint32_t)(keep_base - (int)(uint32_t)(((uint64_t)(uint32_t)jr * (uint64_t)g.slope) >> 20)) <= keep_lim;
+        const bool keep = brx_keep_trip(g.slope, keep_base, keep_lim, brx_jrep_trip(U, tau, s));
         uint32_t P[G], M[G];
 #pragma unroll
         for (int x = 0; x < G; ++x) { P[x] = Pv[x]; M[x] = Mv[x]; }

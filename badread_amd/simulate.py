@@ -217,6 +217,16 @@ class Shard(object):
                 self.dist.destroy_process_group()
                 self.owns_group = False
 
+    def abandon(self):
+        """Leave WITHOUT meeting the peers (this rank failed alone): close the connections so that a peer's next exchange fails
+        at once instead of waiting for this rank until the backend's timeout."""
+        if self.world > 1 and self.dist is not None and self.owns_group and self.dist.is_initialized():
+            try:
+                self.dist.destroy_process_group()
+            except Exception:              # the group may be in the middle of the collective that failed
+                pass
+            self.owns_group = False
+
     @classmethod
     def from_env(cls):
         world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -701,6 +711,41 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     return count, total
 
 
+class _PartsLog(object):
+    """PREFIX.<rank>.parts (and .zparts): a line per batch once the batch's bytes have gone through the sink.  batch() is called by the
+    consumer thread in batch order, wrote() by the ring's writer thread after every write of the sink; a batch's bytes are written
+    by writes of its own (the ring is handed one batch at a time), so when the bytes written reach a batch's end the sink's output
+    counter stands at the end of that batch's last gzip member."""
+
+    def __init__(self, parts_file, zparts_file=None, sink_bytes_out=None):
+        import collections
+        import threading
+        self.parts_file, self.zparts_file, self.sink_bytes_out = parts_file, zparts_file, sink_bytes_out
+        self.lock = threading.Lock()
+        self.ends = collections.deque()
+        self.issued = self.written = self.z_before = 0
+
+    def batch(self, n):
+        with self.lock:
+            self.parts_file.write(f'{n}\n')
+            self.issued += int(n)
+            self.ends.append(self.issued)
+            self._settle()
+
+    def wrote(self, n):
+        with self.lock:
+            self.written += int(n)
+            self._settle()
+
+    def _settle(self):
+        while self.ends and self.written >= self.ends[0]:
+            self.ends.popleft()
+            if self.zparts_file is not None:
+                z = int(self.sink_bytes_out())
+                self.zparts_file.write(f'{z - self.z_before}\n')
+                self.z_before = z
+
+
 # ---------------------------------------------------------------------------------------------
 # the driver
 # ---------------------------------------------------------------------------------------------
@@ -756,22 +801,45 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
             sys.stdout.write(bytes(part).decode('latin-1'))
     # --output-shards PREFIX: every rank writes PREFIX.<rank>.fastq[.gz] itself (and the bytes per batch to PREFIX.<rank>.parts),
     # so that N ranks leave through N PCIe links and N files instead of rank 0's one of each (simulate.py:77-82 is one print loop)
-    local_write = local_parts = shard_file = parts_file = None
+    #   PREFIX.<rank>.parts: one line per batch = the bytes this rank handed to its sink for that batch -- FASTQ text for the plain
+    #   file and for --gzip (whose file holds that text as gzip members), compressed bytes for --gzip-device (the members are made
+    #   on the GPU, batch by batch).  With --gzip, PREFIX.<rank>.zparts holds the compressed bytes per batch beside it (every batch
+    #   ends a gzip member), so that the .gz files too can be put back in read order without decompressing them.
+    local_write = local_parts = None
+    files = []
     prefix = getattr(args, 'output_shards', None)
     if prefix:
         zipped = device_gzip or gzip_level is not None
-        shard_file = open(f'{prefix}.{shard.rank}.fastq' + ('.gz' if zipped else ''), 'wb')
-        parts_file = open(f'{prefix}.{shard.rank}.parts', 'w')
+        open_error = None
+        try:                                # a rank that cannot open its files must not leave the others in their first exchange
+            shard_file = open(f'{prefix}.{shard.rank}.fastq' + ('.gz' if zipped else ''), 'wb')
+            files.append(shard_file)
+            parts_file = open(f'{prefix}.{shard.rank}.parts', 'w')
+            files.append(parts_file)
+            zparts_file = None
+            if gzip_level is not None:
+                zparts_file = open(f'{prefix}.{shard.rank}.zparts', 'w')
+                files.append(zparts_file)
+        except OSError as ex:
+            open_error = ex
+        failed = [int(x[0]) for x in shard.gather_words(np.array([1 if open_error else 0], dtype=np.uint32), [1] * shard.world)]
+        if any(failed):
+            for f in files:
+                f.close()
+            shard.finish()
+            sys.exit(f'Error: could not open the output shards of rank(s) {[r for r, x in enumerate(failed) if x]}'
+                     + (f': {open_error}' if open_error else ''))
         shard_sink = shard_file
         if gzip_level is not None:
             from .output import GzipSink
             shard_sink = GzipSink(shard_file, gzip_level)
+        log = _PartsLog(parts_file, zparts_file, (lambda: shard_sink.bytes_out) if zparts_file is not None else None)
 
         def local_write(part):
             shard_sink.write(memoryview(part))
+            log.wrote(len(part))
 
-        def local_parts(n):
-            parts_file.write(f'{n}\n')
+        local_parts = log.batch
     try:
         try:
             result = run_batches(engine, seed, target_size, float(args.mean_frag_length), write, quiet, shard,
@@ -780,11 +848,16 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
             if prefix and hasattr(shard_sink, 'flush') and shard_sink is not shard_file:
                 shard_sink.flush()
         finally:
-            for f in (shard_file, parts_file):
-                if f is not None:
-                    f.close()
+            for f in files:
+                f.close()
     except (SystemExit, OSError):
         shard.finish()                      # exits every rank takes at the same batch: NOFRAG, a bad read, a failed sink
+        raise
+    except BaseException:
+        # Not an exit the ranks take together (an engine error, a sink raising something else: ADVICE r4): the peers are in, or on
+        # their way to, an exchange this rank will never join.  Leave without meeting them -- under torchrun the failing rank takes
+        # the job down; a peer left alone fails in its exchange instead of waiting for the backend's timeout.
+        shard.abandon()
         raise
     shard.finish()
     if sink is not None and hasattr(sink, 'flush'):

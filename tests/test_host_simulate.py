@@ -242,6 +242,21 @@ def test_output_shards_with_host_gzip(tmp_path, monkeypatch):
     assert r.returncode == 0, r.stderr[-3000:]
     texts, _ = reassemble(prefix, 2, gz=True)
     assert sorted(tuple(x) for x in parse_fastq(b''.join(texts))) == sorted(tuple(x) for x in parse_fastq(single))
+    # .parts counts FASTQ text; .zparts (--gzip only) counts the compressed bytes of the same batches, so the .gz files
+    # go back into read order batch by batch, rank after rank, WITHOUT being decompressed first
+    import gzip
+    gz = [open(f'{prefix}.{r}.fastq.gz', 'rb').read() for r in range(2)]
+    zparts = [[int(x) for x in open(f'{prefix}.{r}.zparts').read().split()] for r in range(2)]
+    parts = [[int(x) for x in open(f'{prefix}.{r}.parts').read().split()] for r in range(2)]
+    assert [len(z) for z in zparts] == [len(p) for p in parts] and all(sum(z) == len(g) for z, g in zip(zparts, gz))
+    joined, at = b'', [0, 0]
+    for b in range(len(zparts[0])):
+        for r in range(2):
+            member = gz[r][at[r]:at[r] + zparts[r][b]]
+            assert len(gzip.decompress(member)) == parts[r][b] if member else parts[r][b] == 0
+            joined += member
+            at[r] += zparts[r][b]
+    assert gzip.decompress(joined) == single
 
 
 def test_single_process_output_shards(tmp_path, monkeypatch):
