@@ -15,7 +15,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <unordered_map>
 #include <vector>
 
@@ -88,6 +91,13 @@ struct brx_fasta {
     uint64_t n_bases = 0;
     uint32_t n_symbols = 5;
     uint8_t sym[16], comp[16];
+    /* a reference loaded from its sidecar keeps the packed words IN the mapped file (772 MB for a human genome: no read into a
+       zero-filled vector, no second copy): `packed` stays empty and the view points into the mapping */
+    const uint32_t *mapped_packed = nullptr;
+    size_t mapped_words = 0;
+    void *map_base = nullptr;
+    size_t map_len = 0;
+    ~brx_fasta() { if (map_base) munmap(map_base, map_len); }
 };
 
 /* byte -> 2-bit code of A,C,G,T in either case; 0xFF for everything else */
@@ -281,10 +291,10 @@ extern "C" int brx_fasta_pack(const char *path, brx_fasta **out, char *err, size
 
 extern "C" int brx_fasta_view_of(const brx_fasta *f, brx_fasta_view *v) {
     if (!f || !v) return BRX_E_ARG;
-    v->n_bases = f->n_bases; v->n_words = f->packed.size();
+    v->n_bases = f->n_bases; v->n_words = f->mapped_packed ? f->mapped_words : f->packed.size();
     v->n_contigs = (uint32_t)f->contigs.size(); v->n_exceptions = (uint32_t)f->exceptions.size();
     v->names_len = (uint32_t)f->names.size(); v->n_symbols = f->n_symbols;
-    v->packed = f->packed.data(); v->contigs = f->contigs.data();
+    v->packed = f->mapped_packed ? f->mapped_packed : f->packed.data(); v->contigs = f->contigs.data();
     v->exceptions = f->exceptions.empty() ? nullptr : f->exceptions.data();
     v->names = f->names.data(); v->depths = f->depths.data();
     memcpy(v->sym, f->sym, 16); memcpy(v->comp, f->comp, 16);
@@ -296,13 +306,13 @@ extern "C" void brx_fasta_free(brx_fasta *f) { delete f; }
 /* ---- sidecar ------------------------------------------------------------------------------------------ */
 namespace {
 struct SidecarHeader {
-    char magic[8];                 /* "BRX2BIT\1" */
+    char magic[8];                 /* "BRX2BIT\2": the packed words start at the next multiple of 8 bytes behind the names */
     uint64_t src_size; int64_t src_mtime_ns;
     uint64_t n_bases, n_words;
     uint32_t n_contigs, n_exceptions, names_len, n_symbols;
     uint8_t sym[16], comp[16];
 };
-const char MAGIC[8] = {'B', 'R', 'X', '2', 'B', 'I', 'T', 1};
+const char MAGIC[8] = {'B', 'R', 'X', '2', 'B', 'I', 'T', 2};
 
 bool stat_source(const char *path, uint64_t *size, int64_t *mtime_ns) {
     struct stat st;
@@ -319,7 +329,9 @@ extern "C" int brx_fasta_save(const brx_fasta *f, const char *source_path, const
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, MAGIC, 8);
     if (!stat_source(source_path, &h.src_size, &h.src_mtime_ns)) return set_err(err, err_cap, BRX_E_ARG, "could not stat %s", source_path);
-    h.n_bases = f->n_bases; h.n_words = f->packed.size();
+    const size_t n_words = f->mapped_packed ? f->mapped_words : f->packed.size();
+    const uint32_t *words = f->mapped_packed ? f->mapped_packed : f->packed.data();
+    h.n_bases = f->n_bases; h.n_words = n_words;
     h.n_contigs = (uint32_t)f->contigs.size(); h.n_exceptions = (uint32_t)f->exceptions.size();
     h.names_len = (uint32_t)f->names.size(); h.n_symbols = f->n_symbols;
     memcpy(h.sym, f->sym, 16); memcpy(h.comp, f->comp, 16);
@@ -331,7 +343,14 @@ extern "C" int brx_fasta_save(const brx_fasta *f, const char *source_path, const
     ok = ok && fwrite(f->depths.data(), sizeof(double), f->depths.size(), fp) == f->depths.size();
     ok = ok && fwrite(f->exceptions.data(), sizeof(brx_exception), f->exceptions.size(), fp) == f->exceptions.size();
     ok = ok && fwrite(f->names.data(), 1, f->names.size(), fp) == f->names.size();
-    ok = ok && fwrite(f->packed.data(), 4, f->packed.size(), fp) == f->packed.size();
+    {   /* the words are read in place from the mapped file: aligned */
+        const size_t at = sizeof(h) + f->contigs.size() * sizeof(brx_contig) + f->depths.size() * sizeof(double) +
+                          f->exceptions.size() * sizeof(brx_exception) + f->names.size();
+        const char zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const size_t pad = (8 - at % 8) % 8;
+        ok = ok && (pad == 0 || fwrite(zeros, 1, pad, fp) == pad);
+    }
+    ok = ok && fwrite(words, 4, n_words, fp) == n_words;
     ok = (fclose(fp) == 0) && ok;
     if (!ok || rename(tmp.c_str(), sidecar_path) != 0) { remove(tmp.c_str()); return set_err(err, err_cap, BRX_E_ARG, "could not write %s", sidecar_path); }
     return BRX_OK;
@@ -342,26 +361,38 @@ extern "C" int brx_fasta_load(const char *source_path, const char *sidecar_path,
     *out = nullptr;
     uint64_t size; int64_t mtime;
     if (!stat_source(source_path, &size, &mtime)) return set_err(err, err_cap, BRX_E_STATE, "could not stat %s", source_path);
-    FILE *fp = fopen(sidecar_path, "rb");
-    if (!fp) return set_err(err, err_cap, BRX_E_STATE, "no sidecar %s", sidecar_path);
+    const int fd = open(sidecar_path, O_RDONLY);
+    if (fd < 0) return set_err(err, err_cap, BRX_E_STATE, "no sidecar %s", sidecar_path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(SidecarHeader)) { close(fd); return set_err(err, err_cap, BRX_E_STATE, "sidecar %s is truncated", sidecar_path); }
+    const size_t len = (size_t)st.st_size;
+    void *base = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) return set_err(err, err_cap, BRX_E_STATE, "could not map %s", sidecar_path);
     SidecarHeader h;
-    if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, MAGIC, 8) != 0 || h.src_size != size || h.src_mtime_ns != mtime ||
+    memcpy(&h, base, sizeof(h));
+    if (memcmp(h.magic, MAGIC, 8) != 0 || h.src_size != size || h.src_mtime_ns != mtime ||
         h.n_words != (h.n_bases + 15) / 16 + 1 || h.n_symbols > 16) {
-        fclose(fp);
+        munmap(base, len);
         return set_err(err, err_cap, BRX_E_STATE, "sidecar %s does not match %s", sidecar_path, source_path);
     }
+    size_t at = sizeof(h);
+    const size_t contigs_at = at; at += (size_t)h.n_contigs * sizeof(brx_contig);
+    const size_t depths_at = at; at += (size_t)h.n_contigs * sizeof(double);
+    const size_t exc_at = at; at += (size_t)h.n_exceptions * sizeof(brx_exception);
+    const size_t names_at = at; at += (size_t)h.names_len;
+    at = (at + 7) & ~(size_t)7;
+    if (at + (size_t)h.n_words * 4 > len) { munmap(base, len); return set_err(err, err_cap, BRX_E_STATE, "sidecar %s is truncated", sidecar_path); }
     brx_fasta *f = new brx_fasta();
     f->n_bases = h.n_bases; f->n_symbols = h.n_symbols;
     memcpy(f->sym, h.sym, 16); memcpy(f->comp, h.comp, 16);
-    f->contigs.resize(h.n_contigs); f->depths.resize(h.n_contigs); f->exceptions.resize(h.n_exceptions);
-    f->names.resize(h.names_len); f->packed.resize((size_t)h.n_words);
-    bool ok = fread(f->contigs.data(), sizeof(brx_contig), h.n_contigs, fp) == h.n_contigs;
-    ok = ok && fread(f->depths.data(), sizeof(double), h.n_contigs, fp) == h.n_contigs;
-    ok = ok && fread(f->exceptions.data(), sizeof(brx_exception), h.n_exceptions, fp) == h.n_exceptions;
-    ok = ok && fread(f->names.data(), 1, h.names_len, fp) == h.names_len;
-    ok = ok && fread(f->packed.data(), 4, (size_t)h.n_words, fp) == (size_t)h.n_words;
-    fclose(fp);
-    if (!ok) { delete f; return set_err(err, err_cap, BRX_E_STATE, "sidecar %s is truncated", sidecar_path); }
+    const char *b = (const char *)base;
+    f->contigs.resize(h.n_contigs); f->depths.resize(h.n_contigs); f->exceptions.resize(h.n_exceptions); f->names.resize(h.names_len);
+    if (h.n_contigs) { memcpy(f->contigs.data(), b + contigs_at, (size_t)h.n_contigs * sizeof(brx_contig)); memcpy(f->depths.data(), b + depths_at, (size_t)h.n_contigs * sizeof(double)); }
+    if (h.n_exceptions) memcpy(f->exceptions.data(), b + exc_at, (size_t)h.n_exceptions * sizeof(brx_exception));
+    if (h.names_len) memcpy(f->names.data(), b + names_at, h.names_len);
+    f->map_base = base; f->map_len = len;
+    f->mapped_packed = (const uint32_t *)(b + at); f->mapped_words = (size_t)h.n_words;
     *out = f;
     return BRX_OK;
 }

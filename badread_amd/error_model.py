@@ -181,16 +181,38 @@ def derive_lookup_tables(t):
     return dict(rowx=rowx, altx=altx, thr=thr)
 
 
+def _rows_field(name):
+    """A per-row list of the model (k-mers, alternatives, probabilities, inner alignment ops): parsed out of the cache file
+    only when something asks for it -- `badread simulate` needs the flattened device tables and nothing else, and turning
+    425 984 alternatives into Python lists at every start was 0.4 s of the command's fixed cost."""
+    private = '_rows' + name
+
+    def get(self):
+        if self._npz_pending is not None:
+            self._parse_rows()
+        return getattr(self, private)
+
+    def put(self, value):
+        setattr(self, private, value)
+    return property(get, put)
+
+
 class ErrorModel(object):
+    _kmers = _rows_field('_kmers')                 # row order as in the file
+    _probs = _rows_field('_probs')                 # list of lists of float
+    _alt_strings = _rows_field('_alt_strings')     # list of lists of alt strings (un-aligned)
+    _ops = _rows_field('_ops')                     # per alt: op arrays for the inner alignment
 
     def __init__(self, model_type_or_filename, output=sys.stderr, aligner=None, use_cache=True):
         self.kmer_size = None
         self.type = None
-        self._kmers = []            # row order as in the file
-        self._probs = []            # list of lists of float
-        self._alt_strings = []      # list of lists of alt strings (un-aligned)
+        self._npz_pending = None    # cache file whose per-row lists have not been parsed yet
+        self._n_rows_in_file = None
+        self._kmers = []
+        self._probs = []
+        self._alt_strings = []
         self._positions = None      # list of lists of k-lists (built lazily from ops)
-        self._ops = None            # per alt: op arrays for the inner alignment
+        self._ops = None
         self._tables = None
         self._alternatives = None
         self._probabilities = None
@@ -215,7 +237,7 @@ class ErrorModel(object):
         if cache:
             print(f'\nLoading error model {name} (packed tables)', file=output)
             self._load_npz(cache)
-            print(f'  done: loaded error distributions for {len(self._kmers)} {self.kmer_size}-mers',
+            print(f'  done: loaded error distributions for {self._n_rows_in_file} {self.kmer_size}-mers',
                   file=output)
             return
         path = find_builtin_file('error_models', name)
@@ -235,7 +257,7 @@ class ErrorModel(object):
                 if os.path.isfile(cache_path):
                     try:
                         self._load_npz(cache_path)
-                        print(f'  done: loaded error distributions for {len(self._kmers)} '
+                        print(f'  done: loaded error distributions for {self._n_rows_in_file} '
                               f'{self.kmer_size}-mers', file=output)
                         return
                     except Exception:          # truncated / foreign file (zipfile.BadZipFile, KeyError ...): re-parse the model
@@ -397,20 +419,43 @@ class ErrorModel(object):
         return self._tables
 
     # ------------------------------------------------------------------ cache (.npz)
+    # the device tables a cache file carries beside the per-row lists (rowx / altx / the padded thr are derived: derive_lookup_tables)
+    _TABLE_ARRAYS = ('row_off', 'self_thr', 'thr', 'desc', 'pool')
+
     def save_npz(self, path):
         lens = np.array([len(a) for a in self._alt_strings], dtype=np.int32)
         flat_alts = '\n'.join('\t'.join(a) for a in self._alt_strings)
         flat_ops = np.concatenate([o for row in self._ops for o in row]) if self._ops else np.zeros(0, np.uint8)
         op_lens = np.array([len(o) for row in self._ops for o in row], dtype=np.int32)
+        extra = {}
+        if self.kmer_size <= 9:
+            self._tables = None
+            t = self.tables()                       # built from the lists: what a later load hands to the engine as it is
+            extra = {'t_' + name: (t[name][:max(int(t['n_alts']), 1)] if name == 'thr' else t[name]) for name in self._TABLE_ARRAYS}
+            extra['t_counts'] = np.array([t['n_rows'], t['n_alts']], dtype=np.int64)
         np.savez_compressed(path, k=np.int32(self.kmer_size), kmers=np.array('\n'.join(self._kmers)),
                             alts=np.array(flat_alts), n_alts=lens,
                             probs=np.array([p for row in self._probs for p in row], dtype=np.float64),
-                            ops=flat_ops, op_lens=op_lens)
+                            ops=flat_ops, op_lens=op_lens, **extra)
 
     def _load_npz(self, path):
+        """The flattened device tables straight from the file when it carries them (tables() built them once, when the file
+        was written); the per-row lists stay in the file until a caller asks for them (_rows_field)."""
         z = np.load(path, allow_pickle=False)
         self.type = 'model'
         self.kmer_size = int(z['k'])
+        self._n_rows_in_file = int(len(z['n_alts']))
+        if 't_counts' in z.files:
+            n_rows, n_alts = (int(x) for x in z['t_counts'])
+            t = dict(k=self.kmer_size, type=1, n_rows=n_rows, n_alts=n_alts)
+            t.update({name: np.ascontiguousarray(z['t_' + name]) for name in self._TABLE_ARRAYS})
+            t.update(derive_lookup_tables(t))
+            self._tables = t
+        self._npz_pending = path
+
+    def _parse_rows(self):
+        path, self._npz_pending = self._npz_pending, None
+        z = np.load(path, allow_pickle=False)
         self._kmers = str(z['kmers']).split('\n')
         self._alt_strings = [row.split('\t') for row in str(z['alts']).split('\n')]
         n_alts = z['n_alts']

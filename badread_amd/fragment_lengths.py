@@ -7,6 +7,7 @@ parameterisation (`gamma_parameters`), the banner lines, and a host `get_fragmen
 the reference's semantics (np.random.gamma, Python round, min 1) for adjust_depths
 (simulate.py:516-536) and for callers that use the class directly.
 """
+import math
 import sys
 
 import numpy as np
@@ -64,5 +65,51 @@ def find_n_value(a, b, n):
     length distribution of gamma(a, rate b) is gamma(a+1, rate b), so this is its quantile.  The
     reference binary-searches the same integral (fragment_lengths.py:67-117); banner use only.
     """
-    import scipy.stats
-    return float(scipy.stats.gamma.ppf(1.0 - n / 100.0, a + 1.0, scale=1.0 / b))
+    target = 1.0 - n / 100.0
+    shape = a + 1.0
+    lo, hi = 0.0, shape + 10.0 * math.sqrt(shape) + 50.0          # in units of the scale 1 / b
+    while _gamma_p(shape, hi) < target:
+        hi *= 2.0
+    for _ in range(200):                      # bisection on the regularised incomplete gamma function (no scipy import: 0.5 s of start-up)
+        mid = 0.5 * (lo + hi)
+        if _gamma_p(shape, mid) < target:
+            lo = mid
+        else:
+            hi = mid
+        if hi - lo <= 1e-13 * hi:
+            break
+    return 0.5 * (lo + hi) / b
+
+
+def _gamma_p(a, x):
+    """Regularised lower incomplete gamma function P(a, x): its power series below a + 1, the continued fraction of Q above."""
+    if x <= 0.0:
+        return 0.0
+    log_front = a * math.log(x) - x - math.lgamma(a)
+    if x < a + 1.0:
+        term = total = 1.0 / a
+        k = a
+        for _ in range(100000):
+            k += 1.0
+            term *= x / k
+            total += term
+            if abs(term) < abs(total) * 1e-16:
+                break
+        return total * math.exp(log_front)
+    tiny = 1e-300
+    b0 = x + 1.0 - a
+    c, d = 1.0 / tiny, 1.0 / b0
+    h = d
+    for i in range(1, 100000):
+        an = -i * (i - a)
+        b0 += 2.0
+        d = an * d + b0
+        d = tiny if abs(d) < tiny else d
+        c = b0 + an / c
+        c = tiny if abs(c) < tiny else c
+        d = 1.0 / d
+        delta = d * c
+        h *= delta
+        if abs(delta - 1.0) < 1e-16:
+            break
+    return 1.0 - math.exp(log_front) * h

@@ -82,16 +82,46 @@ class PackedReference(object):
         self.sym = np.zeros(16, dtype=np.uint8)
         self.comp = np.zeros(16, dtype=np.uint8)
         self.code_of = {}
+        self._native = None          # (library, handle) of the native object `packed` points into, if any
+
+    def __del__(self):
+        native, self._native = getattr(self, '_native', None), None
+        if native is not None:
+            self.packed = np.zeros(1, dtype=np.uint32)       # never leave a view of freed / unmapped memory behind
+            native[0].brx_fasta_free(native[1])
 
     @classmethod
     def from_fasta(cls, filename, cache=None):
         """FASTA or FASTA.gz -> packed reference through libbrx_host.so (csrc/brx_fasta.cpp: one streaming C++ pass
-        instead of Python strings + numpy).  cache=True (or BRX_REFERENCE_CACHE=1) keeps the packed form in
-        `<filename>.brx2bit` and reuses it while the FASTA's size and mtime are unchanged."""
+        instead of Python strings + numpy).  The packed form is kept in a sidecar file and MAPPED from it next time (while the
+        FASTA's size and mtime are unchanged): cache=True keeps it beside the FASTA (`<filename>.brx2bit`); the default
+        (cache=None: what `badread simulate` does) uses such a file when there is one and otherwise keeps its own in the user
+        cache directory (BADREAD_AMD_CACHE, default ~/.cache/badread_amd: 0.25 bytes per base), so that the second run on a
+        genome starts in a fraction of a second instead of re-reading 3 GB of text; BRX_REFERENCE_CACHE=0 (or cache=False)
+        packs every time and writes nothing."""
         import os
+        beside = str(filename) + '.brx2bit'
         if cache is None:
-            cache = os.environ.get('BRX_REFERENCE_CACHE', '') not in ('', '0')
-        return cls._from_native(filename, cache)
+            env = os.environ.get('BRX_REFERENCE_CACHE', '')
+            if env == '0':
+                cache = False
+            elif env not in ('', 'auto'):
+                cache = True
+        if cache is True:
+            return cls._from_native(filename, [beside], beside)
+        if cache is False:
+            return cls._from_native(filename, [], None)
+        own = None
+        from .error_model import user_cache_dir
+        try:
+            worth_it = os.path.getsize(str(filename)) >= (64 << 20)       # a bacterial genome packs in milliseconds: nothing to keep
+        except OSError:
+            worth_it = False
+        d = user_cache_dir() if worth_it else None
+        if d:
+            import hashlib
+            own = os.path.join(d, 'ref-' + hashlib.sha256(os.path.abspath(str(filename)).encode()).hexdigest()[:24] + '.brx2bit')
+        return cls._from_native(filename, [beside] + ([own] if own else []), own)
 
     @classmethod
     def from_fasta_python(cls, filename):
@@ -100,29 +130,34 @@ class PackedReference(object):
         return cls.from_seqs(*load_fasta(filename))
 
     @classmethod
-    def _from_native(cls, filename, cache):
+    def _from_native(cls, filename, sidecars, save_to):
+        """sidecars: candidate files, first match wins; save_to: where a freshly packed reference is kept (None: nowhere)."""
         import ctypes
         lib = host_library()
         err = ctypes.create_string_buffer(512)
         handle = ctypes.c_void_p()
         name = str(filename).encode()
-        sidecar = name + b'.brx2bit'
         rc = -1
-        if cache:
-            rc = lib.brx_fasta_load(name, sidecar, ctypes.byref(handle), err, len(err))
+        for sidecar in sidecars:
+            rc = lib.brx_fasta_load(name, sidecar.encode(), ctypes.byref(handle), err, len(err))
+            if rc == 0:
+                break
         if rc != 0:
             rc = lib.brx_fasta_pack(name, ctypes.byref(handle), err, len(err))
             if rc != 0:
                 raise ValueError(err.value.decode('latin-1') or f'could not read {filename}')
-            if cache:
-                lib.brx_fasta_save(handle, name, sidecar, err, len(err))      # best effort: a read-only directory is fine
+            if save_to:
+                lib.brx_fasta_save(handle, name, save_to.encode(), err, len(err))      # best effort: a read-only directory is fine
+        self = cls()
         try:
             v = FastaView()
             lib.brx_fasta_view_of(handle, ctypes.byref(v))
-            self = cls()
             nc = int(v.n_contigs)
             self.n_bases = int(v.n_bases)
-            self.packed = np.ctypeslib.as_array(v.packed, shape=(int(v.n_words),)).copy()
+            # the words stay where the native object holds them -- the mapped sidecar, or the packer's vector -- for as long as
+            # this object lives (a human genome is 772 MB: every copy is a third of a second of start-up)
+            self.packed = np.ctypeslib.as_array(v.packed, shape=(int(v.n_words),))
+            self._native = (lib, handle)
             self.contigs = np.frombuffer(ctypes.string_at(v.contigs, nc * CONTIG_DTYPE.itemsize), dtype=CONTIG_DTYPE).copy()
             ne = int(v.n_exceptions)
             self.exceptions = (np.frombuffer(ctypes.string_at(v.exceptions, ne * EXCEPTION_DTYPE.itemsize), dtype=EXCEPTION_DTYPE).copy()
@@ -131,8 +166,10 @@ class PackedReference(object):
             depths = np.ctypeslib.as_array(v.depths, shape=(nc,)).copy()
             self.sym = np.frombuffer(bytes(v.sym), dtype=np.uint8).copy()
             self.comp = np.frombuffer(bytes(v.comp), dtype=np.uint8).copy()
-        finally:
-            lib.brx_fasta_free(handle)
+        except BaseException:
+            if getattr(self, '_native', None) is None:
+                lib.brx_fasta_free(handle)
+            raise
         for i in range(nc):
             ct = self.contigs[i]
             n = self.names_pool[int(ct['name_off']):int(ct['name_off']) + int(ct['name_len'])].decode('latin-1')

@@ -332,16 +332,43 @@ class _HostRing(object):
         self.defer_errors = False                   # multi-rank runs: a failed sink is reported through the per-batch exchange, so that every rank stops at the same batch
         self.sink = None
         self.sink_seconds = self.alloc_seconds = 0.0
+        self.copy_stream = None                     # device -> pinned copies of the batches' bytes (write)
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
+
+    def prealloc(self, nbytes):
+        """Page-lock the ring's buffers NOW, on a thread of their own, while the first device batch computes (pinning 3 x 2.5 GB
+        is ~1 s that the consumer thread spent at its first writes: profiles/r04_cli_30x.json, ring_alloc 0.95 s)."""
+        import threading
+        if not self.pinned or nbytes <= 0:
+            return
+        slots = []
+        while True:                                  # take the empty slots; whatever is in use already stays as it is
+            try:
+                slots.append(self.free.get_nowait())
+            except Exception:
+                break
+
+        def make():
+            for slot in slots:
+                if slot is None:
+                    try:
+                        slot = self.torch.empty(int(nbytes), dtype=self.torch.uint8, pin_memory=True)
+                    except Exception:                # not fatal: stage() allocates what it needs
+                        slot = None
+                self.free.put(slot)
+        threading.Thread(target=make, daemon=True).start()
 
     def _run(self):
         while True:
             item = self.todo.get()
             if item is None:
                 return
-            buf, n = item
+            buf, n, landed, _source = item
             try:
+                if landed is not None:              # the copy into `buf` runs on the ring's own stream: sleep until it has landed
+                    while not landed.query():       # (event.synchronize() spins a core on this stack)
+                        time.sleep(0.0002)
                 if self.error is None and n:
                     t0 = time.perf_counter()
                     self.sink(memoryview(buf.numpy())[:n])
@@ -364,12 +391,26 @@ class _HostRing(object):
         return buf
 
     def write(self, tensor):
-        """Copy a uint8 tensor (device or host) into a ring buffer and queue it for the sink."""
+        """Copy a uint8 tensor (device or host) into a ring buffer and queue it for the sink.  A device tensor is copied
+        ASYNCHRONOUSLY on the ring's own stream: the consumer thread goes on to the next batch (stop rule, refill of the pipeline)
+        while the bytes cross PCIe, and the writer thread waits for the copy, not the consumer -- on configs[4] the consumer spent
+        5.0 of the read loop's 9.1 s inside blocking copies (profiles/r04_cli_30x_hifi.json).  The source tensor travels with
+        the queue entry so that its memory is not reused before the copy has read it."""
         n = int(tensor.numel())
         buf = self.stage(n)
-        if n:
+        landed = None
+        if n and self.pinned and tensor.is_cuda and not os.environ.get('BRX_SYNC_COPY_OUT'):
+            torch = self.torch
+            if self.copy_stream is None:
+                self.copy_stream = torch.cuda.Stream(device=tensor.device)
+            self.copy_stream.wait_stream(torch.cuda.current_stream(tensor.device))     # the tensor's producer has been waited for on the current stream
+            with torch.cuda.stream(self.copy_stream):
+                buf[:n].copy_(tensor, non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(self.copy_stream)
+        elif n:
             buf[:n].copy_(tensor, non_blocking=False)
-        self.todo.put((buf, n))
+        self.todo.put((buf, n, landed, tensor if landed is not None else None))
 
     def flush(self, reraise=True):
         self.todo.put(None)
@@ -561,6 +602,8 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         ring = _HostRing(torch, pinned=pool.on_gpu)
         ring.sink = local_write if local_write is not None else write
         ring.defer_errors = shard.world > 1
+        if pool.on_gpu and out_bytes and target_size > 3 * max_batch * expected_mean:      # a job of several full batches: all the buffers will be needed
+            ring.prealloc(int(1.25 * out_bytes))
     sink_failed_on = None
     dev_staging = {}
 
@@ -751,6 +794,10 @@ class _PartsLog(object):
 # ---------------------------------------------------------------------------------------------
 def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
     """Same contract as badread.simulate.simulate(args, output): FASTQ to stdout, the rest to `output`."""
+    marks = [('enter_simulate', time.time())]           # wall-clock marks of the start-up (BRX_DRIVER_TIMING: tools/cli_30x.sh)
+
+    def mark(name):
+        marks.append((name, time.time()))
     shard = shard or Shard.from_env()
     quiet = _Null() if shard.rank != 0 else output
     print_intro(quiet)
@@ -760,15 +807,18 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
     random.seed(seed)
     host_rng = np.random.RandomState(seed % (2 ** 32))
     pref = load_packed_reference(args.reference, quiet)
+    mark('reference_loaded')
     frag_lengths = FragmentLengths(args.mean_frag_length, args.frag_length_stdev, quiet)
     depths = adjust_depths(pref, frag_lengths, args.small_plasmid_bias, host_rng)
     identities = Identities(args.mean_identity, args.identity_stdev, args.max_identity, quiet)
     if engine is None:
         from .engine import default_engine
         engine = default_engine()
+    mark('engine_created')
     # a model file that is not in the cache is aligned (align_kmers, error_model.py:179-229) on THIS engine
     error_model = ErrorModel(args.error_model, quiet, aligner=lambda qs, ts: engine.align_batch(qs, ts)[0])
     qscore_model = QScoreModel(args.qscore_model, quiet)
+    mark('models_loaded')
     print_glitch_summary(args.glitch_rate, args.glitch_size, args.glitch_skip, quiet)
     start_rate, start_amount = adapter_parameters(args.start_adapter)
     end_rate, end_amount = adapter_parameters(args.end_adapter)
@@ -781,10 +831,12 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
 
     _, cum_weight = pref.contig_weights(depths)
     engine.set_reference(pref, cum_weight)
+    mark('reference_on_device')
     engine.set_error_model(error_model.tables())
     engine.set_qscore_model(qscore_model.tables())
     engine.set_params(sim_params_from_args(args, frag_lengths, identities, start_rate, start_amount,
                                            end_rate, end_amount))
+    mark('tables_on_device')
     sink = stdout if stdout is not None else getattr(sys.stdout, 'buffer', None)
     gzip_level = getattr(args, 'gzip_level', None)
     device_gzip = bool(getattr(args, 'gzip_device', False))
@@ -866,6 +918,11 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
         t = dict(run_batches.last_timing)
         t['bases'], t['reads'] = result[1], result[0]
         print('driver_timing ' + repr({k: round(float(v), 3) for k, v in t.items()}), file=sys.stderr)
+        mark('done')
+        t0 = float(os.environ.get('BRX_T0', marks[0][1]))      # epoch seconds at which the shell started the command, if it says so
+        steps = {'interpreter_and_imports': marks[0][1] - t0}
+        steps.update({name: at - before for (name, at), (_, before) in zip(marks[1:], marks[:-1])})
+        print('startup_timing ' + repr({k: round(float(v), 3) for k, v in steps.items()}), file=sys.stderr)
     return result
 
 
