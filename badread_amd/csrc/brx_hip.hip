@@ -183,7 +183,10 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *v = getenv("BRX_FIN_SPREAD"); c->fin_spread = v ? atoi(v) : 1; }
     { const char *v = getenv("BRX_QUAD_WAVES_PER_CU"); c->quad_wpc = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 4u; }
     { const char *v = getenv("BRX_FIN_LANES"); c->fin_lanes = v ? atoi(v) : 1; }
-    { const char *v = getenv("BRX_FIN_QUAD"); c->fin_quad = v ? (atoi(v) & 3) : 3; }
+    /* default: the one-word class only.  Measured on configs[3] (profiles/r05a): 5.30 Gbases/s with it against 5.22 without; the
+       two-word class (bit 1: 14-26 superblocks of 32 rows as 7-13 of 64) costs 20.6 instructions per read column where the whole-wave
+       kernel costs 25 -- the per-lane bookkeeping of four rows eats the lanes it saves -- on half the waves: 4.62-4.67 with both */
+    { const char *v = getenv("BRX_FIN_QUAD"); c->fin_quad = v ? (atoi(v) & 3) : 1; }
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 512u; }
     { const char *v = getenv("BRX_STAGE_WORDS"); c->stage_words = v ? std::min<uint32_t>((uint32_t)atoi(v), (uint32_t)BRX_STAGE_WORDS) : (uint32_t)BRX_STAGE_WORDS; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }

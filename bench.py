@@ -252,10 +252,12 @@ def aligner_lane_model(stats):
     for _ in range(12):
         g = np.where(bw > 56.0 * 32.0 * g, g * 2.0, g)
     lanes = np.full_like(bw, 64.0)
-    if os.environ.get('BRX_FIN_QUAD', '3') != '0':
-        # four reads per wave (k_fin_quad, csrc/brx_quad.h): a row of 16 lanes x 1 word up to 13 x 32 diagonals, x 2 words up to 13 x 64
-        # (reads with symbols outside ACGT keep to the whole wave: not visible in the statistics, a few per thousand)
-        quad1, quad2 = bw <= 13.0 * 32.0, (bw > 13.0 * 32.0) & (bw <= 13.0 * 64.0)
+    quad_bits = int(os.environ.get('BRX_FIN_QUAD', '1') or 0)
+    if quad_bits:
+        # four reads per wave (k_fin_quad, csrc/brx_quad.h): a row of 16 lanes x 1 word up to 13 x 32 diagonals (the default), x 2 words
+        # up to 13 x 64 (BRX_FIN_QUAD=3); reads with symbols outside ACGT keep to the whole wave: not visible in the statistics, a few per thousand
+        quad1 = (bw <= 13.0 * 32.0) & bool(quad_bits & 1)
+        quad2 = (bw > 13.0 * 32.0) & (bw <= 13.0 * 64.0) & bool(quad_bits & 2)
         lanes = np.where(quad1 | quad2, 16.0, lanes)
         g = np.where(quad2, 2.0, g)
     useful = float((n * bw / 32.0)[live].sum())

@@ -29,7 +29,7 @@ ROUTES = [{}, {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '0'}, {'BRX_TAIL_REA
           {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '0', 'BRX_STAGE_WORDS': '2560'}]
 # routes of the final stage with four alignments per wave (k_fin_quad; on by default): without the one-read-per-lane class so that
 # narrow bands go through it too, one word class only, window misses repeated by k_fin_align, few slabs, and switched off
-QUAD_ROUTES = [{'BRX_FIN_LANES': '0'}, {'BRX_FIN_QUAD': '1'}, {'BRX_FIN_QUAD': '2', 'BRX_FIN_LANES': '0'}, {'BRX_FIN_QUAD': '0'},
+QUAD_ROUTES = [{'BRX_FIN_LANES': '0', 'BRX_FIN_QUAD': '3'}, {'BRX_FIN_QUAD': '3'}, {'BRX_FIN_QUAD': '2', 'BRX_FIN_LANES': '0'}, {'BRX_FIN_QUAD': '0'},
                {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '-1'}, {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '0', 'BRX_QUAD_WAVES_PER_CU': '1', 'BRX_WAVES_PER_CU': '1'},
                {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '1', 'BRX_TAIL_READS': '2', 'BRX_HEAD_READS': '3'}]
 ROUTES += QUAD_ROUTES

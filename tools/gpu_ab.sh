@@ -8,7 +8,8 @@ import json, sys
 try:
     d = json.loads(sys.stdin.read()); s = d['stage_ms_per_device_batch']; k = d['kernels_per_device_batch']
     print('[$envs | $args]', round(d['value'] / 1e9, 3), 'Gbases/s  mutate', round(s['mutate'], 1), 'final', round(s['final'], 1), {n: (v.get('launches'), round(v.get('ms', 0), 1)) for n, v in k.items() if v.get('ms', 0) > 15},
-          'retries', d.get('scratch_or_output_retries'), 'misses', d.get('traceback_window_misses_per_step'), 'slabs', d.get('final_stage_launches_per_device_batch'))
+          'retries', d.get('scratch_or_output_retries'), 'misses', d.get('traceback_window_misses_per_step'), 'host_cores', round(d.get('host_cpu', {}).get('busy_cores_per_rank', 0), 2),
+          'lanes', round(d.get('roofline_alu', {}).get('useful_lane_frac_aligner_model') or 0, 3))
 except Exception as ex:
     print('[$envs | $args] failed:', ex, open('/tmp/err.txt').read()[-300:])"
 done
