@@ -602,7 +602,10 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         ring = _HostRing(torch, pinned=pool.on_gpu)
         ring.sink = local_write if local_write is not None else write
         ring.defer_errors = shard.world > 1
-        if pool.on_gpu and out_bytes and target_size > 3 * max_batch * expected_mean:      # a job of several full batches: all the buffers will be needed
+        # (Pinning the ring's buffers on a thread of their own beside the first batch looked free and was not: 3 x 2.6 GB of
+        #  hipHostMalloc ran against the clone threads' 40 GB arenas and every clone took 1.1 s instead of 0.05 -- 5.6 s of
+        #  wait_for_engine, profiles/r05b_cli_30x.json.  BRX_RING_PREALLOC=1 keeps the experiment reachable.)
+        if pool.on_gpu and out_bytes and os.environ.get('BRX_RING_PREALLOC') and target_size > 3 * max_batch * expected_mean:
             ring.prealloc(int(1.25 * out_bytes))
     sink_failed_on = None
     dev_staging = {}
