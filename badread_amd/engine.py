@@ -396,14 +396,19 @@ class HipEngine(EngineBase):
         if self._stats is None or self._stats.numel() < need:
             self._stats = self.torch.empty(int(need), dtype=self.torch.uint8, device=self.device)
 
-    def presize(self, n_reads, mean_length):
+    def presize(self, n_reads, mean_length, error_rate=None):
         """Size the scratch arena for device batches of `n_reads` reads of `mean_length` bases BEFORE the first batch, so that a
         large job does not discover its arena by repeating batches (BRX_E_SCRATCH -> grow -> run again).  Per simulated base:
         fragment, replacement words, read + qualities + ops, col_of[] = 13.5 B; traceback slabs ~35 B per base up to ~20 GB (the
         final align kernels hold at most 2048 / 1024 / 512 / 256 slabs); per-wave window scratch and move-code stores of the
         mutate stage.  An estimate: the library still reports what it needs if this is short."""
         bases = float(n_reads) * (float(mean_length) + 14.0)
-        est = 13.5 * bases + min(35.0 * bases, 20e9) + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 512.0) * 6.6e6 + (64 << 20)
+        # The slabs follow the edits per base (band width x window height): 35 B per base at the 5 % of nanopore2023 defaults, ~2 B
+        # at Q30 reads since the narrow-band class walks its traceback in strips (measured, profiles/r05d: 6.4 GB per 65536-read batch
+        # of configs[4] including col_of[]).  A job whose identity law is known sizes for it -- every GB of arena is 14-29 ms of the
+        # driver clearing it, per engine -- and the library asks for more if this is short (one repeated batch).
+        per_base = 35.0 if error_rate is None else min(35.0, max(3.0, 35.0 * float(error_rate) / 0.05))
+        est = 13.5 * bases + min(per_base * bases, 20e9) + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 512.0) * 6.6e6 + (64 << 20)
         self._ensure_scratch(int(est))
 
     # ------------------------------------------------------------------ configuration

@@ -64,6 +64,20 @@ def host_library():
     return _host_lib
 
 
+class _NativeFasta(object):
+    """Owner of a brx_fasta object (the packer's vector or the mapped sidecar).  The packed words are handed out as a numpy view
+    whose buffer holds a reference to this object, so the memory lives exactly as long as anything can still read it -- an
+    engine that was given `pref.packed` may outlive the PackedReference it came from."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+
+    def __del__(self):
+        handle, self.handle = self.handle, None
+        if handle is not None:
+            self.lib.brx_fasta_free(handle)
+
+
 class PackedReference(object):
     """Packed genome + per-contig metadata.  Build with from_fasta() or from_seqs()."""
 
@@ -82,13 +96,7 @@ class PackedReference(object):
         self.sym = np.zeros(16, dtype=np.uint8)
         self.comp = np.zeros(16, dtype=np.uint8)
         self.code_of = {}
-        self._native = None          # (library, handle) of the native object `packed` points into, if any
-
-    def __del__(self):
-        native, self._native = getattr(self, '_native', None), None
-        if native is not None:
-            self.packed = np.zeros(1, dtype=np.uint32)       # never leave a view of freed / unmapped memory behind
-            native[0].brx_fasta_free(native[1])
+        self._native = None          # the native object `packed` is a view of, if any (the view itself keeps it alive: _NativeFasta)
 
     @classmethod
     def from_fasta(cls, filename, cache=None):
@@ -156,8 +164,11 @@ class PackedReference(object):
             self.n_bases = int(v.n_bases)
             # the words stay where the native object holds them -- the mapped sidecar, or the packer's vector -- for as long as
             # this object lives (a human genome is 772 MB: every copy is a third of a second of start-up)
-            self.packed = np.ctypeslib.as_array(v.packed, shape=(int(v.n_words),))
-            self._native = (lib, handle)
+            keeper = _NativeFasta(lib, handle)
+            words = (ctypes.c_uint32 * int(v.n_words)).from_address(ctypes.addressof(v.packed.contents))
+            words._keeper = keeper                          # every numpy view of the words keeps `words`, and so the mapping, alive
+            self.packed = np.frombuffer(words, dtype=np.uint32)
+            self._native = keeper
             self.contigs = np.frombuffer(ctypes.string_at(v.contigs, nc * CONTIG_DTYPE.itemsize), dtype=CONTIG_DTYPE).copy()
             ne = int(v.n_exceptions)
             self.exceptions = (np.frombuffer(ctypes.string_at(v.exceptions, ne * EXCEPTION_DTYPE.itemsize), dtype=EXCEPTION_DTYPE).copy()

@@ -545,7 +545,7 @@ class _BatchPool(object):
 
 
 def run_batches(engine, seed, target_size, mean_length, write, output, shard=None, max_batch=None, in_flight=1, device_gzip=False,
-                local_write=None, local_parts=None):
+                local_write=None, local_parts=None, expected_error=None):
     """
     The `while total_size < target_size` loop (simulate.py:63-86) over super-batches of read indices.
     `write(bytes_like)` receives the FASTQ bytes in read order on rank 0 only.  Returns (read count, total bases).
@@ -584,7 +584,10 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     t_job = t0
     if hasattr(engine, 'presize'):               # the arena of the first engine (the clones copy its size) for the batches this job will issue
         first_batch = plan_batch(target_size, expected_mean, shard.world, max_batch) // shard.world
-        engine.presize(first_batch, expected_mean)
+        if expected_error is None:
+            engine.presize(first_batch, expected_mean)
+        else:                                    # the job's identity law: arenas for Q30 reads are half those of 95 % reads
+            engine.presize(first_batch, expected_mean, expected_error)
         out_bytes = int(first_batch * (2.1 * expected_mean + 400.0))
     else:
         out_bytes = 0
@@ -757,6 +760,16 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     return count, total
 
 
+def expected_error_rate(identities):
+    """Mean errors per base of the job's identity law (beta: 1 - mean; qscore-normal: E[10^(-q / 10)]): what the traceback stores of
+    a batch grow with (engine.presize)."""
+    import math
+    if identities.type == 'beta':
+        return min(max(1.0 - float(identities.mean), 0.0), 1.0)
+    sigma = float(identities.stdev) * math.log(10.0) / 10.0
+    return min(10.0 ** (-float(identities.mean) / 10.0) * math.exp(0.5 * sigma * sigma), 1.0)
+
+
 class _PartsLog(object):
     """PREFIX.<rank>.parts (and .zparts): a line per batch once the batch's bytes have gone through the sink.  batch() is called by the
     consumer thread in batch order, wrote() by the ring's writer thread after every write of the sink; a batch's bytes are written
@@ -899,7 +912,7 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
         try:
             result = run_batches(engine, seed, target_size, float(args.mean_frag_length), write, quiet, shard,
                                  in_flight=getattr(args, 'gpu_streams', None) or DEFAULT_IN_FLIGHT, device_gzip=device_gzip,
-                                 local_write=local_write, local_parts=local_parts)
+                                 local_write=local_write, local_parts=local_parts, expected_error=expected_error_rate(identities))
             if prefix and hasattr(shard_sink, 'flush') and shard_sink is not shard_file:
                 shard_sink.flush()
         finally:

@@ -135,3 +135,22 @@ def test_library_exports_every_symbol_of_brx_host_h():
     lib = host_library()
     for name in names:
         assert getattr(lib, name) is not None, name
+
+
+def test_the_packed_words_outlive_the_reference_object(tmp_path):
+    """The packed words are a VIEW of the native object (the mapped sidecar, the packer's vector): an engine that was handed
+    `pref.packed` keeps reading them after the PackedReference is gone (tests/oracle_slice_worker.py builds its workload in an
+    expression) -- the view must keep the mapping alive.  Found on the GPU box as a crash of the oracle workers."""
+    import gc
+    rng = np.random.default_rng(3)
+    p = tmp_path / 'keep.fasta'
+    p.write_text('>a\n' + ''.join(rng.choice(list('ACGT'), 100000)) + '\n>b circular=true\n' + ''.join(rng.choice(list('ACGTN'), 5000)) + '\n')
+    for cache in (False, True, True):                     # packed, packed + saved, mapped from the sidecar
+        pref = PackedReference.from_fasta(str(p), cache=cache)
+        want = pref.packed.copy()
+        view = pref.packed
+        del pref
+        gc.collect()
+        junk = [np.zeros(1 << 20, dtype=np.uint8) for _ in range(8)]      # give freed memory a chance to be reused
+        assert np.array_equal(view, want)
+        del junk
