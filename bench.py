@@ -431,8 +431,26 @@ def main():
                 raise a['error']
         return acc
 
+    w_t0, w_cpu0 = time.perf_counter(), time.process_time()
     run_steps(list(range(args.warmup)) if args.warmup else [])
+    warm_busy = (time.process_time() - w_cpu0) / max(time.perf_counter() - w_t0, 1e-9)      # host cores this rank kept busy while warming up
     barrier()
+    if dist is not None and args.warmup:
+        # N > 1 on one node: every rank drives its batches with host threads, and the node has `usable_cores` for all of them
+        # (1.2-1.5 cores per rank measured at N = 1).  Say so BEFORE the timed region, and refuse a run the host would throttle:
+        # its number would measure the CPUs, not the GPUs.  BRX_BENCH_ALLOW_OVERSUBSCRIBED=1 runs it anyway.
+        tb = torch.tensor([warm_busy], dtype=torch.float64, device='cpu' if dry else 'cuda')
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        busy_all = float(tb.item())
+        if rank == 0:
+            print(f'[bench] host cores busy during warm-up: {warm_busy:.2f} on rank 0, {busy_all:.2f} on all {world} ranks, {usable_cores()} usable', file=sys.stderr, flush=True)
+        if busy_all > 1.25 * usable_cores() and not os.environ.get('BRX_BENCH_ALLOW_OVERSUBSCRIBED'):      # (warm-up steps cost more host time than steady ones: a margin)
+            if rank == 0:
+                print(json.dumps({'error': 'host CPU oversubscribed', 'busy_cores_all_ranks_during_warmup': busy_all, 'usable_cores': usable_cores(), 'n_gpus': world,
+                                  'note': 'the ranks need more host cores than the node gives this container: the number would measure the host; '
+                                          'BRX_BENCH_ALLOW_OVERSUBSCRIBED=1 runs anyway'}), flush=True)
+            dist.destroy_process_group()
+            sys.exit(3)
     t0 = time.perf_counter()
     cpu0 = time.process_time()
     acc = run_steps([args.warmup + k for k in range(args.steps)])
