@@ -771,17 +771,22 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                                  reinterpret_cast<unsigned long long *>(cq + 18), d_slabs + slab_at[6], misses, Fbuf, c->scratch, c->scratch, slab_base, clk); }
             score_class(6, cls_stream[1], cq + 21);
         }
+        /* (round 5: the by-lane and four-per-wave classes ran in front of the one-word class on the set's own stream -- 11 + 18 ms
+           that the 85 ms of k_fin_align<1,1,1> waited for in a batch alone on the chip, profiles/r05_batch_timeline.json; they go
+           where the classes are shortest: by lane behind the two-word class, four per wave behind the four-word class) */
+        hipStream_t lanes_stream = (spread && cnt[0]) ? cls_stream[1] : cls_stream[0];
+        hipStream_t quad_stream = (spread && cnt[0]) ? cls_stream[2] : cls_stream[0];
         if (cnt[4]) {                                 /* the narrow-band class, one read per lane: with pacbio2021 / --identity 30,3 nearly every read */
-            { KTIMED(BRX_KERN_FIN_LANES, cls_stream[0]);
-              hipLaunchKernelGGL(k_fin_lanes, dim3(grid[4]), dim3(64), 0, cls_stream[0], dev, rs, d_lists + list_at[4], cnt[4],
+            { KTIMED(BRX_KERN_FIN_LANES, lanes_stream);
+              hipLaunchKernelGGL(k_fin_lanes, dim3(grid[4]), dim3(64), 0, lanes_stream, dev, rs, d_lists + list_at[4], cnt[4],
                                  reinterpret_cast<unsigned long long *>(cq + 12), d_slabs + slab_at[4], misses, Fbuf, c->scratch, c->scratch, slab_base, clk); }
-            score_class(4, cls_stream[0], cq + 14);
+            score_class(4, lanes_stream, cq + 14);
         }
         if (cnt[5]) {                                 /* bands of up to 13 superblocks, four reads per wave */
-            { KTIMED(BRX_KERN_FIN_QUAD1, cls_stream[0]);
-              hipLaunchKernelGGL((k_fin_quad<1>), dim3(grid[5]), dim3(64), 0, cls_stream[0], dev, rs, d_lists + list_at[5], cnt[5],
+            { KTIMED(BRX_KERN_FIN_QUAD1, quad_stream);
+              hipLaunchKernelGGL((k_fin_quad<1>), dim3(grid[5]), dim3(64), 0, quad_stream, dev, rs, d_lists + list_at[5], cnt[5],
                                  reinterpret_cast<unsigned long long *>(cq + 16), d_slabs + slab_at[5], misses, Fbuf, c->scratch, c->scratch, slab_base, clk); }
-            score_class(5, cls_stream[0], cq + 20);
+            score_class(5, quad_stream, cq + 20);
         }
         if (cnt[0]) {
             { KTIMED(BRX_KERN_FIN_ALIGN1, cls_stream[0]);
