@@ -61,6 +61,7 @@ struct brx_ctx {
     hipEvent_t ev_fork3, ev_join3[2];   /* the bulk set's band classes on the head chain's streams */
     int fin_spread;                      /* BRX_FIN_SPREAD (default 1) */
     uint32_t quad_wpc;                   /* BRX_QUAD_WAVES_PER_CU (default 4): most waves per CU of one k_fin_quad launch (four reads each) */
+    uint32_t quad_min_reads;             /* BRX_QUAD_MIN_READS (default 4096): a set with fewer four-per-wave reads aligns them on whole waves */
     int fin_lanes;                       /* BRX_FIN_LANES (default 1): narrow-band final alignments one read per lane (k_fin_lanes) */
     int fin_quad;                        /* BRX_FIN_QUAD (default 3): final alignments four per wave (k_fin_quad); bit 0: one-word bands, bit 1: two-word bands */
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
@@ -182,6 +183,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         (e = hipEventCreateWithFlags(&c->ev_join3[1], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *v = getenv("BRX_FIN_SPREAD"); c->fin_spread = v ? atoi(v) : 1; }
     { const char *v = getenv("BRX_QUAD_WAVES_PER_CU"); c->quad_wpc = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 4u; }
+    { const char *v = getenv("BRX_QUAD_MIN_READS"); c->quad_min_reads = v ? (uint32_t)atoi(v) : 4096u; }
     { const char *v = getenv("BRX_FIN_LANES"); c->fin_lanes = v ? atoi(v) : 1; }
     /* default: the one-word class only.  Measured on configs[3] (profiles/r05a): 5.30 Gbases/s with it against 5.22 without; the
        two-word class (bit 1: 14-26 superblocks of 32 rows as 7-13 of 64) costs 20.6 instructions per read column where the whole-wave
@@ -331,6 +333,7 @@ extern "C" uint32_t brx_last_window_misses(const brx_ctx *c) { return c ? c->win
 /* Small transfers between the arena and the context's pinned blocks, as a kernel on the stream: one wave for a few words, a few
    dozen for the read states.  (The runtime's copy is a blit kernel with its own launch geometry; VERDICT r4: 1495 dispatches,
    10.8 % of the summed kernel time of the bench, 3.65 ms each in the six-batch mix against 15 us alone.) */
+#define BRX_COPY_KERNEL_MAX ((size_t)1 << 20)       /* larger transfers go through hipMemcpyAsync (pinned on the host side: a DMA) */
 __global__ void __launch_bounds__(64) k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (size_t)gridDim.x * 64) dst[i] = src[i];
 }
@@ -343,7 +346,9 @@ static uint8_t *pinned_alias(brx_ctx *c, const void *h) {        /* device view 
 }
 /* device -> pinned host (bytes a multiple of 4); the host reads the block after waiting for the stream */
 static int to_host(brx_ctx *c, hipStream_t st, void *h_dst, const void *d_src, size_t bytes) {
-    uint8_t *alias = c->blit ? nullptr : pinned_alias(c, h_dst);
+    /* the read states of a batch (10 MB, three times per batch) stay with the runtime's copy engine: as a kernel over PCIe they cost
+       configs[4], whose batches take 0.4 s, 1.5 % (profiles/r05g); the kernels are for the few-word read-backs that sat behind blits */
+    uint8_t *alias = (c->blit || bytes > BRX_COPY_KERNEL_MAX) ? nullptr : pinned_alias(c, h_dst);
     if (!alias || (bytes & 3)) { HIPCHK(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st)); return BRX_OK; }
     const size_t n = bytes / 4;
     hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n + 255) / 256, 128)), dim3(64), 0, st, (uint32_t *)alias, (const uint32_t *)d_src, n);
@@ -351,7 +356,7 @@ static int to_host(brx_ctx *c, hipStream_t st, void *h_dst, const void *d_src, s
 }
 /* pinned host -> device; the host block must not change until the stream has been waited for */
 static int to_device(brx_ctx *c, hipStream_t st, void *d_dst, const void *h_src, size_t bytes) {
-    uint8_t *alias = c->blit ? nullptr : pinned_alias(c, h_src);
+    uint8_t *alias = (c->blit || bytes > BRX_COPY_KERNEL_MAX) ? nullptr : pinned_alias(c, h_src);
     if (!alias || (bytes & 3)) { HIPCHK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st)); return BRX_OK; }
     const size_t n = bytes / 4;
     hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n + 255) / 256, 128)), dim3(64), 0, st, (uint32_t *)d_dst, (const uint32_t *)alias, n);
@@ -581,6 +586,12 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         std::vector<uint32_t> cls_list[NCLS];
         std::vector<uint64_t> cls_units[NCLS];
         uint64_t col_total = 0;
+        /* Four per wave pays when the class fills the chip: a group is as slow as its longest read plus four tracebacks, and a
+           class of a few hundred groups is all tail.  configs[4] (1509 such reads beside 63 435 by lane) lost 4 % to it
+           (17.2 against 17.9 Gbases/s, profiles/r05g); below BRX_QUAD_MIN_READS the set's reads keep to whole waves. */
+        uint32_t n_quad_flagged = 0;
+        for (uint32_t i = S.b; i < S.e; ++i) { const RS &r = h_rs[h_order[i]]; n_quad_flagged += (r.n && (r.klass & BRX_KL_QUAD)) ? 1u : 0u; }
+        const bool use_quad = n_quad_flagged >= c->quad_min_reads;
         for (uint32_t i = S.b; i < S.e; ++i) {
             const RS &r = h_rs[h_order[i]];
             const uint64_t col_units = r.n ? ((((uint64_t)r.m * 4 + 7) / 8 + 2 + 31) & ~31ull) : 0;
@@ -597,7 +608,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 cls_units[4].push_back(((uint64_t)r.n << 8) | (uint64_t)brx_finl_blocks(r.m, r.n, r.ub));     /* sorted by fragment length below; units per group follow */
                 continue;
             }
-            if ((r.klass & BRX_KL_QUAD) && phase == 0) {     /* a miss is repeated by k_fin_align (k_fin_quad clears the flag) */
+            if ((r.klass & BRX_KL_QUAD) && phase == 0 && use_quad) {     /* a miss is repeated by k_fin_align (k_fin_quad clears the flag) */
                 const BrxGeom gq = brx_make_geom_quad((int)r.m, (int)r.n, (int)r.ub, (r.klass & BRX_KL_FULL) ? 0 : c->tb_hmul);
                 const int kq = gq.G == 2 ? 6 : 5;
                 cls_list[kq].push_back(h_order[i]);
@@ -855,11 +866,14 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         }
         { int rc_ = fetch_rs(S.st); if (rc_) return rc_; }
         { int rcw = wait_stream(c, S.st, "k_fin_join"); if (rcw) return rcw; }
+        uint32_t n_quad_set = 0;
+        for (uint32_t i = S.b; i < S.e; ++i) { const RS &r = h_rs[h_order[i]]; n_quad_set += (r.n && (r.klass & BRX_KL_QUAD)) ? 1u : 0u; }
+        const bool quad_on = n_quad_set >= c->quad_min_reads;          /* as launch_final_phase decides */
         for (uint32_t i = S.b; i < S.e; ++i) {
             const RS &r = h_rs[h_order[i]];
             if (!r.n) continue;
             const uint32_t kl = r.klass & 0xFFFFu;
-            S.bases_by_class[(r.klass & BRX_KL_LANES) ? 5 : (r.klass & BRX_KL_QUAD) ? (brx_quad_words(r.m, r.n, r.ub) == 2 ? 7 : 6) : kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3] += r.n;
+            S.bases_by_class[(r.klass & BRX_KL_LANES) ? 5 : ((r.klass & BRX_KL_QUAD) && quad_on) ? (brx_quad_words(r.m, r.n, r.ub) == 2 ? 7 : 6) : kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3] += r.n;
             S.bases_by_class[4] += r.n;
         }
         return launch_final_phase(S, 0);

@@ -256,8 +256,10 @@ def aligner_lane_model(stats):
     if quad_bits:
         # four reads per wave (k_fin_quad, csrc/brx_quad.h): a row of 16 lanes x 1 word up to 13 x 32 diagonals (the default), x 2 words
         # up to 13 x 64 (BRX_FIN_QUAD=3); reads with symbols outside ACGT keep to the whole wave: not visible in the statistics, a few per thousand
-        quad1 = (bw <= 13.0 * 32.0) & bool(quad_bits & 1)
-        quad2 = (bw > 13.0 * 32.0) & (bw <= 13.0 * 64.0) & bool(quad_bits & 2)
+        quad1 = (bw <= 13.0 * 32.0) & (bw > 88.0) & live & bool(quad_bits & 1)      # (up to 88 diagonals: the one-read-per-lane class)
+        quad2 = (bw > 13.0 * 32.0) & (bw <= 13.0 * 64.0) & live & bool(quad_bits & 2)
+        if int((quad1 | quad2).sum()) < int(os.environ.get('BRX_QUAD_MIN_READS', '4096')):      # a small class keeps to whole waves (brx_hip.hip)
+            quad1 = quad2 = np.zeros_like(live)
         lanes = np.where(quad1 | quad2, 16.0, lanes)
         g = np.where(quad2, 2.0, g)
     useful = float((n * bw / 32.0)[live].sum())

@@ -85,8 +85,8 @@ ROUTES = [
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_FIN_LANES': 0},        # no read aligned by lane in the final stage (short nanopore reads are, by default)
     {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 0},       # pass waves never stage a read in LDS: 2-bit codes from global memory, changed test on repl[]
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 120},   # a slice of 120 words: reads up to 1.2 kb staged, longer ones beside them from global memory
-    {'BRX_FIN_LANES': 0, 'BRX_FIN_QUAD': 3},                   # narrow bands too go four per wave, a row of 16 lanes each (k_fin_quad), instead of one read per lane; both word classes
-    {'BRX_FIN_LANES': 0, 'BRX_TB_WINDOW': -1},                 # ... and the misses of an 8-row traceback window are repeated by k_fin_align with the full store
+    {'BRX_FIN_LANES': 0, 'BRX_FIN_QUAD': 3, 'BRX_QUAD_MIN_READS': 0},   # narrow bands too go four per wave, a row of 16 lanes each (k_fin_quad), instead of one read per lane; both word classes
+    {'BRX_FIN_LANES': 0, 'BRX_TB_WINDOW': -1, 'BRX_QUAD_MIN_READS': 0},   # ... and the misses of an 8-row traceback window are repeated by k_fin_align with the full store
     {'BRX_FIN_QUAD': 0, 'BRX_FIN_LANES': 0},                   # every final alignment on a whole wave
 ]
 
@@ -243,7 +243,7 @@ def test_four_final_alignments_per_wave(case, monkeypatch):
                   'two_words': (SimParams(frag_mean=3000, frag_stdev=1000, identity_mode=0, id_max=0.80), 10, 'k_fin_quad<2>'),
                   'long': (SimParams(frag_mean=9000, frag_stdev=500, identity_mode=0, id_max=0.97), 5, 'k_fin_quad<1>')}[case]
     orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
-    eng = H.configure(emu_engine(monkeypatch, BRX_FIN_LANES=0 if case == 'one_word' else 1, BRX_FIN_QUAD=3 if case == 'two_words' else 1), pref, 'nanopore2023', 'nanopore2023', p)
+    eng = H.configure(emu_engine(monkeypatch, BRX_FIN_LANES=0 if case == 'one_word' else 1, BRX_FIN_QUAD=3 if case == 'two_words' else 1, BRX_QUAD_MIN_READS=0), pref, 'nanopore2023', 'nanopore2023', p)
     eng.set_kernel_timing(True)
     out_o, st_o = orc.simulate_batch(5, 0, n)
     out_h, st_h = eng.simulate_batch(5, 0, n)
@@ -267,7 +267,7 @@ def test_final_stage_with_fewer_slabs_than_reads(quad, small, monkeypatch):
         # (with four reads per wave the slabs fit any arena that holds the rest of the batch: there the second engine is limited to
         #  one slab-owning wave per CU of the two-CU interpreted chip instead)
         eng = H.configure(emu_engine(monkeypatch, scratch=scratch or 1 << 29, BRX_TB_WINDOW=0, BRX_WIN_KB=128, BRX_FIN_LANES=0, BRX_FIN_QUAD=quad,
-                                     BRX_QUAD_WAVES_PER_CU=4 if scratch else 1), pref, 'nanopore2023', 'nanopore2023', p)
+                                     BRX_QUAD_MIN_READS=0, BRX_QUAD_WAVES_PER_CU=4 if scratch else 1), pref, 'nanopore2023', 'nanopore2023', p)
         out_h, st_h = eng.simulate_batch(8, 0, 28)
         slabs.append(eng.final_launches())
         for f in STAT_FIELDS:

@@ -98,10 +98,10 @@ def test_sequence_fragments_matches_oracle():
                                  {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0', 'BRX_STAGE_WORDS': '0'},    # pass waves never stage a read in LDS
                                  {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_STAGE_WORDS': '500'},   # short reads staged, long ones not
                                  {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0', 'BRX_WAVES_PER_CU': '1'},      # 256 slab-owning waves per band class
-                                 {'BRX_FIN_LANES': '0', 'BRX_FIN_QUAD': '3'},                                  # narrow bands four per wave (k_fin_quad) instead of one per lane; both word classes
-                                 {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '-1'},                                # ... their window misses repeated by k_fin_align
+                                 {'BRX_FIN_LANES': '0', 'BRX_FIN_QUAD': '3', 'BRX_QUAD_MIN_READS': '0'},                               # narrow bands four per wave (k_fin_quad) instead of one per lane; both word classes
+                                 {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '-1', 'BRX_QUAD_MIN_READS': '0'},     # ... their window misses repeated by k_fin_align
                                  {'BRX_FIN_QUAD': '0'},                                                        # no final alignment four per wave
-                                 {'BRX_FIN_QUAD': '1', 'BRX_QUAD_WAVES_PER_CU': '1'}])                         # one-word quads only, one slab-owning wave per CU
+                                 {'BRX_FIN_QUAD': '1', 'BRX_QUAD_WAVES_PER_CU': '1', 'BRX_QUAD_MIN_READS': '0'}])                         # one-word quads only, one slab-owning wave per CU
 def test_alternative_kernel_routes_give_the_same_bytes(env, monkeypatch):
     """The optional routes (full / 8-row / narrow traceback window of the final alignment -- the 8-row window
     makes most reads miss and repeat with the full store --, in-place mutate alignments, lane- or wave-per-window

@@ -32,6 +32,8 @@ ROUTES = [{}, {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '0'}, {'BRX_TAIL_REA
 QUAD_ROUTES = [{'BRX_FIN_LANES': '0', 'BRX_FIN_QUAD': '3'}, {'BRX_FIN_QUAD': '3'}, {'BRX_FIN_QUAD': '2', 'BRX_FIN_LANES': '0'}, {'BRX_FIN_QUAD': '0'},
                {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '-1'}, {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '0', 'BRX_QUAD_WAVES_PER_CU': '1', 'BRX_WAVES_PER_CU': '1'},
                {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '1', 'BRX_TAIL_READS': '2', 'BRX_HEAD_READS': '3'}]
+for _r in QUAD_ROUTES:
+    _r.setdefault('BRX_QUAD_MIN_READS', '0')          # the class is used only when it holds thousands of reads by default
 ROUTES += QUAD_ROUTES
 
 
