@@ -770,23 +770,12 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                                  reinterpret_cast<unsigned long long *>(cq + 4), d_slabs + slab_at[2], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk); }
             score_class(2, cls_stream[2], cq + 11);
         }
-        if (cnt[1]) {
-            { KTIMED(BRX_KERN_FIN_ALIGN2, cls_stream[1]);
-              hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(grid[1]), dim3(64), 0, cls_stream[1], dev, rs, d_lists + list_at[1], cnt[1],
-                                 reinterpret_cast<unsigned long long *>(cq + 2), d_slabs + slab_at[1], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk); }
-            score_class(1, cls_stream[1], cq + 10);
-        }
-        if (cnt[6]) {                                 /* bands of 14-26 superblocks of 32 rows, as two-word superblocks four reads per wave */
-            { KTIMED(BRX_KERN_FIN_QUAD2, cls_stream[1]);
-              hipLaunchKernelGGL((k_fin_quad<2>), dim3(grid[6]), dim3(64), 0, cls_stream[1], dev, rs, d_lists + list_at[6], cnt[6],
-                                 reinterpret_cast<unsigned long long *>(cq + 18), d_slabs + slab_at[6], misses, Fbuf, c->scratch, c->scratch, slab_base, clk); }
-            score_class(6, cls_stream[1], cq + 21);
-        }
         /* (round 5: the by-lane and four-per-wave classes ran in front of the one-word class on the set's own stream -- 11 + 18 ms
-           that the 85 ms of k_fin_align<1,1,1> waited for in a batch alone on the chip, profiles/r05_batch_timeline.json; they go
-           where the classes are shortest: by lane behind the two-word class, four per wave behind the four-word class) */
+           that the 85 ms of k_fin_align<1,1,1> waited for in a batch alone on the chip; behind the two- and four-word classes on
+           the side streams they ended the batch instead -- the third stream is the head set's widest class's until 360 ms into a
+           454 ms batch.  Both go IN FRONT of the two-word class: 35 + 44 ms beside the one-word class's 82.) */
         hipStream_t lanes_stream = (spread && cnt[0]) ? cls_stream[1] : cls_stream[0];
-        hipStream_t quad_stream = (spread && cnt[0]) ? cls_stream[2] : cls_stream[0];
+        hipStream_t quad_stream = lanes_stream;
         if (cnt[4]) {                                 /* the narrow-band class, one read per lane: with pacbio2021 / --identity 30,3 nearly every read */
             { KTIMED(BRX_KERN_FIN_LANES, lanes_stream);
               hipLaunchKernelGGL(k_fin_lanes, dim3(grid[4]), dim3(64), 0, lanes_stream, dev, rs, d_lists + list_at[4], cnt[4],
@@ -798,6 +787,18 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
               hipLaunchKernelGGL((k_fin_quad<1>), dim3(grid[5]), dim3(64), 0, quad_stream, dev, rs, d_lists + list_at[5], cnt[5],
                                  reinterpret_cast<unsigned long long *>(cq + 16), d_slabs + slab_at[5], misses, Fbuf, c->scratch, c->scratch, slab_base, clk); }
             score_class(5, quad_stream, cq + 20);
+        }
+        if (cnt[1]) {
+            { KTIMED(BRX_KERN_FIN_ALIGN2, cls_stream[1]);
+              hipLaunchKernelGGL((k_fin_align<2, 2, 2>), dim3(grid[1]), dim3(64), 0, cls_stream[1], dev, rs, d_lists + list_at[1], cnt[1],
+                                 reinterpret_cast<unsigned long long *>(cq + 2), d_slabs + slab_at[1], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk); }
+            score_class(1, cls_stream[1], cq + 10);
+        }
+        if (cnt[6]) {                                 /* bands of 14-26 superblocks of 32 rows, as two-word superblocks four reads per wave */
+            { KTIMED(BRX_KERN_FIN_QUAD2, cls_stream[1]);
+              hipLaunchKernelGGL((k_fin_quad<2>), dim3(grid[6]), dim3(64), 0, cls_stream[1], dev, rs, d_lists + list_at[6], cnt[6],
+                                 reinterpret_cast<unsigned long long *>(cq + 18), d_slabs + slab_at[6], misses, Fbuf, c->scratch, c->scratch, slab_base, clk); }
+            score_class(6, cls_stream[1], cq + 21);
         }
         if (cnt[0]) {
             { KTIMED(BRX_KERN_FIN_ALIGN1, cls_stream[0]);
