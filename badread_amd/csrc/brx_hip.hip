@@ -747,7 +747,19 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(grid[3]), dim3(64), 0, S.wide, dev, rs, d_lists + list_at[3], cnt[3],
                                reinterpret_cast<unsigned long long *>(cq + 6), d_slabs + slab_at[3], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
         }
-        if (fork) { HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true; }
+        if (fork) {
+            /* ... and is scored there as well.  (Until round 5 the set's own stream waited for the wide stream at this point and
+               scored the class itself: for the head set that stream is `side`, the wait was enqueued when the head's final stage
+               was launched, and everything the BULK set later put on `side` -- its two-word class -- sat behind the head's
+               widest alignments: 391 ms into a 454 ms batch alone on the chip, profiles/r05_batch_timeline.json.  The host waits
+               for both streams in finish_final instead.) */
+            if (cnt[3]) {
+                KTIMED(BRX_KERN_FIN_QSCORE, S.wide);
+                hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.wide, dev, rs, order, b, e,
+                                   cq + 9, phase, 5, 0xFFFF, c->scratch, c->scratch, col_base, clk);
+            }
+            HIPCHK(c, hipEventRecord(c->ev_join2[S.id], S.wide)); S.wide_forked = true;
+        }
         /* The 4-, 2- and 1-word classes are independent (own lists, own slabs), each scored (k_fin_qscore on its class-pure list) as
            soon as it is aligned.  The bulk set spreads them over the head chain's two streams, which are idle by the time the
            bulk passes end (round 3 ran the three classes and their scoring one after the other on the set's stream: ~490 ms of
@@ -812,8 +824,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join3[0], 0));
             HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join3[1], 0));
         }
-        if (fork) HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join2[S.id], 0));
-        if (cnt[3]) {
+        if (cnt[3] && !fork) {
             KTIMED(BRX_KERN_FIN_QSCORE, S.st);
             hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
                                cq + 9, phase, 5, 0xFFFF, c->scratch, c->scratch, col_base, clk);
@@ -884,6 +895,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     auto finish_final = [&](FinalSet &S) -> int {
         if (S.e == S.b) return BRX_OK;
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);
+        if (S.wide != S.st) { int rcw = wait_stream(c, S.wide, "final stage, widest class"); if (rcw) return rcw; }      /* its misses are counted before the counter is read */
         { int rc_ = to_host(c, S.st, h_ctr, set_counter(S, 1), 4); if (rc_) return rc_; }
         { int rcw = wait_stream(c, S.st, S.id ? "final stage (bulk)" : "final stage (head)"); if (rcw) return rcw; }
         const uint32_t misses = h_ctr[0];
@@ -893,6 +905,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         { int rcw_ = wait_stream(c, S.st, "final stage, misses"); if (rcw_) return rcw_; }
         int rcp = launch_final_phase(S, 1);
         if (rcp) return rcp;
+        if (S.wide != S.st) { int rcw = wait_stream(c, S.wide, "final stage, second phase, widest class"); if (rcw) return rcw; }
         return wait_stream(c, S.st, "final stage, second phase");
     };
 
