@@ -402,7 +402,10 @@ class _HostRing(object):
         if n and self.pinned and tensor.is_cuda and not os.environ.get('BRX_SYNC_COPY_OUT'):
             torch = self.torch
             if self.copy_stream is None:
-                self.copy_stream = torch.cuda.Stream(device=tensor.device)
+                # (a high-priority stream for the copy was measured: BRX_COPY_PRIORITY=-1 made configs[4]'s read loop 9.8 s against 8.8 s at the
+                #  default priority, profiles/r05h; the copy itself runs at 57 GB/s on an idle GPU: tools/d2h_probe.py)
+                prio = int(os.environ.get('BRX_COPY_PRIORITY', '0'))
+                self.copy_stream = torch.cuda.Stream(device=tensor.device, priority=prio)
             self.copy_stream.wait_stream(torch.cuda.current_stream(tensor.device))     # the tensor's producer has been waited for on the current stream
             with torch.cuda.stream(self.copy_stream):
                 buf[:n].copy_(tensor, non_blocking=True)
