@@ -90,3 +90,56 @@ def test_pmc_traffic_all_carries_every_kernel_that_may_rank_first(tmp_path):
     assert abs(k['k_mutate_seg<false>']['hbm_bytes_per_launch'] - (2 * 1000.0 + 500.0) * 1024 / 128) < 1e-6      # per pass: every dispatch
     assert abs(k['k_mutate_seg<true>']['hbm_bytes_per_launch'] - (2 * 4000.0 + 2000.0) * 1024 / 4) < 1e-6          # the priming launch is not a full-size one
     assert abs(k['k_fin_align<1,1,1>']['hbm_bytes_per_launch'] - (2 * 900.0 + 600.0) * 1024 / 2) < 1e-6
+
+
+TRACE = """Kernel_Name,Start_Timestamp,End_Timestamp,Queue_Id
+"k_plan_count(BrxDev, RS*)",1000000,1100000,4
+"k_mutate_seg<false, false, 4>(BrxDev)",1200000,3200000,4
+"void k_fin_align<16, 8, 65535>(BrxDev)",3300000,9300000,2
+"void k_fin_align<1, 1, 1>(BrxDev)",5000000,12000000,4
+"void k_fin_quad<1>(BrxDev)",5100000,6100000,1
+"k_emit(BrxDev)",12100000,12500000,4
+"""
+
+
+def test_batch_timeline_says_whether_the_widest_class_ends_the_batch(tmp_path):
+    """tools/batch_timeline.py (the timeline, not the argument): per kernel first start / last end of the
+    LAST batch of a kernel trace, and whether k_fin_align<16,8,...> ends after the bulk set's final alignments."""
+    import json
+    path = tmp_path / 'kernel_trace.csv'
+    warm = TRACE.replace('Kernel_Name,Start_Timestamp,End_Timestamp,Queue_Id\n', '')
+    # two batches: the tool reports the second one (everything from the last k_plan_count on)
+    second = []
+    for ln in warm.strip().splitlines():
+        name, rest = ln.rsplit('",', 1)
+        a, b, q = rest.split(',')
+        second.append(f'{name}",{int(a) + 20000000},{int(b) + 20000000},{q}')
+    path.write_text(TRACE + '\n'.join(second) + '\n')
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'tools', 'batch_timeline.py'), str(path)], capture_output=True, text=True, check=True).stdout
+    d = json.loads(out)
+    assert abs(d['batch_ms'] - 11.5) < 1e-6
+    assert d['kernels']['k_fin_align<16, 8, 65535>'] == {'first_start_ms': 2.3, 'last_end_ms': 8.3, 'busy_ms': 6.0, 'dispatches': 1, 'queues': ['2']}
+    assert d['widest_class_ends_ms'] == 8.3 and d['bulk_final_alignments_end_ms'] == 11.0 and d['widest_class_on_critical_path'] is False
+
+
+def test_parts_log_and_expected_error_rate():
+    """simulate._PartsLog: a .parts line when a batch is issued, a .zparts line once the batch's bytes are through the sink (whatever
+    the interleaving of consumer and writer thread); simulate.expected_error_rate: the arena's slabs are sized by it."""
+    import io
+    sys.path.insert(0, REPO)
+    from badread_amd import simulate as S
+    from badread_amd.identities import Identities
+    parts, zparts = io.StringIO(), io.StringIO()
+    z = {'out': 0}
+    log = S._PartsLog(parts, zparts, lambda: z['out'])
+    log.batch(100)                      # issued before anything was written
+    z['out'] += 40; log.wrote(60)       # first write of the batch: not complete yet
+    assert zparts.getvalue() == ''
+    z['out'] += 30; log.wrote(40)       # complete: 70 compressed bytes
+    log.batch(0)                        # a batch this rank keeps nothing of
+    z['out'] += 5; log.wrote(50); log.batch(50)      # written before the consumer logged it
+    assert parts.getvalue() == '100\n0\n50\n' and zparts.getvalue() == '70\n0\n5\n'
+    null = io.StringIO()
+    assert abs(S.expected_error_rate(Identities(95.0, 2.5, 99.0, null)) - 0.05) < 1e-12
+    q30 = S.expected_error_rate(Identities(30.0, 3.0, None, null))
+    assert 0.001 < q30 < 0.0014          # E[10^(-q/10)] for q ~ N(30, 3): a little above 10^-3
