@@ -302,6 +302,17 @@ class BrxError(RuntimeError):
         self.code = code
 
 
+def arena_estimate(n_reads, mean_length, error_rate=None):
+    """Bytes of scratch arena for device batches of `n_reads` reads of `mean_length` bases (HipEngine.presize): fragment,
+    replacement words, read + qualities + ops, col_of[] = 13.5 B per base; traceback slabs by the edits per base (35 B per base at
+    the 5 % of nanopore2023 defaults up to ~20 GB -- the final align kernels hold at most 2048 / 1024 / 512 / 256 slabs --, ~2 B
+    at Q30 reads since the narrow-band class walks its traceback in strips: measured, profiles/r05d: 6.4 GB per 65536-read batch of
+    configs[4] including col_of[]); per-wave window scratch and move-code stores of the mutate stage."""
+    bases = float(n_reads) * (float(mean_length) + 14.0)
+    per_base = 35.0 if error_rate is None else min(35.0, max(3.0, 35.0 * float(error_rate) / 0.05))
+    return int(13.5 * bases + min(per_base * bases, 20e9) + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 512.0) * 6.6e6 + (64 << 20))
+
+
 class HipEngine(EngineBase):
     """One context on one MI355X.  Not thread-safe; one engine per process per GPU."""
 
@@ -401,15 +412,14 @@ class HipEngine(EngineBase):
         large job does not discover its arena by repeating batches (BRX_E_SCRATCH -> grow -> run again).  Per simulated base:
         fragment, replacement words, read + qualities + ops, col_of[] = 13.5 B; traceback slabs ~35 B per base up to ~20 GB (the
         final align kernels hold at most 2048 / 1024 / 512 / 256 slabs); per-wave window scratch and move-code stores of the
-        mutate stage.  An estimate: the library still reports what it needs if this is short."""
-        bases = float(n_reads) * (float(mean_length) + 14.0)
-        # The slabs follow the edits per base (band width x window height): 35 B per base at the 5 % of nanopore2023 defaults, ~2 B
-        # at Q30 reads since the narrow-band class walks its traceback in strips (measured, profiles/r05d: 6.4 GB per 65536-read batch
-        # of configs[4] including col_of[]).  A job whose identity law is known sizes for it -- every GB of arena is 14-29 ms of the
-        # driver clearing it, per engine -- and the library asks for more if this is short (one repeated batch).
-        per_base = 35.0 if error_rate is None else min(35.0, max(3.0, 35.0 * float(error_rate) / 0.05))
-        est = 13.5 * bases + min(per_base * bases, 20e9) + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 512.0) * 6.6e6 + (64 << 20)
-        self._ensure_scratch(int(est))
+        mutate stage.  A job whose identity law is known sizes for it (error_rate): every GB of arena is 14-29 ms of the driver
+        clearing it, per engine.  An estimate: the library still reports what it needs if this is short (one repeated batch)."""
+        self._ensure_scratch(arena_estimate(n_reads, mean_length, error_rate))
+
+    def adopt_scratch(self, tensor):
+        """Use `tensor` (device uint8) as the arena from now on: the caller allocated it beside other work (simulate._ArenaPrefetch)."""
+        self._scratch = tensor
+        self._check(self.lib.brx_set_scratch(self.ctx, ctypes.c_void_p(self._scratch.data_ptr()), self._scratch.numel()))
 
     # ------------------------------------------------------------------ configuration
     def set_reference(self, pref, cum_weight=None):

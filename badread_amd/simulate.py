@@ -422,6 +422,71 @@ class _HostRing(object):
             raise self.error
 
 
+class _ArenaPrefetch(object):
+    """The job's scratch arenas, allocated by threads of their own from the moment the first engine exists -- beside the model
+    tables, the genome's upload and the first batch -- instead of when the read loop asks for them.  On a freshly leased GPU a
+    40 GB arena is ~4 s of `hipMalloc` (the driver provisions and clears the memory: 21 s of thread time for the five clones of a
+    30x human job, profiles/r05_cli_30x.json); started 1.4 s before the loop, the engines are there 1.4 s earlier.  take() hands
+    out the next arena (waiting for its thread) or None."""
+
+    def __init__(self, torch, device, nbytes, count):
+        import threading
+        self.nbytes, self.count = int(nbytes), int(count)
+        self.slots = [None] * self.count
+        self.errors = []
+        self.lock = threading.Lock()
+        self.next = 0
+        self.seconds = 0.0
+
+        def alloc(i):
+            t0 = time.perf_counter()
+            try:
+                torch.cuda.set_device(device)
+                self.slots[i] = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+            except BaseException as ex:                  # the taker allocates what it needs itself (and reports what fails then)
+                self.errors.append(ex)
+            with self.lock:
+                self.seconds += time.perf_counter() - t0
+        self.threads = [threading.Thread(target=alloc, args=(i,), daemon=True) for i in range(self.count)]
+        for th in self.threads:
+            th.start()
+
+    def take(self):
+        with self.lock:
+            i = self.next
+            if i >= self.count:
+                return None
+            self.next += 1
+        self.threads[i].join()
+        t, self.slots[i] = self.slots[i], None
+        return t
+
+    def release_rest(self):
+        while self.take() is not None:
+            pass
+
+    @staticmethod
+    def for_job(engine, target_size, mean_length, error_rate, in_flight, world):
+        """Arenas for the batches in flight of THIS job on THIS device, or None (not a GPU engine, a job of one small batch,
+        BRX_ARENA_PREFETCH=0).  How many: what the job will use and the free memory holds (_BatchPool.engines_that_fit's rule)."""
+        if getattr(getattr(engine, 'device', None), 'type', '') != 'cuda' or os.environ.get('BRX_ARENA_PREFETCH', '1') == '0':
+            return None
+        from .engine import arena_estimate
+        torch = engine.torch
+        first_batch = plan_batch(target_size, mean_length, world, DEFAULT_MAX_BATCH) // max(world, 1)
+        if first_batch < 4096:
+            return None                                  # a small job: one arena, sized by presize
+        nbytes = arena_estimate(first_batch, mean_length, error_rate)
+        out_bytes = int(first_batch * (2.1 * mean_length + 400.0))
+        batches = -(-int(target_size) // max(int(first_batch * mean_length * max(world, 1)), 1))
+        n = max(1, min(int(in_flight), batches))
+        free, _ = torch.cuda.mem_get_info(engine.device)
+        reserve = int(float(os.environ.get('BRX_DRIVER_RESERVE_GB', '24')) * (1 << 30))
+        while n > 1 and n * nbytes + (2 * n + 2) * out_bytes + reserve > free:
+            n -= 1
+        return _ArenaPrefetch(torch, engine.device, nbytes, n)
+
+
 class _BatchPool(object):
     """`in_flight` engines (the given one + clones sharing its device tables), each driven by its own host thread on
     its own HIP stream, so that several batches overlap on the GPU.
@@ -434,9 +499,10 @@ class _BatchPool(object):
     batch is done (2 GB at HBM speed: ~1 ms) and gives the engine back at once; `depth` = in_flight + 2 batches may be outstanding,
     the surplus holding only their bytes."""
 
-    def __init__(self, engine, in_flight):
+    def __init__(self, engine, in_flight, arenas=None):
         import concurrent.futures
         import queue
+        self.arenas = arenas
         self.engines = [engine]
         self.streams = [None]
         torch = getattr(engine, 'torch', None)           # absent on the tests' CPU checker engines
@@ -461,7 +527,8 @@ class _BatchPool(object):
             try:
                 if self.on_gpu:
                     torch.cuda.set_device(self.engines[0].device)
-                self.engines[i] = self.engines[0].clone()
+                spare = self.arenas.take() if self.arenas is not None else None       # allocated since the first engine exists, or None
+                self.engines[i] = self.engines[0].clone(scratch_tensor=spare) if spare is not None else self.engines[0].clone()
             except BaseException as ex:                  # this slot never joins the queue; engine 0 and the other clones carry on
                 with self.lock:
                     self.create_errors.append(ex)
@@ -548,7 +615,7 @@ class _BatchPool(object):
 
 
 def run_batches(engine, seed, target_size, mean_length, write, output, shard=None, max_batch=None, in_flight=1, device_gzip=False,
-                local_write=None, local_parts=None, expected_error=None):
+                local_write=None, local_parts=None, expected_error=None, arenas=None):
     """
     The `while total_size < target_size` loop (simulate.py:63-86) over super-batches of read indices.
     `write(bytes_like)` receives the FASTQ bytes in read order on rank 0 only.  Returns (read count, total bases).
@@ -587,7 +654,10 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     t_job = t0
     if hasattr(engine, 'presize'):               # the arena of the first engine (the clones copy its size) for the batches this job will issue
         first_batch = plan_batch(target_size, expected_mean, shard.world, max_batch) // shard.world
-        if expected_error is None:
+        first_arena = arenas.take() if arenas is not None else None
+        if first_arena is not None:              # allocated beside the start-up (simulate._ArenaPrefetch)
+            engine.adopt_scratch(first_arena)
+        elif expected_error is None:
             engine.presize(first_batch, expected_mean)
         else:                                    # the job's identity law: arenas for Q30 reads are half those of 95 % reads
             engine.presize(first_batch, expected_mean, expected_error)
@@ -595,13 +665,15 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     else:
         out_bytes = 0
     asked = fit = max(1, int(in_flight))
-    if fit > 1 and hasattr(engine, 'scratch_bytes') and getattr(getattr(engine, 'device', None), 'type', '') == 'cuda':
+    if arenas is not None and first_arena is not None:
+        fit = min(fit, arenas.count)             # decided when the arenas were requested, by the same rule, from the memory that was free then
+    elif fit > 1 and hasattr(engine, 'scratch_bytes') and getattr(getattr(engine, 'device', None), 'type', '') == 'cuda':
         fit = _BatchPool.engines_that_fit(engine.torch, engine, fit, out_bytes)
     if shard.world > 1:                          # the issue schedule depends on the depth of the pipeline: the same on every rank
         fit = min(int(x[0]) for x in shard.gather_words(np.array([fit], dtype=np.uint32), [1] * shard.world))
     if fit < asked and shard.rank == 0:
         print(f'  {fit} of the {asked} batches in flight asked for fit into the free device memory', file=output)
-    pool = _BatchPool(engine, fit)
+    pool = _BatchPool(engine, fit, arenas)
     timing['create_engines'] = time.perf_counter() - t0
     ring = None
     if local_write is not None or shard.rank == 0:
@@ -730,6 +802,9 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
                 pass
         t0 = time.perf_counter()
         pool.close()
+        if arenas is not None:                  # arenas no clone asked for (a job that stopped early, ranks that agreed on fewer engines)
+            arenas.release_rest()
+            timing['arena_prefetch_thread_seconds'] = arenas.seconds
         if gz_engine is not None and gz_engine is not engine:
             gz_engine.close()
         timing['close_engines'] = time.perf_counter() - t0
@@ -834,6 +909,9 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
         from .engine import default_engine
         engine = default_engine()
     mark('engine_created')
+    # the job's arenas from now on, beside everything below (models, genome upload, the first batch): _ArenaPrefetch
+    arenas = _ArenaPrefetch.for_job(engine, get_target_size(pref.n_bases, args.quantity), float(args.mean_frag_length),
+                                    expected_error_rate(identities), getattr(args, 'gpu_streams', None) or DEFAULT_IN_FLIGHT, shard.world)
     # a model file that is not in the cache is aligned (align_kmers, error_model.py:179-229) on THIS engine
     error_model = ErrorModel(args.error_model, quiet, aligner=lambda qs, ts: engine.align_batch(qs, ts)[0])
     qscore_model = QScoreModel(args.qscore_model, quiet)
@@ -915,7 +993,7 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
         try:
             result = run_batches(engine, seed, target_size, float(args.mean_frag_length), write, quiet, shard,
                                  in_flight=getattr(args, 'gpu_streams', None) or DEFAULT_IN_FLIGHT, device_gzip=device_gzip,
-                                 local_write=local_write, local_parts=local_parts, expected_error=expected_error_rate(identities))
+                                 local_write=local_write, local_parts=local_parts, expected_error=expected_error_rate(identities), arenas=arenas)
             if prefix and hasattr(shard_sink, 'flush') and shard_sink is not shard_file:
                 shard_sink.flush()
         finally:
