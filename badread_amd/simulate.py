@@ -469,7 +469,11 @@ class _ArenaPrefetch(object):
     def for_job(engine, target_size, mean_length, error_rate, in_flight, world):
         """Arenas for the batches in flight of THIS job on THIS device, or None (not a GPU engine, a job of one small batch,
         BRX_ARENA_PREFETCH=0).  How many: what the job will use and the free memory holds (_BatchPool.engines_that_fit's rule)."""
-        if getattr(getattr(engine, 'device', None), 'type', '') != 'cuda' or os.environ.get('BRX_ARENA_PREFETCH', '1') == '0':
+        # Opt-in (BRX_ARENA_PREFETCH=1).  Measured (profiles/r05i_arena_prefetch.json): the read loop then runs undisturbed -- 18.8 s for
+        # the 30x human job (23.7 without), 5.8 s = 16.0 Gbases/s for the configs[4] flavour (9.2 s) -- but the allocations hold a lock
+        # of the runtime that the genome's upload waits for (reference_on_device 0.2 -> 6.2 s), and the whole command takes what it took:
+        # 27.2 s against 26.1-27.0 s, 12.1 s against 11.6-12.4 s.  ~0.13 s of hipMalloc per GB of arena is the cost either way.
+        if getattr(getattr(engine, 'device', None), 'type', '') != 'cuda' or os.environ.get('BRX_ARENA_PREFETCH', '0') in ('', '0'):
             return None
         from .engine import arena_estimate
         torch = engine.torch
