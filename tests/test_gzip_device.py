@@ -243,7 +243,8 @@ def test_two_ranks_compress_their_own_bytes_and_rank_0_writes_one_stream(tmp_pat
     outfile = str(tmp_path / 'ranks.fastq.gz')
     script = tmp_path / 'worker.py'
     script.write_text(GZ_WORKER.format(repo=os.path.dirname(here), outfile=outfile))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    # (gloo and one device index for both ranks: the test also passes when it is run, unfiltered, on a box that has ONE GPU)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), BRX_DIST_BACKEND='gloo', BRX_DEVICE='0')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
                         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
                        env=env, capture_output=True, text=True, timeout=900)
