@@ -143,3 +143,40 @@ def test_parts_log_and_expected_error_rate():
     assert abs(S.expected_error_rate(Identities(95.0, 2.5, 99.0, null)) - 0.05) < 1e-12
     q30 = S.expected_error_rate(Identities(30.0, 3.0, None, null))
     assert 0.001 < q30 < 0.0014          # E[10^(-q/10)] for q ~ N(30, 3): a little above 10^-3
+
+
+def test_arena_prefetch_hands_out_what_its_threads_allocated():
+    """simulate._ArenaPrefetch (the job's arenas requested when the first engine exists): take() gives each arena once, in order,
+    waiting for its thread; a failed allocation is a None the taker replaces; nothing is left after release_rest()."""
+    sys.path.insert(0, REPO)
+    from badread_amd import simulate as S
+
+    class FakeCuda(object):
+        def set_device(self, device):
+            pass
+
+    class FakeTorch(object):
+        uint8 = 'u8'
+        cuda = FakeCuda()
+
+        def __init__(self):
+            self.made = 0
+
+        def empty(self, n, dtype=None, device=None):
+            self.made += 1
+            if self.made == 2:
+                raise MemoryError('no room')
+            return ('arena', n, device)
+
+    torch = FakeTorch()
+    pre = S._ArenaPrefetch(torch, 'dev0', 1000, 3)
+    got = [pre.take(), pre.take(), pre.take(), pre.take()]
+    assert got[3] is None and sum(1 for g in got[:3] if g == ('arena', 1000, 'dev0')) == 2 and sum(1 for g in got[:3] if g is None) == 1
+    assert len(pre.errors) == 1
+    pre.release_rest()
+    assert pre.take() is None
+    # not a GPU engine, or switched off: no prefetch at all
+
+    class Cpu(object):
+        device = None
+    assert S._ArenaPrefetch.for_job(Cpu(), 10 ** 12, 15000.0, 0.05, 6, 1) is None
