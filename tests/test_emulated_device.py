@@ -97,7 +97,7 @@ def test_pipeline_routes_equal_the_oracle(env, monkeypatch):
     p = SimParams(frag_mean=1100, frag_stdev=900)
     eng = H.configure(emu_engine(monkeypatch, **env), pref, 'nanopore2023', 'nanopore2023', p)
     orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
-    n = 40
+    n = 30
     out_h, st_h = eng.simulate_batch(42, 0, n)
     out_o, st_o = orc.simulate_batch(42, 0, n)
     for f in STAT_FIELDS:
