@@ -46,6 +46,8 @@ struct brx_ctx {
     uint32_t final_launches, mutate_passes;
     int mutate_inline;
     uint32_t seg_waves_per_cu;   /* BRX_SEG_WAVES_PER_CU: persistent waves of k_mutate_seg per CU */
+    uint32_t post_waves_per_cu;  /* BRX_POST_WAVES_PER_CU: waves of k_mut_post per CU (grid-stride over the pass's reads) */
+    int pass_seg;                /* BRX_PASS_SEG=1: bulk passes with the wave-per-read kernel of rounds 2-5 (k_mutate_seg<false>) */
     uint32_t tail_reads;         /* BRX_TAIL_READS: this few reads left in the mutate stage -> one in-place launch (0xFFFFFFFF = not set: n_reads / 8, at least 1024;
                                     measured on configs[3]: 1024 of 16384, 4096 of 49152) */
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
@@ -205,6 +207,8 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 0xFFFFFFFFu; }   /* unset: an eighth of the batch, at least 1024 */
     { const char *sw = getenv("BRX_SEG_WAVES_PER_CU"); c->seg_waves_per_cu = sw && atoi(sw) > 0 ? (uint32_t)atoi(sw) : 8u; }
     { const char *lt = getenv("BRX_LANE_THRESHOLD"); c->lane_threshold = lt ? (uint32_t)atoi(lt) : 3000u; }
+    { const char *v = getenv("BRX_POST_WAVES_PER_CU"); c->post_waves_per_cu = v ? std::max<uint32_t>(1u, (uint32_t)atoi(v)) : 32u; }
+    { const char *v = getenv("BRX_PASS_SEG"); c->pass_seg = v && atoi(v) != 0; }
     { const char *v = getenv("BRX_LANE_WAVES"); c->lane_waves = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 512u; }
     c->err[0] = 0;
     *out = c;
@@ -487,6 +491,10 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *active_head = (uint32_t *)A.take((size_t)n_reads * 4);
     uint8_t *winbuf = (uint8_t *)A.take((size_t)n_reads * BRX_WIN_STRIDE + 64);
     uint2 *lane_tb = (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
+    /* the bulk passes' survivor rings (brx_passes.h): 20 bytes per entry, BRX_SV_CAP entries per read */
+    PQ *pq = (PQ *)A.take((size_t)n_reads * sizeof(PQ));
+    uint4 *sv_a = (uint4 *)A.take((size_t)n_reads * BRX_SV_CAP * sizeof(uint4));
+    uint32_t *sv_z = (uint32_t *)A.take((size_t)n_reads * BRX_SV_CAP * sizeof(uint32_t));
     /* traceback stores of the packed window aligner: one set of 8 per wave of k_win_pack */
     const uint32_t pack_waves = std::min<uint32_t>((std::min<uint32_t>(n_reads, c->lane_threshold) + BRX_PACK_NG - 1) / BRX_PACK_NG, (uint32_t)c->n_cu * 4u);
     const uint32_t tail_eff = c->tail_reads != 0xFFFFFFFFu ? c->tail_reads : std::max<uint32_t>(1024u, n_reads / 8u);
@@ -911,6 +919,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
 
     { int rc_ = to_host(c, st, h_order, order, (size_t)n_reads * 4); if (rc_) return rc_; }
     HIPCHK(c, hipMemsetAsync(msv, 0, (size_t)n_reads * sizeof(MS), st));
+    HIPCHK(c, hipMemsetAsync(pq, 0, (size_t)n_reads * sizeof(PQ), st));
     HIPCHK(c, hipMemsetAsync(mctr, 0, 8 * MC_WORDS * sizeof(uint32_t), st));
     HIPCHK(c, hipMemsetAsync(lane_cls, 0, 2 * MC_WORDS * sizeof(uint32_t), st));
     {
@@ -951,6 +960,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     int rc2 = BRX_OK;
     if (n_mb) {
         const uint32_t seg_waves = std::min<uint64_t>(n_mb, (uint64_t)c->n_cu * (uint64_t)c->seg_waves_per_cu);
+        const uint32_t post_waves = std::min<uint64_t>(n_mb, (uint64_t)c->n_cu * (uint64_t)c->post_waves_per_cu);
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;                                 /* [0] count, [1] queue; not reset per pass */
         const uint32_t *n_in = mctr + 2 * MC_WORDS + MC_OUT;
@@ -988,7 +998,24 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             /* which window kernel follows is the HOST's choice (its count of active reads may be a few passes old): the segment
                kernel lists the windows for that kernel -- by band class for the lane kernel, one list for the packed one */
             const uint32_t lane_pass_thr = n_up > lane_threshold ? 0u : 0xFFFFFFFFu;
-            {
+            if (!c->pass_seg) {
+                /* round 6 (brx_passes.h): the survivors of a read are applied by ONE LANE from the read's ring (k_mut_apply), a
+                   wave per read parks the window or writes the epilogue and proposes ahead (k_mut_post) */
+                if (pass == 0) {                       /* the first rings: every bulk read is "not started" */
+                    KTIMED(BRX_KERN_MUT_POST, st);
+                    hipLaunchKernelGGL((k_mut_post<BRX_POST_U>), dim3(std::min(post_waves, n_up)), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in, act_out,
+                                       mctr + 7 * MC_WORDS, h_aux[0], Fbuf, repl, lane_pass_thr, F2buf, Cbuf, lane_cls + (pass & 1u) * MC_WORDS, sv_a, sv_z);
+                }
+                {
+                    KTIMED(BRX_KERN_MUTATE_SEG, st);
+                    hipLaunchKernelGGL(k_mut_apply, dim3((n_up + 63u) / 64u), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in, sv_a, sv_z, repl, Cbuf);
+                }
+                {
+                    KTIMED(BRX_KERN_MUT_POST, st);
+                    hipLaunchKernelGGL((k_mut_post<BRX_POST_U>), dim3(std::min(post_waves, n_up)), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in, act_out,
+                                       ctr, h_aux[0], Fbuf, repl, lane_pass_thr, F2buf, Cbuf, lane_cls + (pass & 1u) * MC_WORDS, sv_a, sv_z);
+                }
+            } else {
                 KTIMED(BRX_KERN_MUTATE_SEG, st);
                 if (c->profile)
                     hipLaunchKernelGGL((k_mutate_seg<false, true, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,

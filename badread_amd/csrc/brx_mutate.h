@@ -93,7 +93,11 @@ __shared__ uint32_t brx_stage_lds[BRX_STAGE_WORDS];
 /* the run-to-completion kernel never stages a read: its parking window is its own, smaller array (a 10 KB slice beside the
    aligner's 2 KB ring would keep a CU at 13 of its 16 waves) */
 __shared__ uint32_t brx_park_small_lds[(BRX_WIN_BYTES - BRX_WIN_Q) / 4 + 4];
-#define brx_park_lds (reinterpret_cast<uint8_t *>(PLANES ? brx_stage_lds : brx_park_small_lds))
+/* k_mut_post (brx_passes.h) parks with planes and stages nothing: its own window-sized array */
+#define BRX_POST_LDS_WORDS ((BRX_WIN_BYTES - BRX_WIN_Q) / 4 + 4)
+__shared__ uint32_t brx_post_lds[BRX_POST_LDS_WORDS];
+#define brx_park_lds (reinterpret_cast<uint8_t *>(!PLANES ? brx_park_small_lds : POST ? brx_post_lds : brx_stage_lds))
+#define brx_park_lds_rows ((uint32_t)((POST ? BRX_POST_LDS_WORDS : BRX_STAGE_WORDS) / 4))
 static_assert(BRX_STAGE_WORDS * 4 >= BRX_WIN_BYTES - BRX_WIN_Q + 16, "the parking window lives in the staging slice");
 struct __attribute__((packed, aligned(1))) BrxB16 { uint32_t x, y, z, w; };      /* sixteen bytes behind any address */
 static_assert(BRX_ALIGN_SIZE + 16 <= 1024 && BRX_WIN_Q >= 1024, "a window is 64 lanes x 16 positions");
@@ -109,7 +113,7 @@ __device__ __forceinline__ uint32_t brx_byte_bits(uint32_t v, int bit) { return 
  * neighbouring lanes per plane word.  (The loop over 64-position steps it replaces made ~45 dependent global round trips
  * per parked window -- fragment byte and replacement, pool characters, scan, stores, sixteen times over: 77 k of the ~290 k
  * cycles of a mutate cycle, profiles/r04b.)  Memory image of the slot: as before. */
-template <bool PLANES>
+template <bool PLANES, bool POST = false>
 __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F, const uint32_t *repl, uint32_t a, uint32_t b,
                                      uint8_t *qb, uint8_t *tbuf, uint32_t tmax, uint32_t *cost, bool *odd, uint32_t *pl = nullptr) {
     const int lane = lane_id();
@@ -188,7 +192,7 @@ __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F
         const uint32_t tl = run < BRX_PARK_LDS ? run : BRX_PARK_LDS;
         for (uint32_t g0 = 0; 16u * g0 < ((tl + 63u) & ~63u); g0 += 64u) {
             const uint32_t g = g0 + (uint32_t)lane;
-            const BrxU4 t4 = *reinterpret_cast<const BrxU4 *>(brx_park_lds + 16u * (g < (BRX_STAGE_WORDS / 4u) ? g : 0u));
+            const BrxU4 t4 = *reinterpret_cast<const BrxU4 *>(brx_park_lds + 16u * (g < brx_park_lds_rows ? g : 0u));
             const uint32_t tv[4] = {t4.x, t4.y, t4.z, t4.w};
             uint32_t lo = 0u, hi = 0u;
 #pragma unroll
@@ -317,17 +321,22 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
         bool parked = false;
       for (;;) {                                   /* INLINE: one trip per alignment of this read */
         errors = 0.0; loops = 0; change = 0; nalign = 0;
-        bool resume = ms.phase == 1u;
+        /* phase 4 (brx_passes.h, MP_HUNGRY): a read taken over from the bulk passes between two survivors, no alignment pending --
+           a resumed round at iteration round_loops (surv_lane = j_next = 0) whose errors are NOT blended */
+        const bool hungry = ms.phase == 4u;
+        bool resume = ms.phase == 1u || hungry;
         st_extra = ms.status;
         parked = false;
         if (resume) {
             errors = ms.errors; loops = ms.round_loops; change = ms.change; nalign = ms.nalign;
-            const double id = ms.res_ncols ? (double)ms.res_nmatch / (double)ms.res_ncols : 0.0;     /* misc.py:228-240 */
-            if (n <= BRX_ALIGN_SIZE) errors = (1.0 - id) * dn;                                       /* simulate.py:333 */
-            else {
-                const double est_err = (1.0 - id) * dn;
-                const double weight = (double)BRX_ALIGN_SIZE / dn;
-                errors = est_err * weight + errors * (1.0 - weight);                                 /* simulate.py:344-346 */
+            if (!hungry) {
+                const double id = ms.res_ncols ? (double)ms.res_nmatch / (double)ms.res_ncols : 0.0; /* misc.py:228-240 */
+                if (n <= BRX_ALIGN_SIZE) errors = (1.0 - id) * dn;                                   /* simulate.py:333 */
+                else {
+                    const double est_err = (1.0 - id) * dn;
+                    const double weight = (double)BRX_ALIGN_SIZE / dn;
+                    errors = est_err * weight + errors * (1.0 - weight);                             /* simulate.py:344-346 */
+                }
             }
         }
         bool done = !resume && need < 0.5;

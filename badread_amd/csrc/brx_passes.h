@@ -1,0 +1,323 @@
+/*
+ * brx_passes.h -- the BULK passes of the mutate loop (/root/reference/badread/simulate.py:272-346), round 6, included by
+ * brx_kernels.h behind brx_mutate.h.
+ *
+ * What the loop looks like from the hardware's side.  An iteration draws a position i, reads the k-mer of the ORIGINAL
+ * fragment there (simulate.py:296: `fragment[i:i+k_size]`, never `new_fragment_bases`) and asks the error model for an
+ * alternative (error_model.py:135-160).  Nothing of that depends on what earlier iterations did: the PROPOSAL of iteration t
+ * is a pure function of (seed, read, t) and the fragment.  Only what happens to the ~7 % of proposals that change the k-mer
+ * (the "survivors") is sequential: the changed-position test (simulate.py:309), the running error estimate with its
+ * `est ** 1.5` (:321) and the alignment every 25th change (:325-346).
+ *
+ * Rounds 2-5 ran both halves in one wave per read (k_mutate_seg<false>): 64 proposals, then the survivors one after the other
+ * by the wave -- seven of its 64 lanes take part in an application, one lane's worth of double arithmetic decides what follows --
+ * with three dependent table loads per round in front of every application.  profiles/r05_pmc_per_kernel.csv: 25.9 % of the
+ * path's wave-cycles, issuing in 34 % of them, 16.7 instructions per simulated base.  Here the halves are separate kernels, each
+ * shaped for what it does:
+ *
+ *   k_mut_post   1 wave = 1 read.  (a) What a wave is good at: parking the window of a read whose 25th change has just been
+ *                applied (wave_park: 64 lanes x 16 positions, planes by ballot), or the epilogue of a finished read.  (b) PROPOSE
+ *                AHEAD: 64 iterations per lane-round, BRX_POST_U rounds per trip with their table loads in flight together; the
+ *                survivors are appended, in iteration order, to the read's RING (BRX_SV_CAP entries of 20 bytes) until it holds
+ *                BRX_SV_STOCK of them.  No LDS staging, no loop state: the wave holds a handful of registers and many of them
+ *                fit a SIMD, so the three dependent loads of a proposal wait beside other waves' instead of in front of the
+ *                read's own next step.  A survivor that is not consumed in this pass stays in the ring: nothing is proposed twice.
+ *   k_mut_apply  1 LANE = 1 read.  Plain sequential code: take the read's survivors from its ring in order, test the changed
+ *                map, write replacement words, update the estimate -- until the 25th change (ask k_mut_post for a window), the end of
+ *                the loop (ask for the epilogue) or an empty ring (ask for more: "hungry", the read takes part in the next pass
+ *                without an alignment).  A read's map, replacement words and ring are touched by ONE lane, so program order is
+ *                all the ordering there is: no fences, no LDS.  64 reads share every instruction the old kernel issued for one.
+ *
+ * The pass is then {k_mut_apply, k_mut_post, k_win_lane | k_win_pack, k_win_wave}.  Results are identical to the sequential
+ * loop, and to k_mutate_seg<true> (which still runs the head set and the in-place tail and takes reads over in any state:
+ * MS keeps its meaning -- round_loops / surv_lane / j_next name the survivor to resume in).
+ */
+#ifndef BRX_PASSES_H
+#define BRX_PASSES_H
+
+#ifndef BRX_SV_CAP
+#define BRX_SV_CAP 256u                                  /* ring entries per read (power of two) */
+#endif
+#ifndef BRX_SV_STOCK
+#define BRX_SV_STOCK 56u                                 /* k_mut_post proposes until the ring holds this many survivors */
+#endif
+#ifndef BRX_POST_U
+#define BRX_POST_U 2                                     /* proposal rounds (of 64 iterations) in flight per trip */
+#endif
+static_assert((BRX_SV_CAP & (BRX_SV_CAP - 1u)) == 0u && BRX_SV_CAP >= 64u * BRX_POST_U + BRX_SV_STOCK, "ring: a power of two with room for a trip");
+
+/* ring bookkeeping of a read: sequence numbers of the first unconsumed and the first free entry, the first iteration that has
+   not been proposed yet (a multiple of 64 until the loop cap is reached) */
+struct PQ { uint32_t head, tail, next_t, pad; };
+
+/* MS.phase between the kernels of a pass (0-3 as in brx_mutate.h) */
+enum { MP_HUNGRY = 4,      /* ring empty, no alignment pending: resume at iteration round_loops (k_mutate_seg<true>: a resumed round without blending) */
+       MP_PARK = 5,        /* k_mut_apply -> k_mut_post: park the window; surv_lane / j_next say where the loop stopped */
+       MP_FINISH = 6 };    /* k_mut_apply -> k_mut_post: the loop is over (round_loops = loop_count), write the epilogue */
+
+/* iterations are counted in 32 bits here (RS.loops is 32 bits wide anyway): the reference's cap of 100 x frag_len iterations
+   (simulate.py:280) is applied as written for reads of up to 42.9 Mb and at 2^32 - 256 iterations beyond */
+__device__ __forceinline__ uint32_t brx_loop_cap32(uint32_t n) {
+    const uint64_t cap = 100ull * (uint64_t)n;
+    return cap > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)cap;
+}
+
+/* -------------------------------------------------------------------------------------------------
+ * k_mut_apply: one read per lane
+ * ----------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(64, 8) k_mut_apply(BrxDev d, const RS *rs, MS *msv, PQ *pq, const uint32_t *active_in, const uint32_t *n_in_ptr,
+                                                      const uint4 *sv_a, const uint32_t *sv_z, uint32_t *repl, uint32_t *Cbuf) {
+    const uint32_t idx = blockIdx.x * 64u + (uint32_t)lane_id();
+    if (idx >= *n_in_ptr) return;
+    const uint32_t r = active_in[idx];
+    const uint32_t n = rs[r].n;
+    if (n == 0u) return;
+    const brx_error_model &em = d.em;
+    const int k = em.k;
+    const uint64_t F_off = rs[r].F_off;
+    const double target = rs[r].target;
+    uint32_t *rp = repl + F_off;
+    uint32_t *cm = Cbuf + (F_off >> 4);
+    MS *mp = &msv[r];
+    const uint32_t phase = mp->phase;
+    const double dn = (double)n;
+    const uint32_t cap = brx_loop_cap32(n);
+    double errors = 0.0, est = 1.0;
+    uint32_t change = 0u, j0 = 0u;
+    bool fresh = true;                              /* est is 1 - errors / dn of the CURRENT errors */
+    uint32_t outcome = MP_HUNGRY, loops = 0u, t_at = 0u, jn = 0u;
+    bool over = false;
+    if (phase == 0u) {
+        if (dn * (1.0 - target) < 0.5) { over = true; outcome = MP_FINISH; loops = 0u; }                 /* simulate.py:274 */
+        else {
+            est = 1.0 - errors / dn;
+            if (est <= target) { over = true; outcome = MP_FINISH; loops = 1u; }                          /* :290-291 in iteration 1 */
+        }
+    } else {
+        errors = mp->errors; est = mp->est; change = mp->change;
+        if (phase == 1u) {                                                                                /* the window's alignment came back */
+            const uint32_t nc = mp->res_ncols, nm = mp->res_nmatch;
+            const double id = nc ? (double)nm / (double)nc : 0.0;                                         /* misc.py:228-240 */
+            if (n <= BRX_ALIGN_SIZE) errors = (1.0 - id) * dn;                                            /* simulate.py:333 */
+            else {
+                const double est_err = (1.0 - id) * dn;
+                const double weight = (double)BRX_ALIGN_SIZE / dn;
+                errors = est_err * weight + errors * (1.0 - weight);                                      /* simulate.py:344-346 */
+            }
+            j0 = mp->j_next;
+            fresh = false;                          /* the rest of this k-mer is applied with the estimate of its iteration (:321) */
+        }
+    }
+    PQ q = pq[r];
+    const uint4 *ra = sv_a + (size_t)r * BRX_SV_CAP;
+    const uint32_t *rz = sv_z + (size_t)r * BRX_SV_CAP;
+    while (!over) {
+        if (q.head == q.tail) {
+            if (q.next_t >= cap) { outcome = MP_FINISH; loops = cap + 1u; }                               /* :280-281 */
+            else { outcome = MP_HUNGRY; t_at = q.next_t; }
+            break;
+        }
+        const uint32_t slot = q.head & (BRX_SV_CAP - 1u);
+        const uint4 e = ra[slot];
+        const uint32_t pz = rz[slot];
+        const uint32_t t = e.x, i0 = e.y, px = e.z, py = e.w;
+        /* the changed map of positions i0 .. i0 + k - 1 */
+        const uint32_t wi = i0 >> 5, sh = i0 & 31u;
+        const uint32_t m0 = cm[wi], m1 = cm[wi + 1u];                                                     /* the word behind the map is the map of odd symbols: readable */
+        const uint64_t cur = ((((uint64_t)m1) << 32) | (uint64_t)m0) >> sh;
+        uint64_t set = 0ull;
+        bool applies = false, parked = false;
+        double scale = 0.0;
+        uint32_t before = 0u;
+        for (int j = 0; j < k; ++j) {
+            /* the replacement word of position j (brx_prop_word, one position at a time) */
+            uint32_t wj = 0u;
+            if (py & BRX_PROP_RANDOM) wj = (uint32_t)j == (py & 0xFFu) ? px : 0u;
+            else {
+                const uint32_t len = (py & 0x10000u) ? (uint32_t)em.d_pool[px + 2u + (uint32_t)j] : (j < 8 ? (pz >> (4u * (uint32_t)j)) & 15u : 0u);
+                if ((py >> j) & 1u) wj = 0x80000000u | (len << 24) | (px + 2u + (uint32_t)k + before);
+                before += len;
+            }
+            if ((uint32_t)j < j0 || wj == 0u || ((cur >> j) & 1ull)) continue;                            /* simulate.py:309 */
+            if (!applies) { applies = true; scale = est * brx_sqrt(est); }                                /* :321 */
+            rp[i0 + (uint32_t)j] = wj;
+            set |= 1ull << j;
+            change += 1u;
+            const uint32_t len = (wj >> 24) & 0x7Fu;
+            errors += (double)(len < 2u ? 1u : len - 1u) * scale;
+            if (change % BRX_ALIGN_INTERVAL == 0u) { parked = true; jn = (uint32_t)j + 1u; break; }      /* :325 */
+        }
+        if (set) {
+            const uint64_t add = set << sh;
+            if ((uint32_t)add) cm[wi] = m0 | (uint32_t)add;
+            if ((uint32_t)(add >> 32)) cm[wi + 1u] = m1 | (uint32_t)(add >> 32);
+        }
+        if (parked) { outcome = MP_PARK; t_at = t; break; }                                               /* the entry stays: the next pass resumes in it */
+        q.head += 1u;
+        j0 = 0u;
+        if (applies || !fresh) {                    /* top-of-loop tests of the iteration behind this survivor (:285-291) */
+            const double est2 = 1.0 - errors / dn;
+            if ((double)change > 0.9 * dn || est2 <= target) { outcome = MP_FINISH; loops = t + 2u; break; }
+            est = est2;
+            fresh = true;
+        }
+    }
+    pq[r].head = q.head;
+    mp->errors = errors; mp->est = est; mp->change = change;
+    if (outcome == MP_FINISH) mp->round_loops = (uint64_t)loops;
+    else { mp->round_loops = (uint64_t)(t_at & ~63u); mp->surv_lane = t_at & 63u; mp->j_next = outcome == MP_PARK ? jn : 0u; }
+    mp->phase = outcome;
+}
+
+/* -------------------------------------------------------------------------------------------------
+ * k_mut_post: one read per wave -- park / epilogue, then propose ahead
+ * ----------------------------------------------------------------------------------------------- */
+/* The proposal of iteration t of `read` (identical to the proposal round of k_mutate_seg): false = the k-mer stays. */
+__device__ __forceinline__ bool brx_propose_iter(const BrxDev &d, uint64_t read, uint32_t t, uint32_t max_i1, const uint32_t *f2g, const uint32_t *oddg,
+                                                 bool coded, const uint8_t *F, uint32_t *ipos_out, BrxProp *out) {
+    const brx_error_model &em = d.em;
+    const int k = em.k;
+    uint32_t w[4];
+    brx_draw4(d.seed, read, BRX_ST_MUT, (uint64_t)t, w);
+    const uint32_t ipos = (uint32_t)brx_mulhi64(((uint64_t)w[1] << 32) | w[0], (uint64_t)max_i1);
+    const uint32_t wi = ipos >> 4, sh = 2u * (ipos & 15u);
+    const uint32_t w0 = f2g[wi], w1 = f2g[wi + 1u];
+    const uint32_t row = (uint32_t)(((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) >> (64 - 2 * k));
+    bool bad = false;                               /* a symbol outside ACGT in the k-mer: error_model.py:142-143 */
+    if (!coded) {
+        const uint64_t both = (((uint64_t)oddg[(ipos >> 5) + 1u] << 32) | (uint64_t)oddg[ipos >> 5]) >> (ipos & 31u);
+        bad = (both & ((1ull << k) - 1ull)) != 0ull;
+    }
+    BrxProp pr;
+    if (bad) {
+        const BrxRc c = dev_random_change_split(w[3], k);
+        pr.x = dev_random_change_word(c, (uint32_t)F[ipos + c.pos]); pr.y = BRX_PROP_RANDOM | c.pos; pr.z = 0u;
+    } else pr = dev_propose_row(em, row, w[2], w[3]);
+    *ipos_out = ipos; *out = pr;
+    return pr.y != 0u;
+}
+
+template <int U>
+__global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, PQ *pq, const uint32_t *active_in, const uint32_t *n_in_ptr,
+                                                     uint32_t *active_out, uint32_t *ctr, const MutAux aux, const uint8_t *Fbuf, uint32_t *repl,
+                                                     uint32_t lane_threshold, const uint32_t *F2buf, const uint32_t *Cbuf, uint32_t *lane_cls,
+                                                     uint4 *sv_a, uint32_t *sv_z) {
+    const int lane = lane_id();
+    const brx_error_model &em = d.em;
+    const int k = em.k;
+    const uint32_t n_in = uni(*n_in_ptr);
+    for (uint32_t qi = blockIdx.x; qi < n_in; qi += gridDim.x) {
+        const uint32_t r = uni(active_in[qi]);
+        const RS s = rs[r];
+        if (s.n == 0) continue;
+        const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+        MS ms = msv[r];
+        const uint32_t n = s.n;
+        const uint8_t *F = Fbuf + s.F_off;
+        uint32_t *rp = repl + s.F_off;
+        uint64_t *ck = aux.clk + (uint64_t)r * 8;
+        bool goes_on = false;                       /* the read takes part in the next pass */
+        if (ms.phase == (uint32_t)MP_PARK) {
+            /* ---- park the read: the window pair goes to its slot (simulate.py:325-343) ---- */
+            uint32_t a = 0, b = n;
+            if (n > BRX_ALIGN_SIZE) {
+                uint32_t ww[4];
+                brx_draw4(d.seed, d.first_read + r, BRX_ST_WIN, (uint64_t)ms.nalign, ww);
+                a = (uint32_t)brx_mulhi64(((uint64_t)ww[1] << 32) | ww[0], (uint64_t)n - BRX_ALIGN_SIZE + 1);
+                b = a + BRX_ALIGN_SIZE;
+            }
+            uint32_t cost = 0;
+            uint8_t *qb = aux.winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+            bool odd = false;
+            const uint32_t tl = wave_park<true, true>(em, F, rp, a, b, qb, tbuf, BRX_WIN_TMAX, &cost, &odd, reinterpret_cast<uint32_t *>(qb + BRX_WIN_PLANES));
+            const uint32_t ql = b - a;
+            uint32_t klass = MC_LEGACY;
+            int band_blocks_of = 0;
+            if (tl <= BRX_WIN_TMAX) {
+                const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
+                const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
+                band_blocks_of = band_blocks;
+                /* "easy" windows go to a throughput kernel: one window per LANE while the pass is large, eight windows per wave
+                   (k_win_pack) once fewer than lane_threshold reads are active */
+                const bool easy = !odd && g.G == 1 && tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 &&
+                                  (n_in > lane_threshold ? band_blocks <= BRX_LANE_W : brx_pack_eligible(ql, tl, cost, odd));
+                klass = easy ? MC_EASY : MC_HARD;
+            }
+            if (lane == 0) {
+                MS *o = &msv[r];
+                o->nalign = ms.nalign + 1u;
+                o->phase = klass == MC_LEGACY ? 3u : 1u;
+                o->win_a = a; o->win_b = b; o->tl = tl; o->cost = cost; o->res_ncols = 0; o->res_nmatch = 0;
+                o->passes = ms.passes + 1u;
+                if (klass == MC_EASY && n_in > lane_threshold) {
+                    /* lane passes: the windows are listed by band width (BRX_LANE_CLASSES lists of d.n_reads entries) */
+                    const uint32_t cls = brx_lane_class(band_blocks_of);
+                    aux.req_easy[(size_t)cls * d.n_reads + atomicAdd(&lane_cls[cls], 1u)] = r;
+                    atomicAdd(&ctr[MC_EASY], 1u);
+                } else {
+                    uint32_t *list = klass == MC_EASY ? aux.req_easy : klass == MC_HARD ? aux.req_hard : aux.req_legacy;
+                    list[atomicAdd(klass == MC_LEGACY ? aux.legacy_ctr : &ctr[klass], 1u)] = r;
+                }
+                if (klass != MC_LEGACY) active_out[atomicAdd(&ctr[MC_OUT], 1u)] = r;
+            }
+            goes_on = klass != MC_LEGACY;
+        } else if (ms.phase == (uint32_t)MP_FINISH) {
+            /* ---- epilogue: lengths of the mutated read, trims (simulate.py:348-349), proven distance bound ---- */
+            uint32_t cost = 0;
+            const uint32_t m = wave_join(em, F, rp, 0, n, nullptr, &cost);
+            uint32_t st = 0, et = 0;
+            if (lane < k) { st = rep_len(rp[lane]); et = rep_len(rp[n - k + lane]); }
+            st = wave_sum(st); et = wave_sum(et);
+            if (lane == 0) {
+                RS *o = &rs[r];
+                o->status = s.status | ms.status; o->m = m; o->ub = cost; o->start_trim = st; o->end_trim = et;
+                o->loops = (uint32_t)ms.round_loops; o->changes = ms.change; o->naligns = ms.nalign;
+                o->units = 0;                                          /* sized by k_fin_join */
+                msv[r].phase = 2u;
+                ck[1] = ms.passes;
+            }
+        } else {                                    /* not started (the fill before the first pass) or hungry */
+            goes_on = true;
+            if (ms.phase == (uint32_t)MP_HUNGRY && lane == 0) active_out[atomicAdd(&ctr[MC_OUT], 1u)] = r;
+        }
+        if (goes_on) {
+            /* ---- propose ahead: survivors of the next iterations into the ring, in iteration order ---- */
+            PQ q = pq[r];
+            const uint32_t cap = brx_loop_cap32(n);
+            const uint32_t max_i1 = n - (uint32_t)k;                   /* max_kmer_index + 1 (simulate.py:270) */
+            const uint32_t *f2g = F2buf + (s.F_off >> 4);
+            const uint32_t nw2 = (n + 15u) >> 4, nwc = (n + 31u) >> 5;
+            const bool coded = uni(f2g[nw2] == 0u);
+            const uint32_t *oddg = Cbuf + (s.F_off >> 4) + nwc;
+            uint4 *ra = sv_a + (size_t)r * BRX_SV_CAP;
+            uint32_t *rz = sv_z + (size_t)r * BRX_SV_CAP;
+            uint32_t have = q.tail - q.head;
+            while (have < BRX_SV_STOCK && have + 64u * (uint32_t)U <= BRX_SV_CAP && q.next_t < cap) {
+                uint32_t ip[U]; BrxProp pr[U]; bool sv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t t = q.next_t + 64u * (uint32_t)u + (uint32_t)lane;
+                    sv[u] = false; ip[u] = 0u; pr[u].x = pr[u].y = pr[u].z = 0u;
+                    if (t < cap && t >= q.next_t) sv[u] = brx_propose_iter(d, d.first_read + r, t, max_i1, f2g, oddg, coded, F, &ip[u], &pr[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned long long m = __ballot(sv[u]);
+                    if (sv[u]) {
+                        const uint32_t slot = (q.tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (BRX_SV_CAP - 1u);
+                        ra[slot] = make_uint4(q.next_t + 64u * (uint32_t)u + (uint32_t)lane, ip[u], pr[u].x, pr[u].y);
+                        rz[slot] = pr[u].z;
+                    }
+                    const uint32_t cnt = (uint32_t)__popcll(m);
+                    q.tail += cnt; have += cnt;
+                }
+                const uint32_t room = cap - q.next_t;
+                q.next_t += room < 64u * (uint32_t)U ? room : 64u * (uint32_t)U;
+            }
+            if (lane == 0) { pq[r].tail = q.tail; pq[r].next_t = q.next_t; }
+        }
+        if (lane == 0) ck[0] += __builtin_amdgcn_s_memtime() - t_begin;
+    }
+}
+
+#endif /* BRX_PASSES_H */

@@ -35,6 +35,11 @@ QUAD_ROUTES = [{'BRX_FIN_LANES': '0', 'BRX_FIN_QUAD': '3'}, {'BRX_FIN_QUAD': '3'
 for _r in QUAD_ROUTES:
     _r.setdefault('BRX_QUAD_MIN_READS', '0')          # the class is used only when it holds thousands of reads by default
 ROUTES += QUAD_ROUTES
+# round 6: the bulk passes as {k_mut_apply, k_mut_post} (brx_passes.h) -- every read through the passes, passes with an in-place
+# tail that takes reads over in any state, both window kernels; `defines` builds a variant of the kernels whose rings are kept
+# nearly empty, so that reads go hungry (a pass without an alignment) all the time
+PASS_ROUTES = [{'BRX_TAIL_READS': t, 'BRX_HEAD_READS': h, 'BRX_LANE_THRESHOLD': l} for t in ('0', '2', '5') for h in ('0', '2') for l in ('0', '1000000')]
+PASS_DEFINES = [(), ('-DBRX_SV_STOCK=3u', '-DBRX_SV_CAP=128u', '-DBRX_POST_U=1'), ('-DBRX_SV_STOCK=1u', '-DBRX_SV_CAP=256u', '-DBRX_POST_U=3')]
 
 
 def draw_case(rng, focus=None):
@@ -58,7 +63,8 @@ def draw_case(rng, focus=None):
         p.update(id_a=float(rng.choice([10.0, 20.0, 30.0])), id_b=float(rng.choice([1.0, 3.0, 6.0])), id_max=1.0)
     return dict(params=p, em=str(rng.choice(MODELS)), qm=str(rng.choice(QMODELS)), seed=int(rng.integers(0, 2 ** 40)),
                 first=int(rng.integers(0, 10 ** 6)), n=int(rng.choice([1, 7, 16, 30])), with_n=bool(rng.integers(0, 2)),
-                route=dict((QUAD_ROUTES if focus == 'quad' else ROUTES)[int(rng.integers(0, len(QUAD_ROUTES if focus == 'quad' else ROUTES)))]))
+                route=dict((QUAD_ROUTES if focus == 'quad' else PASS_ROUTES if focus == 'pass' else ROUTES)[int(rng.integers(0, len(QUAD_ROUTES if focus == 'quad' else PASS_ROUTES if focus == 'pass' else ROUTES)))]),
+                defines=list(PASS_DEFINES[int(rng.integers(0, len(PASS_DEFINES)))]) if focus == 'pass' else [])
 
 
 def run_case(case):
@@ -69,7 +75,7 @@ def run_case(case):
     os.environ.update(case['route'])
     pref, _ = H.small_reference(with_n=case['with_n'])
     p = SimParams(**case['params'])
-    emu = H.configure(EE.EmuEngine(1 << 29), pref, case['em'], case['qm'], p)
+    emu = H.configure(EE.EmuEngine(1 << 29, tuple(case.get('defines', ()))), pref, case['em'], case['qm'], p)
     orc = H.configure(H.oracle_engine(), pref, case['em'], case['qm'], p)
     out_h, st_h = emu.simulate_batch(case['seed'], case['first'], case['n'], allow_nofrag=True)
     out_o, st_o = orc.simulate_batch(case['seed'], case['first'], case['n'], allow_nofrag=True)
@@ -83,7 +89,7 @@ def run_case(case):
 def main():
     seconds, wid = float(sys.argv[1]), int(sys.argv[2])
     logdir = sys.argv[3] if len(sys.argv) > 3 else '/tmp/brx_fuzz'
-    focus = sys.argv[4] if len(sys.argv) > 4 else None          # 'quad': only the k_fin_quad routes, longer reads
+    focus = sys.argv[4] if len(sys.argv) > 4 else None          # 'quad': only the k_fin_quad routes, longer reads; 'pass': the bulk passes
     os.makedirs(logdir, exist_ok=True)
     rng = np.random.default_rng(1000 + wid)
     t0, cases, bases, fails = time.time(), 0, 0, 0
