@@ -483,7 +483,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *active_a = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *active_b = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_easy = (uint32_t *)A.take((size_t)n_reads * 4 * BRX_LANE_CLASSES);    /* lane passes: one list per band-width class */
-    uint32_t *lane_cls = (uint32_t *)A.take(2 * MC_WORDS * sizeof(uint32_t));             /* their counts, a block per pass parity */
+    uint32_t *lane_cls = (uint32_t *)A.take(2 * MC_WORDS * BRX_CLS_STRIDE * sizeof(uint32_t));             /* their counts, a block per pass parity */
     MutAux *aux_dev = (MutAux *)A.take(2 * sizeof(MutAux));                               /* [0] bulk chain, [1] head chain: what k_mutate_seg reads where it uses it */
     uint32_t *req_hard = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy = (uint32_t *)A.take((size_t)n_reads * 4);
@@ -921,7 +921,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     HIPCHK(c, hipMemsetAsync(msv, 0, (size_t)n_reads * sizeof(MS), st));
     HIPCHK(c, hipMemsetAsync(pq, 0, (size_t)n_reads * sizeof(PQ), st));
     HIPCHK(c, hipMemsetAsync(mctr, 0, 8 * MC_WORDS * sizeof(uint32_t), st));
-    HIPCHK(c, hipMemsetAsync(lane_cls, 0, 2 * MC_WORDS * sizeof(uint32_t), st));
+    HIPCHK(c, hipMemsetAsync(lane_cls, 0, 2 * MC_WORDS * BRX_CLS_STRIDE * sizeof(uint32_t), st));
     {
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         memset(h_ctr, 0, 2 * MC_WORDS * sizeof(uint32_t));
@@ -1003,8 +1003,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                    wave per read parks the window or writes the epilogue and proposes ahead (k_mut_post) */
                 if (pass == 0) {                       /* the first rings: every bulk read is "not started" */
                     KTIMED(BRX_KERN_MUT_POST, st);
-                    hipLaunchKernelGGL((k_mut_post<BRX_POST_U>), dim3(std::min(post_waves, n_up)), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in, act_out,
-                                       mctr + 7 * MC_WORDS, h_aux[0], Fbuf, repl, lane_pass_thr, F2buf, Cbuf, lane_cls + (pass & 1u) * MC_WORDS, sv_a, sv_z);
+                    hipLaunchKernelGGL((k_mut_post<BRX_POST_U>), dim3(std::min(post_waves, n_up)), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in,
+                                       h_aux[0], Fbuf, repl, lane_pass_thr, F2buf, Cbuf, sv_a, sv_z);
                 }
                 {
                     KTIMED(BRX_KERN_MUTATE_SEG, st);
@@ -1012,22 +1012,24 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 }
                 {
                     KTIMED(BRX_KERN_MUT_POST, st);
-                    hipLaunchKernelGGL((k_mut_post<BRX_POST_U>), dim3(std::min(post_waves, n_up)), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in, act_out,
-                                       ctr, h_aux[0], Fbuf, repl, lane_pass_thr, F2buf, Cbuf, lane_cls + (pass & 1u) * MC_WORDS, sv_a, sv_z);
+                    hipLaunchKernelGGL((k_mut_post<BRX_POST_U>), dim3(std::min(post_waves, n_up)), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in,
+                                       h_aux[0], Fbuf, repl, lane_pass_thr, F2buf, Cbuf, sv_a, sv_z);
+                    hipLaunchKernelGGL(k_pass_lists, dim3((n_up + 63u) / 64u), dim3(64), 0, st, msv, act_in, n_in, act_out, ctr,
+                                       lane_cls + (pass & 1u) * MC_WORDS * BRX_CLS_STRIDE, h_aux[0], n_reads, n_up > lane_threshold ? 1u : 0u);
                 }
             } else {
                 KTIMED(BRX_KERN_MUTATE_SEG, st);
                 if (c->profile)
                     hipLaunchKernelGGL((k_mutate_seg<false, true, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                                       ctr, aux_dev, Fbuf, repl, lane_pass_thr, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS);
+                                       ctr, aux_dev, Fbuf, repl, lane_pass_thr, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS * BRX_CLS_STRIDE);
                 else
                     hipLaunchKernelGGL((k_mutate_seg<false, false, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                                       ctr, aux_dev, Fbuf, repl, lane_pass_thr, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS);
+                                       ctr, aux_dev, Fbuf, repl, lane_pass_thr, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS * BRX_CLS_STRIDE);
             }
             if (n_up > lane_threshold) {
                 KTIMED(BRX_KERN_WIN_LANE, st);
                 hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64 + BRX_LANE_CLASSES)), dim3(64), 0, st, msv, req_easy,
-                                   lane_cls + (pass & 1u) * MC_WORDS, n_reads, winbuf, lane_tb);
+                                   lane_cls + (pass & 1u) * MC_WORDS * BRX_CLS_STRIDE, n_reads, winbuf, lane_tb);
             } else {                                   /* few reads left: eight windows per wave (same list, same class) */
                 KTIMED(BRX_KERN_WIN_LANE, st);
                 hipLaunchKernelGGL(k_win_pack, dim3(std::min(pack_waves, (n_up + BRX_PACK_NG - 1) / BRX_PACK_NG)), dim3(64), 0, st, msv, req_easy,
@@ -1039,7 +1041,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                    wave per active read was 4096 waves that start only to find the queue empty, once per pass on the critical path */
                 hipLaunchKernelGGL(k_win_wave, dim3(std::min(std::min(side_waves, 512u), n_up)), dim3(64), 0, st, msv, req_hard, ctr + MC_HARD,
                                    ctr + 5, winbuf, win, (uint64_t)c->win_bytes, counters + 1, mctr + ((pass + 1) & 1u) * MC_WORDS,
-                                   lane_cls + ((pass + 1) & 1u) * MC_WORDS);
+                                   lane_cls + ((pass + 1) & 1u) * MC_WORDS * BRX_CLS_STRIDE);
             }
             /* the active count only shrinks: look at it every 4th pass while it is large, every pass near the end */
             if (n_up <= 4 * std::min<uint32_t>(tail_reads, 48u) || n_up <= tail_reads + 64 || (pass & 3u) == 3u) {

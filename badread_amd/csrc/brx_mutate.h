@@ -57,6 +57,8 @@ struct MS {                       /* loop state of a parked read */
     uint32_t win_a, win_b, tl, cost;
     uint32_t res_ncols, res_nmatch;
     uint32_t status, passes;
+    uint32_t win_kind;            /* bulk passes (brx_passes.h): which aligner the parked window goes to -- MC_EASY | band class << 8, MC_HARD, MC_LEGACY */
+    uint32_t pad_;
 };
 
 enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WORDS = 8 };
@@ -64,6 +66,9 @@ enum { MC_QUEUE = 0, MC_OUT = 1, MC_EASY = 2, MC_HARD = 3, MC_LEGACY = 4, MC_WOR
  * as its WIDEST window needs, and the widest of 64 windows taken as they come is near the top of the range (7-8 slots) while
  * most need 3-5.  Class c = band blocks - 3 (<= 3 blocks: class 0; 8 blocks: class 5). */
 #define BRX_LANE_CLASSES 6
+/* the class counters live a cache line apart: device-scope atomics on ONE line retire at 11.4 ns each whatever the number of waves
+   (tools/native/atomic_bench.hip, profiles/r06_atomic_bench.jsonl) */
+#define BRX_CLS_STRIDE 32
 __device__ __forceinline__ uint32_t brx_lane_class(int band_blocks) {
     const int c = band_blocks - 3;
     return (uint32_t)(c < 0 ? 0 : c > BRX_LANE_CLASSES - 1 ? BRX_LANE_CLASSES - 1 : c);
@@ -479,7 +484,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                                     /* lane passes: the windows are listed by band width (BRX_LANE_CLASSES lists of d.n_reads entries),
                                        so that the 64 windows of a lane-kernel wave are equally wide (k_win_lane) */
                                     const uint32_t cls = brx_lane_class(band_blocks_of);
-                                    c_easy[(size_t)cls * d.n_reads + atomicAdd(&lane_cls[cls], 1u)] = r;
+                                    c_easy[(size_t)cls * d.n_reads + atomicAdd(&lane_cls[cls * BRX_CLS_STRIDE], 1u)] = r;
                                     atomicAdd(&ctr[MC_EASY], 1u);
                                 } else {
                                     uint32_t *list = klass == MC_EASY ? c_easy : klass == MC_HARD ? c_hard : c_legacy;
@@ -568,7 +573,7 @@ __global__ void __launch_bounds__(64, 5) k_win_wave(MS *msv, const uint32_t *req
     const int lane = lane_id();
     const uint32_t n_req = uni(*n_req_ptr);
     /* the counter block of the NEXT pass: last read (as the input count) by this pass's k_mutate_seg, which is done */
-    if (next_ctr && blockIdx.x == 0 && lane < (int)MC_WORDS) { next_ctr[lane] = 0u; next_cls[lane] = 0u; }
+    if (next_ctr && blockIdx.x == 0 && lane < (int)MC_WORDS) { next_ctr[lane] = 0u; next_cls[lane * BRX_CLS_STRIDE] = 0u; }
     uint2 *tb = reinterpret_cast<uint2 *>(scr_base + (uint64_t)blockIdx.x * scr_bytes);
     for (;;) {
         const uint32_t qi = wave_pop(queue);
@@ -773,7 +778,7 @@ __global__ void __launch_bounds__(64, 4) k_win_lane(MS *msv, const uint32_t *req
     /* groups of 64 windows, the widest class first (it is also the longest-running: every column computes more slots) */
     uint32_t cnt[BRX_LANE_CLASSES], total = 0;
 #pragma unroll
-    for (int cidx = 0; cidx < BRX_LANE_CLASSES; ++cidx) { cnt[cidx] = uni(cls_cnt[cidx]); total += (cnt[cidx] + 63u) >> 6; }
+    for (int cidx = 0; cidx < BRX_LANE_CLASSES; ++cidx) { cnt[cidx] = uni(cls_cnt[cidx * BRX_CLS_STRIDE]); total += (cnt[cidx] + 63u) >> 6; }
     for (uint32_t grp = blockIdx.x; grp < total; grp += gridDim.x) {
         uint32_t g0 = grp, cls = 0, n_req = 0;
 #pragma unroll

@@ -199,9 +199,8 @@ __device__ __forceinline__ bool brx_propose_iter(const BrxDev &d, uint64_t read,
 
 template <int U>
 __global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, PQ *pq, const uint32_t *active_in, const uint32_t *n_in_ptr,
-                                                     uint32_t *active_out, uint32_t *ctr, const MutAux aux, const uint8_t *Fbuf, uint32_t *repl,
-                                                     uint32_t lane_threshold, const uint32_t *F2buf, const uint32_t *Cbuf, uint32_t *lane_cls,
-                                                     uint4 *sv_a, uint32_t *sv_z) {
+                                                     const MutAux aux, const uint8_t *Fbuf, uint32_t *repl, uint32_t lane_threshold,
+                                                     const uint32_t *F2buf, const uint32_t *Cbuf, uint4 *sv_a, uint32_t *sv_z) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
@@ -249,16 +248,7 @@ __global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, P
                 o->phase = klass == MC_LEGACY ? 3u : 1u;
                 o->win_a = a; o->win_b = b; o->tl = tl; o->cost = cost; o->res_ncols = 0; o->res_nmatch = 0;
                 o->passes = ms.passes + 1u;
-                if (klass == MC_EASY && n_in > lane_threshold) {
-                    /* lane passes: the windows are listed by band width (BRX_LANE_CLASSES lists of d.n_reads entries) */
-                    const uint32_t cls = brx_lane_class(band_blocks_of);
-                    aux.req_easy[(size_t)cls * d.n_reads + atomicAdd(&lane_cls[cls], 1u)] = r;
-                    atomicAdd(&ctr[MC_EASY], 1u);
-                } else {
-                    uint32_t *list = klass == MC_EASY ? aux.req_easy : klass == MC_HARD ? aux.req_hard : aux.req_legacy;
-                    list[atomicAdd(klass == MC_LEGACY ? aux.legacy_ctr : &ctr[klass], 1u)] = r;
-                }
-                if (klass != MC_LEGACY) active_out[atomicAdd(&ctr[MC_OUT], 1u)] = r;
+                o->win_kind = klass | (brx_lane_class(band_blocks_of) << 8);     /* k_pass_lists enters the read in the list of its aligner */
             }
             goes_on = klass != MC_LEGACY;
         } else if (ms.phase == (uint32_t)MP_FINISH) {
@@ -276,10 +266,7 @@ __global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, P
                 msv[r].phase = 2u;
                 ck[1] = ms.passes;
             }
-        } else {                                    /* not started (the fill before the first pass) or hungry */
-            goes_on = true;
-            if (ms.phase == (uint32_t)MP_HUNGRY && lane == 0) active_out[atomicAdd(&ctr[MC_OUT], 1u)] = r;
-        }
+        } else goes_on = true;                      /* not started (the fill before the first pass) or hungry */
         if (goes_on) {
             /* ---- propose ahead: survivors of the next iterations into the ring, in iteration order ---- */
             PQ q = pq[r];
@@ -317,6 +304,60 @@ __global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, P
             if (lane == 0) { pq[r].tail = q.tail; pq[r].next_t = q.next_t; }
         }
         if (lane == 0) ck[0] += __builtin_amdgcn_s_memtime() - t_begin;
+    }
+}
+
+/* -------------------------------------------------------------------------------------------------
+ * k_pass_lists: one read per lane -- the lists of the pass's window kernels and of the next pass
+ * -----------------------------------------------------------------------------------------------
+ * Every read of the pass enters the list its state names: the next pass's input (parked or hungry), the lane kernel's list of its
+ * band class (or the packed kernel's one list), the wave kernel's list, the whole-read kernel's list.  An append is
+ * `atomicAdd(counter, pred)` by EVERY lane on a wave-uniform address: the compiler turns that into one atomic per wave and a prefix
+ * over the lanes.  (Rounds 2-5 appended from one lane of a wave per read: three to four device-scope atomics per read and pass on
+ * two cache lines -- at 11.4 ns per atomic on a line, profiles/r06_atomic_bench.jsonl, the first pass of a 65536-read batch could
+ * not take less than 2.2 ms whatever its waves did: the pass kernel of those rounds was waiting for THIS 60 % of its time.) */
+__global__ void __launch_bounds__(64) k_pass_lists(const MS *msv, const uint32_t *active_in, const uint32_t *n_in_ptr, uint32_t *active_out,
+                                                    uint32_t *ctr, uint32_t *lane_cls, const MutAux aux, uint32_t n_reads, uint32_t lane_mode) {
+    const uint32_t idx = blockIdx.x * 64u + (uint32_t)lane_id();
+    const bool in = idx < *n_in_ptr;
+    const uint32_t r = in ? active_in[idx] : 0u;
+    const uint32_t phase = in ? msv[r].phase : 0xFFu, kind = in ? msv[r].win_kind : 0u;
+    const bool parked = phase == 1u;
+    const uint32_t klass = kind & 0xFFu, cls = kind >> 8;
+    {
+        const bool p = parked || phase == (uint32_t)MP_HUNGRY;
+        const uint32_t at = atomicAdd(&ctr[MC_OUT], p ? 1u : 0u);
+        if (p) active_out[at] = r;
+    }
+    if (lane_mode) {
+#pragma unroll
+        for (uint32_t cc = 0; cc < (uint32_t)BRX_LANE_CLASSES; ++cc) {
+            const bool p = parked && klass == (uint32_t)MC_EASY && cls == cc;
+            if (__ballot(p) == 0ull) continue;
+            const uint32_t at = atomicAdd(&lane_cls[cc * BRX_CLS_STRIDE], p ? 1u : 0u);
+            if (p) aux.req_easy[(size_t)cc * n_reads + at] = r;
+        }
+    }
+    {
+        const bool p = parked && klass == (uint32_t)MC_EASY;
+        if (__ballot(p) != 0ull) {
+            const uint32_t at = atomicAdd(&ctr[MC_EASY], p ? 1u : 0u);
+            if (p && !lane_mode) aux.req_easy[at] = r;
+        }
+    }
+    {
+        const bool p = parked && klass == (uint32_t)MC_HARD;
+        if (__ballot(p) != 0ull) {
+            const uint32_t at = atomicAdd(&ctr[MC_HARD], p ? 1u : 0u);
+            if (p) aux.req_hard[at] = r;
+        }
+    }
+    {
+        const bool p = phase == 3u;
+        if (__ballot(p) != 0ull) {
+            const uint32_t at = atomicAdd(aux.legacy_ctr, p ? 1u : 0u);
+            if (p) aux.req_legacy[at] = r;
+        }
     }
 }
 
