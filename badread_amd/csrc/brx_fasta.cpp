@@ -335,9 +335,13 @@ extern "C" int brx_fasta_save(const brx_fasta *f, const char *source_path, const
     h.n_contigs = (uint32_t)f->contigs.size(); h.n_exceptions = (uint32_t)f->exceptions.size();
     h.names_len = (uint32_t)f->names.size(); h.n_symbols = f->n_symbols;
     memcpy(h.sym, f->sym, 16); memcpy(h.comp, f->comp, 16);
-    const std::string tmp = std::string(sidecar_path) + ".tmp";
-    FILE *fp = fopen(tmp.c_str(), "wb");
-    if (!fp) return set_err(err, err_cap, BRX_E_ARG, "could not write %s", tmp.c_str());
+    /* a name of this process's own next to the target (mkstemp): the ranks of a first multi-GPU run pack and save at the same
+       time, and a shared "<sidecar>.tmp" let one rank truncate what another was writing or had just renamed into place */
+    std::string tmp = std::string(sidecar_path) + ".XXXXXX";
+    const int fd = mkstemp(&tmp[0]);
+    FILE *fp = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+    if (!fp) { if (fd >= 0) { close(fd); remove(tmp.c_str()); } return set_err(err, err_cap, BRX_E_ARG, "could not write %s", tmp.c_str()); }
+    (void)fchmod(fd, 0644);                                     /* mkstemp creates 0600: the cache is as readable as fopen would have made it */
     bool ok = fwrite(&h, sizeof(h), 1, fp) == 1;
     ok = ok && fwrite(f->contigs.data(), sizeof(brx_contig), f->contigs.size(), fp) == f->contigs.size();
     ok = ok && fwrite(f->depths.data(), sizeof(double), f->depths.size(), fp) == f->depths.size();

@@ -1056,6 +1056,10 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         }
         c->mutate_passes += pass;
         if (n_up > 0) return fail(c, BRX_E_INTERNAL, "mutate pipeline did not converge after %u passes", pass);
+        if (!c->pass_seg) {                            /* the reads that finished inside the passes: their epilogues, once */
+            KTIMED(BRX_KERN_MUT_POST, st);
+            hipLaunchKernelGGL(k_mut_epilogue, dim3(std::min(post_waves, n_mb)), dim3(64), 0, st, dev, rs, msv, order + n_mh, n_mb, h_aux[0], Fbuf, repl);
+        }
     }
     if (!n_mh) {
         /* one mutate chain for all reads: the whole-read fallback (windows that did not fit a slot) runs here, for both

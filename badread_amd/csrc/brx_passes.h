@@ -252,20 +252,7 @@ __global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, P
             }
             goes_on = klass != MC_LEGACY;
         } else if (ms.phase == (uint32_t)MP_FINISH) {
-            /* ---- epilogue: lengths of the mutated read, trims (simulate.py:348-349), proven distance bound ---- */
-            uint32_t cost = 0;
-            const uint32_t m = wave_join(em, F, rp, 0, n, nullptr, &cost);
-            uint32_t st = 0, et = 0;
-            if (lane < k) { st = rep_len(rp[lane]); et = rep_len(rp[n - k + lane]); }
-            st = wave_sum(st); et = wave_sum(et);
-            if (lane == 0) {
-                RS *o = &rs[r];
-                o->status = s.status | ms.status; o->m = m; o->ub = cost; o->start_trim = st; o->end_trim = et;
-                o->loops = (uint32_t)ms.round_loops; o->changes = ms.change; o->naligns = ms.nalign;
-                o->units = 0;                                          /* sized by k_fin_join */
-                msv[r].phase = 2u;
-                ck[1] = ms.passes;
-            }
+            /* the loop is over: the epilogue waits for k_mut_epilogue, once, behind the last pass */
         } else goes_on = true;                      /* not started (the fill before the first pass) or hungry */
         if (goes_on) {
             /* ---- propose ahead: survivors of the next iterations into the ring, in iteration order ---- */
@@ -304,6 +291,41 @@ __global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, P
             if (lane == 0) { pq[r].tail = q.tail; pq[r].next_t = q.next_t; }
         }
         if (lane == 0) ck[0] += __builtin_amdgcn_s_memtime() - t_begin;
+    }
+}
+
+/* -------------------------------------------------------------------------------------------------
+ * k_mut_epilogue: one finished read per wave, ONCE behind the last pass
+ * -----------------------------------------------------------------------------------------------
+ * Lengths of the mutated read, trims (simulate.py:348-349), proven distance bound: a walk over the whole read (n / 64 steps of
+ * dependent loads).  Inside the passes -- where rounds 2-5 and the first k_mut_post had it -- the ~1000 reads that finish in a
+ * pass made that pass's kernel as long as ONE such walk, 64 times per batch; nothing needs these numbers before the final stage. */
+__global__ void __launch_bounds__(64, 8) k_mut_epilogue(BrxDev d, RS *rs, MS *msv, const uint32_t *list, uint32_t n_list, const MutAux aux,
+                                                         const uint8_t *Fbuf, const uint32_t *repl) {
+    const int lane = lane_id();
+    const brx_error_model &em = d.em;
+    const int k = em.k;
+    for (uint32_t qi = blockIdx.x; qi < n_list; qi += gridDim.x) {
+        const uint32_t r = uni(list[qi]);
+        if (uni(msv[r].phase) != (uint32_t)MP_FINISH) continue;
+        const RS s = rs[r];
+        const MS ms = msv[r];
+        const uint32_t n = s.n;
+        const uint8_t *F = Fbuf + s.F_off;
+        const uint32_t *rp = repl + s.F_off;
+        uint32_t cost = 0;
+        const uint32_t m = wave_join(em, F, rp, 0, n, nullptr, &cost);
+        uint32_t st = 0, et = 0;
+        if (lane < k) { st = rep_len(rp[lane]); et = rep_len(rp[n - k + lane]); }
+        st = wave_sum(st); et = wave_sum(et);
+        if (lane == 0) {
+            RS *o = &rs[r];
+            o->status = s.status | ms.status; o->m = m; o->ub = cost; o->start_trim = st; o->end_trim = et;
+            o->loops = (uint32_t)ms.round_loops; o->changes = ms.change; o->naligns = ms.nalign;
+            o->units = 0;                                          /* sized by k_fin_join */
+            msv[r].phase = 2u;
+            aux.clk[(uint64_t)r * 8 + 1] = ms.passes;
+        }
     }
 }
 

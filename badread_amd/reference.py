@@ -165,10 +165,13 @@ class PackedReference(object):
             # the words stay where the native object holds them -- the mapped sidecar, or the packer's vector -- for as long as
             # this object lives (a human genome is 772 MB: every copy is a third of a second of start-up)
             keeper = _NativeFasta(lib, handle)
-            words = (ctypes.c_uint32 * int(v.n_words)).from_address(ctypes.addressof(v.packed.contents))
-            words._keeper = keeper                          # every numpy view of the words keeps `words`, and so the mapping, alive
-            self.packed = np.frombuffer(words, dtype=np.uint32)
-            self._native = keeper
+            self._native = keeper                           # from here on the handle is freed by `keeper` alone (never twice)
+            if int(v.n_words):
+                words = (ctypes.c_uint32 * int(v.n_words)).from_address(ctypes.addressof(v.packed.contents))
+                words._keeper = keeper                      # every numpy view of the words keeps `words`, and so the mapping, alive
+                self.packed = np.frombuffer(words, dtype=np.uint32)
+            else:                                           # no bases at all: `packed` is a null pointer
+                self.packed = np.zeros(0, dtype=np.uint32)
             self.contigs = np.frombuffer(ctypes.string_at(v.contigs, nc * CONTIG_DTYPE.itemsize), dtype=CONTIG_DTYPE).copy()
             ne = int(v.n_exceptions)
             self.exceptions = (np.frombuffer(ctypes.string_at(v.exceptions, ne * EXCEPTION_DTYPE.itemsize), dtype=EXCEPTION_DTYPE).copy()

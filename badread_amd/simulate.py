@@ -658,6 +658,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
     timing = run_batches.last_timing = collections.Counter()     # seconds of the consumer thread per activity (bench.py --d2h)
     t0 = time.perf_counter()
     t_job = t0
+    first_arena = None
     if hasattr(engine, 'presize'):               # the arena of the first engine (the clones copy its size) for the batches this job will issue
         first_batch = plan_batch(target_size, expected_mean, shard.world, max_batch) // shard.world
         first_arena = arenas.take() if arenas is not None else None
@@ -692,14 +693,13 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         if pool.on_gpu and out_bytes and os.environ.get('BRX_RING_PREALLOC') and target_size > 3 * max_batch * expected_mean:
             ring.prealloc(int(1.25 * out_bytes))
     sink_failed_on = None
-    dev_staging = {}
 
-    def staging(nbytes):                     # where rank 0 receives another rank's records (device memory under RCCL)
-        dev = shard._device()
-        buf = dev_staging.get('buf')
-        if buf is None or buf.numel() < nbytes:
-            buf = dev_staging['buf'] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
-        return buf[:nbytes]
+    def staging(nbytes):
+        """Where rank 0 receives another rank's records (device memory under RCCL): a tensor of ITS OWN per receive.  The ring
+        copies device tensors to the host asynchronously on its copy stream and keeps the tensor with the queue entry until the
+        copy has landed; one reused staging buffer would be overwritten by the next rank's `recv` (ordered behind the current
+        stream only) while that copy still reads it.  The caching allocator makes this as cheap as the reuse was."""
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=shard._device())
 
     gz_engine = None
     if device_gzip:
@@ -811,6 +811,11 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         if arenas is not None:                  # arenas no clone asked for (a job that stopped early, ranks that agreed on fewer engines)
             arenas.release_rest()
             timing['arena_prefetch_thread_seconds'] = arenas.seconds
+            if arenas.errors:                   # a prefetch that failed left its clone to allocate by itself: say so (it may be what ran out of memory later)
+                timing['arena_prefetch_failures'] = len(arenas.errors)
+                if shard.rank == 0:
+                    print(f'  {len(arenas.errors)} of the {arenas.count} scratch arenas could not be allocated ahead '
+                          f'({type(arenas.errors[0]).__name__}: {arenas.errors[0]})', file=output)
         if gz_engine is not None and gz_engine is not engine:
             gz_engine.close()
         timing['close_engines'] = time.perf_counter() - t0

@@ -154,3 +154,40 @@ def test_the_packed_words_outlive_the_reference_object(tmp_path):
         junk = [np.zeros(1 << 20, dtype=np.uint8) for _ in range(8)]      # give freed memory a chance to be reused
         assert np.array_equal(view, want)
         del junk
+
+
+def test_ranks_saving_the_same_sidecar_at_once_do_not_clobber_each_other(tmp_path):
+    """on a first multi-rank run every rank packs and saves the sidecar at the same time.  The save goes through a
+    temporary file of its own (mkstemp) and a rename, so whichever rename lands last the file is whole, and no temporary is
+    left behind."""
+    import threading
+    p = tmp_path / 'ref.fasta'
+    p.write_bytes(b'>a circular=true\n' + b'ACGTTGCA' * 40000 + b'\n>b\nGGGGRRRRNNNN\n')
+    want = PackedReference.from_fasta(str(p), cache=False)
+    errors = []
+
+    def rank():
+        try:
+            same(PackedReference.from_fasta(str(p), cache=True), want)
+        except BaseException as ex:                      # noqa: BLE001 -- reported by the assertion below
+            errors.append(ex)
+    threads = [threading.Thread(target=rank) for _ in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert sorted(os.listdir(tmp_path)) == ['ref.fasta', 'ref.fasta.brx2bit']       # no '.tmp' / '.XXXXXX' leftovers
+    assert oct(os.stat(str(p) + '.brx2bit').st_mode & 0o777) == oct(0o644)
+    same(PackedReference.from_fasta(str(p), cache=True), want)                       # and what is there loads
+
+
+def test_a_file_without_a_single_base_has_an_empty_packed_array(tmp_path):
+    """`packed` is a null pointer then; the view must not dereference it."""
+    p = tmp_path / 'empty.fasta'
+    p.write_bytes(b'>only_a_header\n')
+    try:
+        ref = PackedReference.from_fasta(str(p), cache=False)
+    except ValueError:
+        return                                            # refusing the file is as good
+    assert ref.n_bases == 0 and len(ref.packed) <= 1 and not ref.packed.any()      # the packer keeps one zero word
