@@ -39,22 +39,14 @@ struct brx_ctx {
                                     to and from it (k_copy_words) -- a hipMemcpyAsync of a few bytes is a blit kernel of the runtime that
                                     waited 3.6 ms on average behind the resident waves of six batches, ~50 times per batch */
     size_t stage_bytes;
-    int blit;                    /* BRX_BLIT=1: the runtime's copies instead (A/B) */
     uint32_t *h_prog, *d_prog;   /* host / device views of the progress words */
     hipEvent_t ev_b[BRX_STAGE_COUNT], ev_e[BRX_STAGE_COUNT];   /* begin / end of each stage on the launch stream */
     float stage_ms[BRX_STAGE_COUNT];
     uint32_t final_launches, mutate_passes;
-    int mutate_inline;
-    uint32_t seg_waves_per_cu;   /* BRX_SEG_WAVES_PER_CU: persistent waves of k_mutate_seg per CU */
-    uint32_t post_waves_per_cu;  /* BRX_POST_WAVES_PER_CU: waves of k_mut_post per CU (grid-stride over the pass's reads) */
-    int pass_seg;                /* BRX_PASS_SEG=1: bulk passes with the wave-per-read kernel of rounds 2-5 (k_mutate_seg<false>) */
     uint32_t tail_reads;         /* BRX_TAIL_READS: this few reads left in the mutate stage -> one in-place launch (0xFFFFFFFF = not set: n_reads / 8, at least 1024;
                                     measured on configs[3]: 1024 of 16384, 4096 of 49152) */
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
     uint32_t window_misses;      /* reads of the last batch whose final traceback left the stored window (phase 1) */
-    uint32_t lane_threshold;
-    uint32_t lane_waves;         /* BRX_LANE_WAVES: most waves of one k_win_lane launch */
-    uint32_t stage_words;        /* BRX_STAGE_WORDS: LDS words of a pass wave's slice that may hold a read (0 = never stage; at most the compiled size) */
     uint32_t fin_head_reads;     /* BRX_FIN_HEAD_READS: the longest reads of a batch form the head set of the final stage (side streams) */
     uint32_t head_reads;         /* BRX_HEAD_READS: the longest reads of a batch run as their own chain on the side stream (0 = off) */
     int wide_stream;             /* BRX_WIDE_STREAM: the head set's widest band class aligns on a third stream */
@@ -62,15 +54,13 @@ struct brx_ctx {
     hipEvent_t ev_fork2[2], ev_join2[2], ev_head_mut;
     hipEvent_t ev_fork3, ev_join3[2];   /* the bulk set's band classes on the head chain's streams */
     int fin_spread;                      /* BRX_FIN_SPREAD (default 1) */
-    uint32_t quad_wpc;                   /* BRX_QUAD_WAVES_PER_CU (default 4): most waves per CU of one k_fin_quad launch (four reads each) */
     uint32_t quad_min_reads;             /* BRX_QUAD_MIN_READS (default 4096): a set with fewer four-per-wave reads aligns them on whole waves */
     int fin_lanes;                       /* BRX_FIN_LANES (default 1): narrow-band final alignments one read per lane (k_fin_lanes) */
-    int fin_quad;                        /* BRX_FIN_QUAD (default 3): final alignments four per wave (k_fin_quad); bit 0: one-word bands, bit 1: two-word bands */
+    int fin_quad;                        /* BRX_FIN_QUAD (default 1): final alignments of one-word bands four per wave (k_fin_quad<1>) */
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
                                     three wide classes: a stream per class measured 30 % slower, r01d) */
     hipEvent_t ev_fork, ev_join;
-    hipEvent_t ev_wait;          /* blocking-sync event: the host thread SLEEPS in wait_stream instead of spinning (BRX_SPIN_WAIT=1: spin) */
-    int spin_wait;
+    hipEvent_t ev_wait;          /* the host thread polls this event with a short sleep in wait_stream (hipStreamSynchronize spins a core) */
     uint64_t *d_clk, *d_phase; uint32_t clk_reads;
     /* per-kernel launch timing (brx_set_kernel_timing / brx_last_kernel_stats): event pairs around every launch */
     int ktiming;
@@ -169,7 +159,6 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     if ((e = hipHostGetDevicePointer(&dp, c->h_totals, 0)) != hipSuccess) return create_fail(c, "hipHostGetDevicePointer", e);
     c->d_totals_alias = (uint8_t *)dp;
     c->d_prog = (uint32_t *)(c->d_totals_alias + 16 * sizeof(uint64_t));
-    { const char *v = getenv("BRX_BLIT"); c->blit = v ? atoi(v) : 0; }
     for (int i = 0; i < BRX_STAGE_COUNT; ++i) {
         if ((e = hipEventCreate(&c->ev_b[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
         if ((e = hipEventCreate(&c->ev_e[i])) != hipSuccess) return create_fail(c, "hipEventCreate", e);
@@ -184,32 +173,24 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
         (e = hipEventCreateWithFlags(&c->ev_join3[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_join3[1], hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *v = getenv("BRX_FIN_SPREAD"); c->fin_spread = v ? atoi(v) : 1; }
-    { const char *v = getenv("BRX_QUAD_WAVES_PER_CU"); c->quad_wpc = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 4u; }
     { const char *v = getenv("BRX_QUAD_MIN_READS"); c->quad_min_reads = v ? (uint32_t)atoi(v) : 4096u; }
     { const char *v = getenv("BRX_FIN_LANES"); c->fin_lanes = v ? atoi(v) : 1; }
-    /* default: the one-word class only.  Measured on configs[3] (profiles/r05a): 5.30 Gbases/s with it against 5.22 without; the
-       two-word class (bit 1: 14-26 superblocks of 32 rows as 7-13 of 64) costs 20.6 instructions per read column where the whole-wave
-       kernel costs 25 -- the per-lane bookkeeping of four rows eats the lanes it saves -- on half the waves: 4.62-4.67 with both */
-    { const char *v = getenv("BRX_FIN_QUAD"); c->fin_quad = v ? (atoi(v) & 3) : 1; }
+    /* the one-word class.  Measured on configs[3] (profiles/r05a): 5.30 Gbases/s with it against 5.22 without.  (A two-word class --
+       14-26 superblocks of 32 rows as 7-13 of 64 -- cost 20.6 instructions per read column where the whole-wave kernel costs 25, on
+       half the waves: 4.62-4.67 with both; round 6 removed its instantiation.  brx_quad.h keeps the words per lane a template
+       parameter.) */
+    { const char *v = getenv("BRX_FIN_QUAD"); c->fin_quad = v ? (atoi(v) & 1) : 1; }
     { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 512u; }
-    { const char *v = getenv("BRX_STAGE_WORDS"); c->stage_words = v ? std::min<uint32_t>((uint32_t)atoi(v), (uint32_t)BRX_STAGE_WORDS) : (uint32_t)BRX_STAGE_WORDS; }
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
     /* a context owns exactly three streams besides the caller's: every stream of a context takes a hardware queue, and two idle
        extra streams per context (6 contexts) cost 24 % of the rate (round 2, A/B on one box: 2.97 -> 2.27 Gbases/s) */
     if ((e = hipEventCreateWithFlags(&c->ev_wait, hipEventDisableTiming | hipEventBlockingSync)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
-    { const char *v = getenv("BRX_SPIN_WAIT"); c->spin_wait = v ? atoi(v) : 0; }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
-    { const char *mi = getenv("BRX_MUTATE_INLINE"); c->mutate_inline = (mi && atoi(mi)) ? 1 : 0; }
     { const char *pf = getenv("BRX_PROFILE"); c->profile = (pf && atoi(pf)) ? 1 : 0; }
     { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
     { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 0xFFFFFFFFu; }   /* unset: an eighth of the batch, at least 1024 */
-    { const char *sw = getenv("BRX_SEG_WAVES_PER_CU"); c->seg_waves_per_cu = sw && atoi(sw) > 0 ? (uint32_t)atoi(sw) : 8u; }
-    { const char *lt = getenv("BRX_LANE_THRESHOLD"); c->lane_threshold = lt ? (uint32_t)atoi(lt) : 3000u; }
-    { const char *v = getenv("BRX_POST_WAVES_PER_CU"); c->post_waves_per_cu = v ? std::max<uint32_t>(1u, (uint32_t)atoi(v)) : 32u; }
-    { const char *v = getenv("BRX_PASS_SEG"); c->pass_seg = v && atoi(v) != 0; }
-    { const char *v = getenv("BRX_LANE_WAVES"); c->lane_waves = v && atoi(v) > 0 ? (uint32_t)atoi(v) : 512u; }
     c->err[0] = 0;
     *out = c;
     return BRX_OK;
@@ -260,7 +241,6 @@ static int wait_stream(brx_ctx *c, hipStream_t st, const char *what) {
         /* A batch waits ~25 times for its stream, and a rank keeps six batches in flight on six host threads: hipStreamSynchronize
            spins, i.e. six busy cores per GPU -- 48 on an 8-GPU node whose container has 16.  The thread polls an event every 40 us
            instead (tens of microseconds later per wait, against ~1.7 s per batch). */
-        if (c->spin_wait) { HIPCHK(c, hipStreamSynchronize(st)); return BRX_OK; }
         HIPCHK(c, hipEventRecord(c->ev_wait, st));
         for (;;) {                                   /* hipEventSynchronize spins even on a blocking-sync event (measured: 6.1 busy cores per rank) */
             const hipError_t q = hipEventQuery(c->ev_wait);
@@ -352,7 +332,7 @@ static uint8_t *pinned_alias(brx_ctx *c, const void *h) {        /* device view 
 static int to_host(brx_ctx *c, hipStream_t st, void *h_dst, const void *d_src, size_t bytes) {
     /* the read states of a batch (10 MB, three times per batch) stay with the runtime's copy engine: as a kernel over PCIe they cost
        configs[4], whose batches take 0.4 s, 1.5 % (profiles/r05g); the kernels are for the few-word read-backs that sat behind blits */
-    uint8_t *alias = (c->blit || bytes > BRX_COPY_KERNEL_MAX) ? nullptr : pinned_alias(c, h_dst);
+    uint8_t *alias = (bytes > BRX_COPY_KERNEL_MAX) ? nullptr : pinned_alias(c, h_dst);
     if (!alias || (bytes & 3)) { HIPCHK(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st)); return BRX_OK; }
     const size_t n = bytes / 4;
     hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n + 255) / 256, 128)), dim3(64), 0, st, (uint32_t *)alias, (const uint32_t *)d_src, n);
@@ -360,7 +340,7 @@ static int to_host(brx_ctx *c, hipStream_t st, void *h_dst, const void *d_src, s
 }
 /* pinned host -> device; the host block must not change until the stream has been waited for */
 static int to_device(brx_ctx *c, hipStream_t st, void *d_dst, const void *h_src, size_t bytes) {
-    uint8_t *alias = (c->blit || bytes > BRX_COPY_KERNEL_MAX) ? nullptr : pinned_alias(c, h_src);
+    uint8_t *alias = (bytes > BRX_COPY_KERNEL_MAX) ? nullptr : pinned_alias(c, h_src);
     if (!alias || (bytes & 3)) { HIPCHK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st)); return BRX_OK; }
     const size_t n = bytes / 4;
     hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n + 255) / 256, 128)), dim3(64), 0, st, (uint32_t *)d_dst, (const uint32_t *)alias, n);
@@ -476,7 +456,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *F2buf = (uint32_t *)A.take(((size_t)f_bytes / 16 + 16) * 4);       /* the fragments as 2-bit codes: word F_off / 16 (k_build) */
     uint32_t *Cbuf = (uint32_t *)A.take(((size_t)f_bytes / 16 + 16) * 4);        /* a bit per base: replaced (same index) */
     const uint32_t side_waves = std::min<uint32_t>(n_reads, 4096u);                 /* wave-level window aligner / legacy */
-    const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, c->lane_waves);   /* lane-level window aligner: one 6.4 MB store of move codes per wave */
+    const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, 512u);   /* lane-level window aligner: one 6.4 MB store of move codes per wave */
     uint8_t *win = (uint8_t *)A.take((size_t)(side_waves + 1) * c->win_bytes);      /* one slot per wave */
     MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
     uint32_t *mctr = (uint32_t *)A.take(8 * MC_WORDS * sizeof(uint32_t));   /* pass counters 0/1, 2 first bulk input, 3 bulk legacy, 4 head input, 5 head legacy, 6 head pass */
@@ -488,18 +468,14 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *req_hard = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy_head = (uint32_t *)A.take((size_t)n_reads * 4);
-    uint32_t *active_head = (uint32_t *)A.take((size_t)n_reads * 4);
     uint8_t *winbuf = (uint8_t *)A.take((size_t)n_reads * BRX_WIN_STRIDE + 64);
     uint2 *lane_tb = (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
     /* the bulk passes' survivor rings (brx_passes.h): 20 bytes per entry, BRX_SV_CAP entries per read */
     PQ *pq = (PQ *)A.take((size_t)n_reads * sizeof(PQ));
     uint4 *sv_a = (uint4 *)A.take((size_t)n_reads * BRX_SV_CAP * sizeof(uint4));
     uint32_t *sv_z = (uint32_t *)A.take((size_t)n_reads * BRX_SV_CAP * sizeof(uint32_t));
-    /* traceback stores of the packed window aligner: one set of 8 per wave of k_win_pack */
-    const uint32_t pack_waves = std::min<uint32_t>((std::min<uint32_t>(n_reads, c->lane_threshold) + BRX_PACK_NG - 1) / BRX_PACK_NG, (uint32_t)c->n_cu * 4u);
     const uint32_t tail_eff = c->tail_reads != 0xFFFFFFFFu ? c->tail_reads : std::max<uint32_t>(1024u, n_reads / 8u);
-    const bool all_head = c->mutate_inline || n_reads <= tail_eff;      /* the whole batch in one run-to-completion launch */
-    uint2 *pack_tb = (uint2 *)A.take((size_t)std::max<uint32_t>(pack_waves, 1u) * BRX_PACK_NG * BRX_PACK_TB_UNITS * sizeof(uint2));
+    const bool all_head = n_reads <= tail_eff;      /* the whole batch in one run-to-completion launch */
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
     if (!raw) { KTIMED(BRX_KERN_PLAN, st); hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces); }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_PLAN], st));
@@ -634,8 +610,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         const uint32_t wpc = (uint32_t)c->waves_per_cu;
         const uint32_t limit[NCLS] = {(uint32_t)c->n_cu * std::max(wpc / 2u, 1u), (uint32_t)c->n_cu * std::max(wpc / 4u, 1u),
                                       (uint32_t)c->n_cu * std::max(wpc / 8u, 1u), (uint32_t)c->n_cu * std::max(wpc / 16u, 1u),
-                                      (uint32_t)c->n_cu * std::max(wpc / 4u, 1u), (uint32_t)c->n_cu * std::max(c->quad_wpc, 1u),
-                                      (uint32_t)c->n_cu * std::max(c->quad_wpc, 1u)};
+                                      (uint32_t)c->n_cu * std::max(wpc / 4u, 1u), (uint32_t)c->n_cu * std::max(wpc / 4u, 1u),
+                                      (uint32_t)c->n_cu * std::max(wpc / 4u, 1u)};
         uint32_t grid[NCLS];
         std::vector<uint64_t> sufmax[NCLS];
         for (int k = 0; k < NCLS; ++k) {
@@ -814,12 +790,6 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                                  reinterpret_cast<unsigned long long *>(cq + 2), d_slabs + slab_at[1], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk); }
             score_class(1, cls_stream[1], cq + 10);
         }
-        if (cnt[6]) {                                 /* bands of 14-26 superblocks of 32 rows, as two-word superblocks four reads per wave */
-            { KTIMED(BRX_KERN_FIN_QUAD2, cls_stream[1]);
-              hipLaunchKernelGGL((k_fin_quad<2>), dim3(grid[6]), dim3(64), 0, cls_stream[1], dev, rs, d_lists + list_at[6], cnt[6],
-                                 reinterpret_cast<unsigned long long *>(cq + 18), d_slabs + slab_at[6], misses, Fbuf, c->scratch, c->scratch, slab_base, clk); }
-            score_class(6, cls_stream[1], cq + 21);
-        }
         if (cnt[0]) {
             { KTIMED(BRX_KERN_FIN_ALIGN1, cls_stream[0]);
               hipLaunchKernelGGL((k_fin_align<1, 1, 1>), dim3(grid[0]), dim3(64), 0, cls_stream[0], dev, rs, d_lists + list_at[0], cnt[0],
@@ -931,17 +901,15 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         { int rc_ = to_device(c, st, mctr + 4 * MC_WORDS, h_ctr + MC_WORDS, MC_WORDS * sizeof(uint32_t)); if (rc_) return rc_; }
         { int rcw_ = wait_stream(c, st, "mutate counters"); if (rcw_) return rcw_; }
     }
-    const uint32_t lane_threshold = c->lane_threshold;   /* fewer active reads than this: one wave per window (lower latency) */
     /* reads taken to completion in ONE launch (the head set from the start; the last BRX_TAIL_READS of the bulk set):
        k_mutate_seg<true>, every read aligning its own windows with a whole wave.  (Rounds 2 and 3 measured three ways of
        taking these windows to a cheaper aligner -- workgroups of 8 reads with packed alignments, 8-wave pass kernels, a
        persistent launch with device queues -- and every one lost to this chain on the batch's critical path: DESIGN.md section 7.) */
-    auto launch_run = [&](hipStream_t s, uint32_t count, const uint32_t *act_in, const uint32_t *n_in, uint32_t *act_out, uint32_t *ctr,
-                          const MutAux *aux) {
+    auto launch_run = [&](hipStream_t s, uint32_t count, const uint32_t *act_in, const uint32_t *n_in, uint32_t *ctr, const MutAux *aux) {
         KTIMED(BRX_KERN_MUTATE_RUN, s);
 #define BRX_LAUNCH_RUN(PROF)                                                                                                        \
-        hipLaunchKernelGGL((k_mutate_seg<true, PROF, BRX_SEG_WPS>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in,   \
-                           act_out, ctr, aux, Fbuf, repl, lane_threshold, F2buf, Cbuf, c->stage_words, lane_cls)
+        hipLaunchKernelGGL((k_mutate_seg<PROF, BRX_SEG_WPS>), dim3(std::min(count, side_waves)), dim3(64), 0, s, dev, rs, msv, act_in, n_in,   \
+                           ctr, aux, Fbuf, repl, F2buf, Cbuf)
         if (c->profile) BRX_LAUNCH_RUN(true); else BRX_LAUNCH_RUN(false);
 #undef BRX_LAUNCH_RUN
     };
@@ -952,15 +920,14 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             HIPCHK(c, hipEventRecord(c->ev_fork, st));
             HIPCHK(c, hipStreamWaitEvent(s_head, c->ev_fork, 0));
         }
-        launch_run(s_head, n_mh, order, mctr + 4 * MC_WORDS + MC_OUT, active_head, mctr + 6 * MC_WORDS, aux_dev + 1);
+        launch_run(s_head, n_mh, order, mctr + 4 * MC_WORDS + MC_OUT, mctr + 6 * MC_WORDS, aux_dev + 1);
         if (n_mb) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
         c->mutate_passes = 1;
     }
     /* ---- bulk chain: passes ---- */
     int rc2 = BRX_OK;
     if (n_mb) {
-        const uint32_t seg_waves = std::min<uint64_t>(n_mb, (uint64_t)c->n_cu * (uint64_t)c->seg_waves_per_cu);
-        const uint32_t post_waves = std::min<uint64_t>(n_mb, (uint64_t)c->n_cu * (uint64_t)c->post_waves_per_cu);
+        const uint32_t post_waves = std::min<uint64_t>(n_mb, (uint64_t)c->n_cu * 32u);      /* k_mut_post: eight waves per SIMD, grid-stride over the pass's reads */
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;                                 /* [0] count, [1] queue; not reset per pass */
         const uint32_t *n_in = mctr + 2 * MC_WORDS + MC_OUT;
@@ -988,54 +955,37 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                     HIPCHK(c, hipStreamSynchronize(st));
                     for (uint32_t x : h_act) if (x < n_reads) tail_bases += h_rs[x].n;
                 }
-                launch_run(st, n_up, act_in, n_in, act_out, ctr, aux_dev);
+                launch_run(st, n_up, act_in, n_in, ctr, aux_dev);
                 rc2 = read_counts(ctr);
                 if (rc2) return rc2;
                 n_up = h_ctr[MC_OUT];                   /* 0 unless a window overflowed its slot (then: legacy list) */
                 ++pass;
                 break;
             }
-            /* which window kernel follows is the HOST's choice (its count of active reads may be a few passes old): the segment
-               kernel lists the windows for that kernel -- by band class for the lane kernel, one list for the packed one */
-            const uint32_t lane_pass_thr = n_up > lane_threshold ? 0u : 0xFFFFFFFFu;
-            if (!c->pass_seg) {
-                /* round 6 (brx_passes.h): the survivors of a read are applied by ONE LANE from the read's ring (k_mut_apply), a
-                   wave per read parks the window or writes the epilogue and proposes ahead (k_mut_post) */
-                if (pass == 0) {                       /* the first rings: every bulk read is "not started" */
-                    KTIMED(BRX_KERN_MUT_POST, st);
-                    hipLaunchKernelGGL((k_mut_post<BRX_POST_U>), dim3(std::min(post_waves, n_up)), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in,
-                                       h_aux[0], Fbuf, repl, lane_pass_thr, F2buf, Cbuf, sv_a, sv_z);
-                }
-                {
-                    KTIMED(BRX_KERN_MUTATE_SEG, st);
-                    hipLaunchKernelGGL(k_mut_apply, dim3((n_up + 63u) / 64u), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in, sv_a, sv_z, repl, Cbuf);
-                }
-                {
-                    KTIMED(BRX_KERN_MUT_POST, st);
-                    hipLaunchKernelGGL((k_mut_post<BRX_POST_U>), dim3(std::min(post_waves, n_up)), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in,
-                                       h_aux[0], Fbuf, repl, lane_pass_thr, F2buf, Cbuf, sv_a, sv_z);
-                    hipLaunchKernelGGL(k_pass_lists, dim3((n_up + 63u) / 64u), dim3(64), 0, st, msv, act_in, n_in, act_out, ctr,
-                                       lane_cls + (pass & 1u) * MC_WORDS * BRX_CLS_STRIDE, h_aux[0], n_reads, n_up > lane_threshold ? 1u : 0u);
-                }
-            } else {
-                KTIMED(BRX_KERN_MUTATE_SEG, st);
-                if (c->profile)
-                    hipLaunchKernelGGL((k_mutate_seg<false, true, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                                       ctr, aux_dev, Fbuf, repl, lane_pass_thr, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS * BRX_CLS_STRIDE);
-                else
-                    hipLaunchKernelGGL((k_mutate_seg<false, false, BRX_SEG_WPS>), dim3(std::min(seg_waves, n_up)), dim3(64), 0, st, dev, rs, msv, act_in, n_in, act_out,
-                                       ctr, aux_dev, Fbuf, repl, lane_pass_thr, F2buf, Cbuf, c->stage_words, lane_cls + (pass & 1u) * MC_WORDS * BRX_CLS_STRIDE);
+            /* round 6 (brx_passes.h): the survivors of a read are applied by ONE LANE from the read's ring (k_mut_apply), a
+               wave per read parks the window and proposes ahead (k_mut_post), the lists are appended by wave (k_pass_lists) */
+            if (pass == 0) {                       /* the first rings: every bulk read is "not started" */
+                KTIMED(BRX_KERN_MUT_POST, st);
+                hipLaunchKernelGGL((k_mut_post<BRX_POST_U>), dim3(std::min(post_waves, n_up)), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in,
+                                   h_aux[0], Fbuf, repl, F2buf, Cbuf, sv_a, sv_z);
             }
-            if (n_up > lane_threshold) {
+            {
+                KTIMED(BRX_KERN_MUTATE_SEG, st);
+                hipLaunchKernelGGL(k_mut_apply, dim3((n_up + 63u) / 64u), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in, sv_a, sv_z, repl, Cbuf);
+            }
+            {
+                KTIMED(BRX_KERN_MUT_POST, st);
+                hipLaunchKernelGGL((k_mut_post<BRX_POST_U>), dim3(std::min(post_waves, n_up)), dim3(64), 0, st, dev, rs, msv, pq, act_in, n_in,
+                                   h_aux[0], Fbuf, repl, F2buf, Cbuf, sv_a, sv_z);
+                hipLaunchKernelGGL(k_pass_lists, dim3((n_up + 63u) / 64u), dim3(64), 0, st, msv, act_in, n_in, act_out, ctr,
+                                   lane_cls + (pass & 1u) * MC_WORDS * BRX_CLS_STRIDE, h_aux[0], n_reads);
+            }
+            {
                 KTIMED(BRX_KERN_WIN_LANE, st);
                 hipLaunchKernelGGL(k_win_lane, dim3(std::min(lane_waves, (n_up + 63) / 64 + BRX_LANE_CLASSES)), dim3(64), 0, st, msv, req_easy,
                                    lane_cls + (pass & 1u) * MC_WORDS * BRX_CLS_STRIDE, n_reads, winbuf, lane_tb);
-            } else {                                   /* few reads left: eight windows per wave (same list, same class) */
-                KTIMED(BRX_KERN_WIN_LANE, st);
-                hipLaunchKernelGGL(k_win_pack, dim3(std::min(pack_waves, (n_up + BRX_PACK_NG - 1) / BRX_PACK_NG)), dim3(64), 0, st, msv, req_easy,
-                                   ctr + MC_EASY, ctr + 6, winbuf, pack_tb);
             }
-            {   /* the windows the lane / pack kernel does not take: one per wave; it also zeroes the counter block of the NEXT pass */
+            {   /* the windows the lane kernel does not take: one per wave; it also zeroes the counter block of the NEXT pass */
                 KTIMED(BRX_KERN_WIN_WAVE, st);
                 /* few windows take this kernel (symbols outside ACGT, very wide bands): 512 waves pull them from the queue; a grid of one
                    wave per active read was 4096 waves that start only to find the queue empty, once per pass on the critical path */
@@ -1056,7 +1006,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         }
         c->mutate_passes += pass;
         if (n_up > 0) return fail(c, BRX_E_INTERNAL, "mutate pipeline did not converge after %u passes", pass);
-        if (!c->pass_seg) {                            /* the reads that finished inside the passes: their epilogues, once */
+        {                                              /* the reads that finished inside the passes: their epilogues, once */
             KTIMED(BRX_KERN_MUT_POST, st);
             hipLaunchKernelGGL(k_mut_epilogue, dim3(std::min(post_waves, n_mb)), dim3(64), 0, st, dev, rs, msv, order + n_mh, n_mb, h_aux[0], Fbuf, repl);
         }
@@ -1136,12 +1086,11 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         c->kstat[BRX_KERN_PLAN].bases = c->kstat[BRX_KERN_BUILD].bases = c->kstat[BRX_KERN_FIN_JOIN].bases =
             c->kstat[BRX_KERN_FIN_QSCORE].bases = c->kstat[BRX_KERN_EMIT].bases = (double)all;
         c->kstat[BRX_KERN_MUTATE_RUN].bases = (double)(head_b + tail_bases);
-        c->kstat[BRX_KERN_MUTATE_SEG].bases = c->kstat[BRX_KERN_WIN_LANE].bases = c->kstat[BRX_KERN_WIN_WAVE].bases = (double)(all - head_b);
+        c->kstat[BRX_KERN_MUTATE_SEG].bases = c->kstat[BRX_KERN_MUT_POST].bases = c->kstat[BRX_KERN_WIN_LANE].bases = c->kstat[BRX_KERN_WIN_WAVE].bases = (double)(all - head_b);
         c->kstat[BRX_KERN_FIN_ALIGN1].bases = by_class[0]; c->kstat[BRX_KERN_FIN_ALIGN2].bases = by_class[1];
         c->kstat[BRX_KERN_FIN_ALIGN4].bases = by_class[2]; c->kstat[BRX_KERN_FIN_ALIGN16].bases = by_class[3];
         c->kstat[BRX_KERN_FIN_LANES].bases = (double)(sets[0].bases_by_class[5] + sets[1].bases_by_class[5]);
         c->kstat[BRX_KERN_FIN_QUAD1].bases = (double)(sets[0].bases_by_class[6] + sets[1].bases_by_class[6]);
-        c->kstat[BRX_KERN_FIN_QUAD2].bases = (double)(sets[0].bases_by_class[7] + sets[1].bases_by_class[7]);
         /* compatibility: the two per-launch stage entries of brx_last_stage_ms */
         if (c->kstat[BRX_KERN_FIN_ALIGN1].launches) c->stage_ms[BRX_STAGE_ALIGN1] = c->kstat[BRX_KERN_FIN_ALIGN1].ms / (float)c->kstat[BRX_KERN_FIN_ALIGN1].launches;
         if (c->kstat[BRX_KERN_FIN_QSCORE].launches) c->stage_ms[BRX_STAGE_QSCORE] = c->kstat[BRX_KERN_FIN_QSCORE].ms / (float)c->kstat[BRX_KERN_FIN_QSCORE].launches;

@@ -854,7 +854,6 @@ __global__ void __launch_bounds__(64) k_mutate(BrxDev d, RS *rs, const uint32_t 
     }
 }
 
-#include "brx_pack.h"
 #include "brx_mutate.h"
 #include "brx_passes.h"
 #include "brx_model.h"

@@ -8,12 +8,12 @@
  * with 3-4 of its 64 lanes busy -- r01 profiles: 80 % of the mutate stage.  Here the loop is cut at
  * every alignment:
  *
- *   k_mutate_seg   1 wave = 1 read.  Runs the loop until the read finishes or reaches an alignment;
- *                  there it writes the window pair to the read's slot (bytes and 2-bit planes), saves the
- *                  loop state (MS) and parks the read.  On the next pass it resumes in the middle of the
- *                  same k-mer.  k-mers come from the read's 2-bit codes (F2) and the "already changed"
- *                  test from a bit map, both staged in the wave's LDS slice for reads that fit; the error
- *                  model is read through its lookup-order tables (include/brx.h: d_rowx, d_altx).
+ *   k_mutate_seg   1 wave = 1 read, run to completion: the loop with every window aligned IN PLACE by the
+ *                  wave-systolic aligner (the head set of a batch and the in-place tail of its bulk set).  It
+ *                  takes a read over from the bulk passes in any state (MS).  k-mers come from the read's
+ *                  2-bit codes (F2); the error model is read through its lookup-order tables (include/brx.h:
+ *                  d_rowx, d_altx).  The BULK passes themselves are brx_passes.h (round 6): k_mut_apply (one
+ *                  read per lane), k_mut_post (park / propose ahead), k_pass_lists.
  *   k_win_lane     1 LANE = 1 parked window (64 windows per wave): banded block Myers over the window
  *                  with the band state, the query planes and a 32-column window of the target planes in
  *                  REGISTERS (the lanes are skewed so that every band moves in the same loop trip; no
@@ -22,7 +22,7 @@
  *   k_win_wave     1 wave = 1 parked window, for windows the lane kernel does not take (non-ACGT
  *                  symbols, very wide bands, very long targets): the wave-systolic aligner.
  *
- * The host repeats {k_mutate_seg, k_win_lane, k_win_wave} until no read is left.  Results are
+ * The host repeats {k_mut_apply, k_mut_post, k_pass_lists, k_win_lane, k_win_wave} until few reads are left.  Results are
  * identical to the sequential loop: proposals are pure functions of (seed, read, iteration), the
  * alignment result is applied exactly where the inline alignment was, and both aligners produce
  * the canonical path (distance, columns and matches are all that is used here).
@@ -84,26 +84,11 @@ __device__ __forceinline__ uint32_t brx_lane_class(int band_blocks) {
  * planes are ballots on that.  (Round 2 read both byte strings back from global memory: two more chains of dependent round
  * trips in a wave that has nothing else to do -- parking was 92 of the ~300 kcycles of a mutate cycle.) */
 #define BRX_PARK_LDS BRX_LANE_TMAX
-#if defined(__HIP_DEVICE_COMPILE__)
-#define BRX_KEEP2(a, b) asm volatile("" : "+v"(a), "+v"(b))       /* the values pass through an opaque point of the instruction stream */
-#else
-#define BRX_KEEP2(a, b) ((void)0)
-#endif
-/* LDS of a pass wave (k_mutate_seg<false>): the read it is working on -- F2 words [0, nw2], then the changed map -- while the
- * proposal rounds run; the parking pass, which ends the wave's work on the read, reuses the front of it as its byte window. */
-#ifndef BRX_STAGE_WORDS
-#define BRX_STAGE_WORDS 2560                              /* 10 KB: sixteen waves per CU keep their slices; F2 + map of reads up to 27 kb */
-#endif
-__shared__ uint32_t brx_stage_lds[BRX_STAGE_WORDS];
-/* the run-to-completion kernel never stages a read: its parking window is its own, smaller array (a 10 KB slice beside the
-   aligner's 2 KB ring would keep a CU at 13 of its 16 waves) */
-__shared__ uint32_t brx_park_small_lds[(BRX_WIN_BYTES - BRX_WIN_Q) / 4 + 4];
-/* k_mut_post (brx_passes.h) parks with planes and stages nothing: its own window-sized array */
-#define BRX_POST_LDS_WORDS ((BRX_WIN_BYTES - BRX_WIN_Q) / 4 + 4)
-__shared__ uint32_t brx_post_lds[BRX_POST_LDS_WORDS];
-#define brx_park_lds (reinterpret_cast<uint8_t *>(!PLANES ? brx_park_small_lds : POST ? brx_post_lds : brx_stage_lds))
-#define brx_park_lds_rows ((uint32_t)((POST ? BRX_POST_LDS_WORDS : BRX_STAGE_WORDS) / 4))
-static_assert(BRX_STAGE_WORDS * 4 >= BRX_WIN_BYTES - BRX_WIN_Q + 16, "the parking window lives in the staging slice");
+/* LDS of a parking wave: the joined window on its way to the slot (bytes) and to bit planes */
+#define BRX_PARK_LDS_WORDS ((BRX_WIN_BYTES - BRX_WIN_Q) / 4 + 4)
+__shared__ uint32_t brx_park_words[BRX_PARK_LDS_WORDS];
+#define brx_park_lds (reinterpret_cast<uint8_t *>(brx_park_words))
+#define brx_park_lds_rows ((uint32_t)(BRX_PARK_LDS_WORDS / 4))
 struct __attribute__((packed, aligned(1))) BrxB16 { uint32_t x, y, z, w; };      /* sixteen bytes behind any address */
 static_assert(BRX_ALIGN_SIZE + 16 <= 1024 && BRX_WIN_Q >= 1024, "a window is 64 lanes x 16 positions");
 
@@ -118,7 +103,7 @@ __device__ __forceinline__ uint32_t brx_byte_bits(uint32_t v, int bit) { return 
  * neighbouring lanes per plane word.  (The loop over 64-position steps it replaces made ~45 dependent global round trips
  * per parked window -- fragment byte and replacement, pool characters, scan, stores, sixteen times over: 77 k of the ~290 k
  * cycles of a mutate cycle, profiles/r04b.)  Memory image of the slot: as before. */
-template <bool PLANES, bool POST = false>
+template <bool PLANES>
 __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F, const uint32_t *repl, uint32_t a, uint32_t b,
                                      uint8_t *qb, uint8_t *tbuf, uint32_t tmax, uint32_t *cost, bool *odd, uint32_t *pl = nullptr) {
     const int lane = lane_id();
@@ -219,30 +204,24 @@ __device__ inline uint32_t wave_park(const brx_error_model &em, const uint8_t *F
 /* -------------------------------------------------------------------------------------------------
  * k_mutate_seg
  * ----------------------------------------------------------------------------------------------- */
-/* INLINE = false: park at every alignment (bulk passes).  INLINE = true: align in place with the
- * wave-systolic aligner and run every read to completion (the last few reads of a batch, where a
- * host round trip per alignment would cost more than the alignment). */
+/* Every read is run to completion, its windows aligned in place with the wave-systolic aligner: the head set of a batch (its
+ * longest chains, from the start) and the last reads of the bulk set, where a host round trip per alignment would cost more than
+ * the alignment.  (Until round 5 the same template, INLINE = false, was the bulk passes' kernel -- a wave per read that parked
+ * at every alignment, with the read staged in a 10 KB LDS slice; brx_passes.h replaced it.) */
 /* PROFILE = true (BRX_PROFILE=1): shader-clock time of every phase of the loop is added to phase[8 r + i]:
  *   0 propose (draws, k-mer bytes, table lookups)   1 apply survivors   2 park (window join + copies, state)
- *   3 in-place alignment (INLINE)   4 everything else   5 / 6 forward / traceback part of 3
+*   3 in-place alignment   4 everything else   5 / 6 forward / traceback part of 3
  * The phase clock is wave-uniform scalar code; the default instantiations do not contain it. */
 #define BRX_PHASE(next)                                                                                          \
     do { if constexpr (PROFILE) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); const uint64_t dt_ = now_ - ph_last;  \
              ph_last = now_; ph0 += ph_cur == 0 ? dt_ : 0; ph1 += ph_cur == 1 ? dt_ : 0; ph2 += ph_cur == 2 ? dt_ : 0;   \
              ph3 += ph_cur == 3 ? dt_ : 0; ph4 += ph_cur == 4 ? dt_ : 0; ph_cur = (next); } } while (0)
 
-/* One wave per workgroup and the self thresholds read through L2.  Staging the thresholds in LDS (32 KB of 16-bit halves for
- * k = 7: SURVEY.md section 0.6 / Appendix C) needs workgroups of several waves to pay for the table, and was measured three
- * times, bit-exact each time, slower each time: pass kernels as 4-8-wave workgroups (round 2: 1.69-1.75 vs 2.02 Gbases/s -- a short
- * kernel that needs 4-8 free wave slots on ONE CU is dispatched late), a workgroup kernel with packed alignments (round 2: 1.57-1.71
- * vs 2.04), a persistent launch with device queues (round 3: 0.65-1.6 vs 2.96).  What the table would save
- * is one 4-byte L2 hit per proposal. */
 /* WPS = waves per SIMD the register budget is set for.  Measured (round 4, configs[3], six batches in flight): the run-to-
  * completion instantiation carries the wave aligner's registers beside the loop state and keeps 160 B per lane in scratch memory
  * at four waves per SIMD (128 VGPRs), nothing at two (214) -- and the un-spilled build is SLOWER (4.30-4.34 against 4.46 Gbases/s,
  * again 4.70-4.72 against 4.76 on the next tree): the head chain is one wave per SIMD, but its registers are taken from the
- * other five batches' kernels on the same SIMDs.  The pass kernel at three waves (156 VGPRs, no scratch) against four (128,
- * 116 B): 4.76 against 4.88.  Four it is, for both. */
+ * other five batches' kernels on the same SIMDs.  Four it is. */
 /* What only parking, the in-place alignment and the epilogue use -- once per alignment cycle -- lives in device memory and is read
  * where it is used (a volatile load: not hoisted), not in kernel arguments: the kernel runs at its SGPR limit (106), a fifth of its
  * instructions were v_readlane / v_writelane spill traffic, and every argument is two SGPRs that stay live over the whole loop. */
@@ -264,12 +243,11 @@ __device__ __forceinline__ T brx_cold(T const *field) {
     return out;
 }
 
-template <bool INLINE, bool PROFILE = false, int WPS = 4>
+template <bool PROFILE = false, int WPS = 4>
 __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *msv, const uint32_t *active_in,
-                                                    const uint32_t *n_in_ptr, uint32_t *active_out, uint32_t *ctr,
+                                                    const uint32_t *n_in_ptr, uint32_t *ctr,
                                                     const MutAux *aux, const uint8_t *Fbuf, uint32_t *repl,
-                                                    uint32_t lane_threshold, const uint32_t *F2buf, uint32_t *Cbuf, uint32_t stage_words,
-                                                    uint32_t *lane_cls) {
+                                                    const uint32_t *F2buf, const uint32_t *Cbuf) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
     const int k = em.k;
@@ -290,29 +268,12 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
         const uint32_t n = s.n;
         const uint8_t *F = Fbuf + s.F_off;
         uint32_t *rp = repl + s.F_off;
-        /* ---- the read as 2-bit codes (k_build): k-mers of the proposal rounds come from these.  A pass wave stages them in
-           its LDS slice together with the changed map when both fit (STAGED); otherwise the codes are read from global memory
-           (3.75 KB per 15 kb read: L2 resident) and the changed test stays on repl[].  A read that holds a symbol outside ACGT
-           keeps to the bytes. ---- */
+        /* ---- the read as 2-bit codes (k_build): k-mers of the proposal rounds come from these (3.75 KB per 15 kb read: L2
+           resident); the changed test is on repl[].  A read that holds a symbol outside ACGT keeps to the bytes for those k-mers. ---- */
         const uint32_t *f2g = F2buf + (s.F_off >> 4);
-        uint32_t *cmg = Cbuf + (s.F_off >> 4);
         const uint32_t nw2 = (n + 15u) >> 4, nwc = (n + 31u) >> 5;
         const bool coded = uni(f2g[nw2] == 0u);
-        /* the slice: [0, nwc) the changed map when it fits (reads up to 82 kb), behind it the codes when they fit as well
-           (up to 27 kb).  With the map in LDS an applied change is visible to the next survivor's test without waiting
-           for its store to repl[] to come back (the fence per change below: ~2 k cycles each, 25 per cycle). */
-        const bool staged_cm = !INLINE && uni(nwc <= stage_words);
-        const bool staged = staged_cm && uni(nwc + nw2 + 1u <= stage_words);
-        const uint32_t *oddg = cmg + nwc;                                /* a bit per base: a symbol outside ACGT (k_build) */
-        const uint32_t f20 = nwc;                                        /* first word of the codes in the slice */
-        if constexpr (!INLINE) {
-            if (staged_cm) {
-                for (uint32_t x = (uint32_t)lane; x < nwc; x += 64u) brx_stage_lds[x] = cmg[x];
-                if (staged) for (uint32_t x = (uint32_t)lane; x <= nw2; x += 64u) brx_stage_lds[f20 + x] = f2g[x];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_s_waitcnt(0);
-            }
-        }
+        const uint32_t *oddg = Cbuf + (s.F_off >> 4) + nwc;              /* a bit per base: a symbol outside ACGT (k_build) */
         const double target = s.target;
         const double dn = (double)n;
         const uint64_t max_i = (uint64_t)n - 1 - (uint64_t)k;
@@ -324,7 +285,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
         uint32_t change = 0, nalign = 0;
         uint32_t st_extra = ms.status;
         bool parked = false;
-      for (;;) {                                   /* INLINE: one trip per alignment of this read */
+      for (;;) {                                   /* one trip per alignment of this read */
         errors = 0.0; loops = 0; change = 0; nalign = 0;
         /* phase 4 (brx_passes.h, MP_HUNGRY): a read taken over from the bulk passes between two survivors, no alignment pending --
            a resumed round at iteration round_loops (surv_lane = j_next = 0) whose errors are NOT blended */
@@ -364,11 +325,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                 brx_draw4(d.seed, read, BRX_ST_MUT, loops + (uint64_t)lane, w);
                 ipos = brx_mulhi64(((uint64_t)w[1] << 32) | w[0], max_i + 1);
                 const uint32_t wi = (uint32_t)(ipos >> 4), sh = 2u * ((uint32_t)ipos & 15u);
-                uint32_t w0, w1;
-                /* two loads in two address spaces: the empty asm keeps the compiler from folding the branches into ONE load
-                   through a selected generic pointer (a flat load: DESIGN.md section 5, lessons) */
-                if (staged) { w0 = brx_stage_lds[f20 + wi]; w1 = brx_stage_lds[f20 + wi + 1u]; BRX_KEEP2(w0, w1); }
-                else { w0 = f2g[wi]; w1 = f2g[wi + 1u]; BRX_KEEP2(w0, w1); }
+                const uint32_t w0 = f2g[wi], w1 = f2g[wi + 1u];
                 const uint32_t row = (uint32_t)(((((uint64_t)w0 << 32) | (uint64_t)w1) << sh) >> (64 - 2 * k));
                 bool bad = false;                   /* a symbol outside ACGT in the k-mer: error_model.py:142-143 */
                 if (!coded) {
@@ -398,10 +355,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                    changed positions (simulate.py:309) are applied in order */
                 const uint32_t wj = brx_prop_word(em, wave_bcast_u32(pr.x, l), wave_bcast_u32(pr.y, l), wave_bcast_u32(pr.z, l));
                 uint32_t curj = 1u;
-                if (staged_cm) {
-                    const uint32_t pp = (uint32_t)i0 + (uint32_t)lane;
-                    if (lane < k) curj = (brx_stage_lds[pp >> 5] >> (pp & 31u)) & 1u;
-                } else if (lane < k) curj = rp[i0 + (uint64_t)lane];
+                if (lane < k) curj = rp[i0 + (uint64_t)lane];
                 unsigned long long todo = __ballot(lane < k && wj != 0u && curj == 0u);
                 if (first) todo &= ~((1ull << j0) - 1ull);
                 const bool applies = todo != 0ull;
@@ -412,21 +366,8 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                     const int j = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
                     const uint32_t w = wave_bcast_u32(wj, j);
-                    if (lane == j) {
-                        rp[i0 + (uint64_t)j] = w;
-                        if constexpr (!INLINE) {
-                            /* the map in global memory is what the next pass stages; the slice is what this one reads.  One lane,
-                               plain read-modify-write: this wave is the only writer of the read's map, its LDS operations stay in
-                               order, and without the slice the fence below orders the words in memory.  (As atomics these two cost
-                               ~25 instructions each: the compiler wraps every atomic in a wave-wide reduction.) */
-                            const uint32_t pp = (uint32_t)i0 + (uint32_t)j;
-                            uint32_t word;
-                            if (staged_cm) { word = brx_stage_lds[pp >> 5] | (1u << (pp & 31u)); brx_stage_lds[pp >> 5] = word; }
-                            else word = cmg[pp >> 5] | (1u << (pp & 31u));
-                            cmg[pp >> 5] = word;
-                        }
-                    }
-                    if (!staged_cm) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      /* the next survivor tests repl[] */
+                    if (lane == j) rp[i0 + (uint64_t)j] = w;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      /* the next survivor tests repl[] */
                     change += 1;
                     const uint32_t len = (w >> 24) & 0x7Fu;
                     errors += (double)(len < 2 ? 1u : len - 1u) * scale;
@@ -448,51 +389,26 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
                         uint32_t cost = 0;
                         uint8_t *qb = brx_cold(&aux->winbuf) + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
                         bool odd = false;
-                        const uint32_t tl = wave_park<!INLINE>(em, F, rp, a, b, qb, tbuf, BRX_WIN_TMAX, &cost, &odd,
-                                                               reinterpret_cast<uint32_t *>(qb + BRX_WIN_PLANES));
+                        const uint32_t tl = wave_park<false>(em, F, rp, a, b, qb, tbuf, BRX_WIN_TMAX, &cost, &odd);
                         const uint32_t ql = b - a;
-                        uint32_t klass = MC_LEGACY;
-                        int band_blocks_of = 0;
-                        if (tl <= BRX_WIN_TMAX) {
-                            if constexpr (INLINE) {                    /* the in-place aligner below reads the bytes back */
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                                __builtin_amdgcn_s_waitcnt(0);
-                            }
-                            const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
-                            const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
-                            band_blocks_of = band_blocks;
-                            /* "easy" windows go to a throughput kernel: one window per LANE while the pass is large, eight
-                               windows per wave (k_win_pack) once fewer than lane_threshold reads are active */
-                            const bool easy = !INLINE && !odd && g.G == 1 && tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 &&
-                                              (n_in > lane_threshold ? band_blocks <= BRX_LANE_W : brx_pack_eligible(ql, tl, cost, odd));
-                            klass = easy ? MC_EASY : MC_HARD;
+                        const bool fits = tl <= BRX_WIN_TMAX;       /* else: the whole-read kernel (k_mutate) starts the read over */
+                        if (fits) {                                 /* the in-place aligner below reads the bytes back */
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __builtin_amdgcn_s_waitcnt(0);
                         }
-                        /* the lists a parked read is entered in (read here by the whole wave, used by lane 0) */
-                        uint32_t *c_easy = brx_cold(&aux->req_easy), *c_hard = brx_cold(&aux->req_hard), *c_legacy = brx_cold(&aux->req_legacy);
-                        uint32_t *c_legacy_ctr = brx_cold(&aux->legacy_ctr);
                         {
                             MS o = ms;
                             o.errors = errors; o.est = est; o.round_loops = loops; o.change = change; o.nalign = nalign;
-                            o.phase = klass == MC_LEGACY ? 3u : 1u;
+                            o.phase = fits ? 1u : 3u;
                             o.surv_lane = (uint32_t)l; o.j_next = (uint32_t)(j + 1);
                             o.win_a = a; o.win_b = b; o.tl = tl; o.cost = cost; o.res_ncols = 0; o.res_nmatch = 0;
                             o.passes = ms.passes + 1; o.status = st_extra;
-                            if (INLINE && klass != MC_LEGACY) ms = o;          /* stays in registers: aligned below */
-                            else if (lane == 0) {
-                                msv[r] = o;
-                                if (klass == MC_EASY && n_in > lane_threshold) {
-                                    /* lane passes: the windows are listed by band width (BRX_LANE_CLASSES lists of d.n_reads entries),
-                                       so that the 64 windows of a lane-kernel wave are equally wide (k_win_lane) */
-                                    const uint32_t cls = brx_lane_class(band_blocks_of);
-                                    c_easy[(size_t)cls * d.n_reads + atomicAdd(&lane_cls[cls * BRX_CLS_STRIDE], 1u)] = r;
-                                    atomicAdd(&ctr[MC_EASY], 1u);
-                                } else {
-                                    uint32_t *list = klass == MC_EASY ? c_easy : klass == MC_HARD ? c_hard : c_legacy;
-                                    list[atomicAdd(klass == MC_LEGACY ? c_legacy_ctr : &ctr[klass], 1u)] = r;
-                                }
-                                if (klass != MC_LEGACY) active_out[atomicAdd(&ctr[MC_OUT], 1u)] = r;
+                            if (fits) ms = o;                       /* stays in registers: aligned below */
+                            else {
+                                uint32_t *c_legacy = brx_cold(&aux->req_legacy), *c_legacy_ctr = brx_cold(&aux->legacy_ctr);
+                                if (lane == 0) { msv[r] = o; c_legacy[atomicAdd(c_legacy_ctr, 1u)] = r; }
+                                ms.phase = 3u;
                             }
-                            if (klass == MC_LEGACY) ms.phase = 3u;
                         }
                         parked = true;
                         break;
@@ -513,7 +429,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
             if (B < 64) { loops += 1; break; }
         }
         BRX_PHASE(4);
-        if (INLINE && parked && ms.phase == 1u) {
+        if (parked && ms.phase == 1u) {
             /* align the parked window here, at the top level where only MS is live, and resume the same read */
             const uint8_t *qb = brx_cold(&aux->winbuf) + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
             const uint64_t scr_bytes = brx_cold(&aux->scr_bytes);
@@ -559,7 +475,7 @@ __global__ void __launch_bounds__(64, WPS) k_mutate_seg(BrxDev d, RS *rs, MS *ms
             o->loops = (uint32_t)loops; o->changes = change; o->naligns = nalign;
             o->units = 0;                                          /* sized by k_fin_join */
             msv[r].phase = 2u;
-            ck[0] += __builtin_amdgcn_s_memtime() - t_begin; ck[1] = INLINE ? nalign : ms.passes;
+            ck[0] += __builtin_amdgcn_s_memtime() - t_begin; ck[1] = nalign;
         }
     }
 }
@@ -800,64 +716,6 @@ __global__ void __launch_bounds__(64, 4) k_win_lane(MS *msv, const uint32_t *req
         if (valid) {
             msv[r].res_ncols = ncols; msv[r].res_nmatch = nmatch;
             if (!ok) msv[r].status = ms.status | BRX_RS_BAND;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-    }
-}
-
-/* -------------------------------------------------------------------------------------------------
- * k_win_pack: EIGHT parked windows per wave (brx_pack.h), for passes with few active reads
- * -----------------------------------------------------------------------------------------------
- * The lane-per-window kernel is the cheapest in instructions (1.9 k wave-instructions per window) but one launch takes
- * 2.4-7 ms, because a lane walks 1000 columns alone; the wave-per-window aligner answers in ~0.1 ms but spends a whole
- * wave's instruction stream on 4-6 busy lanes (61 k per window), which is what made the in-place tail of round 1 17 % of
- * all VALU instructions of a batch -- on a path that is bound by VALU issue.  Passes with fewer than BRX_LANE_THRESHOLD
- * active reads (the long reads: hundreds of dependent cycles) therefore use this kernel: 8 windows share a wave (12 k
- * per window), one launch takes ~0.3 ms.  A wave pulls eight requests, turns their byte pairs (winbuf slots written by
- * wave_park) into 2-bit planes in LDS, aligns them and writes the results to the reads' MS. */
-__global__ void __launch_bounds__(64, 4) k_win_pack(MS *msv, const uint32_t *req, const uint32_t *n_req_ptr, uint32_t *queue,
-                                                  const uint8_t *winbuf, uint2 *tb_base) {
-    __shared__ BrxPackWin s_win[BRX_PACK_NG];
-    const int lane = lane_id();
-    const uint32_t n_req = uni(*n_req_ptr);
-    uint2 *tb = tb_base + (size_t)blockIdx.x * (size_t)BRX_PACK_NG * (size_t)BRX_PACK_TB_UNITS;
-    for (;;) {
-        const uint32_t q0 = uni(atomicAdd(queue, lane == 0 ? (uint32_t)BRX_PACK_NG : 0u));
-        if (q0 >= n_req) break;
-        const uint32_t cnt = n_req - q0 < (uint32_t)BRX_PACK_NG ? n_req - q0 : (uint32_t)BRX_PACK_NG;
-        /* ---- planes of the (up to) eight pairs: 64 symbols per step, one ballot per plane ---- */
-        for (uint32_t w = 0; w < (uint32_t)BRX_PACK_NG; ++w) {
-            BrxPackWin &W = s_win[w];
-            if (w >= cnt) { if (lane == 0) { W.Q = 0; W.T = 0; W.k = 0; } continue; }
-            const uint32_t r = req[q0 + w];
-            const MS ms = msv[r];
-            const uint32_t Q = ms.win_b - ms.win_a, T = ms.tl;
-            const uint8_t *qb = winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
-            for (uint32_t it = 0; 64u * it < Q; ++it) {
-                const uint32_t x = 64u * it + (uint32_t)lane;
-                const uint32_t c = x < Q ? qb[x] : 0u;
-                const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
-                if (lane < 2) { W.qlo[2 * it + lane] = (uint32_t)(lo >> (32 * lane)); W.qhi[2 * it + lane] = (uint32_t)(hi >> (32 * lane)); }
-            }
-            for (uint32_t it = 0; 64u * it < T; ++it) {
-                const uint32_t x = 64u * it + (uint32_t)lane;
-                const uint32_t c = x < T ? tbuf[x] : 0u;
-                const unsigned long long lo = __ballot(c & 1u), hi = __ballot(c & 2u);
-                if (lane < 2 && 2 * it + lane < BRX_PACK_TW) { W.tlo[2 * it + lane] = (uint32_t)(lo >> (32 * lane)); W.thi[2 * it + lane] = (uint32_t)(hi >> (32 * lane)); }
-            }
-            if (lane == 0) { W.Q = Q; W.T = T; W.k = ms.cost; W.ncols = 0; W.nmatch = 0; W.ok = 0; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        brx_pack_align(s_win, tb);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        if ((uint32_t)lane < cnt) {
-            const uint32_t r = req[q0 + (uint32_t)lane];
-            const BrxPackWin &W = s_win[lane];
-            msv[r].res_ncols = W.ncols; msv[r].res_nmatch = W.nmatch;
-            if (!W.ok) msv[r].status |= BRX_RS_BAND;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);

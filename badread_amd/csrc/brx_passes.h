@@ -28,7 +28,7 @@
  *                without an alignment).  A read's map, replacement words and ring are touched by ONE lane, so program order is
  *                all the ordering there is: no fences, no LDS.  64 reads share every instruction the old kernel issued for one.
  *
- * The pass is then {k_mut_apply, k_mut_post, k_win_lane | k_win_pack, k_win_wave}.  Results are identical to the sequential
+ * The pass is then {k_mut_apply, k_mut_post, k_pass_lists, k_win_lane, k_win_wave}.  Results are identical to the sequential
  * loop, and to k_mutate_seg<true> (which still runs the head set and the in-place tail and takes reads over in any state:
  * MS keeps its meaning -- round_loops / surv_lane / j_next name the survivor to resume in).
  */
@@ -199,7 +199,7 @@ __device__ __forceinline__ bool brx_propose_iter(const BrxDev &d, uint64_t read,
 
 template <int U>
 __global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, PQ *pq, const uint32_t *active_in, const uint32_t *n_in_ptr,
-                                                     const MutAux aux, const uint8_t *Fbuf, uint32_t *repl, uint32_t lane_threshold,
+                                                     const MutAux aux, const uint8_t *Fbuf, uint32_t *repl,
                                                      const uint32_t *F2buf, const uint32_t *Cbuf, uint4 *sv_a, uint32_t *sv_z) {
     const int lane = lane_id();
     const brx_error_model &em = d.em;
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, P
             uint32_t cost = 0;
             uint8_t *qb = aux.winbuf + (uint64_t)r * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
             bool odd = false;
-            const uint32_t tl = wave_park<true, true>(em, F, rp, a, b, qb, tbuf, BRX_WIN_TMAX, &cost, &odd, reinterpret_cast<uint32_t *>(qb + BRX_WIN_PLANES));
+            const uint32_t tl = wave_park<true>(em, F, rp, a, b, qb, tbuf, BRX_WIN_TMAX, &cost, &odd, reinterpret_cast<uint32_t *>(qb + BRX_WIN_PLANES));
             const uint32_t ql = b - a;
             uint32_t klass = MC_LEGACY;
             int band_blocks_of = 0;
@@ -236,10 +236,8 @@ __global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, P
                 const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
                 const int band_blocks = (g.dhi - g.dlo) / 32 + 2;
                 band_blocks_of = band_blocks;
-                /* "easy" windows go to a throughput kernel: one window per LANE while the pass is large, eight windows per wave
-                   (k_win_pack) once fewer than lane_threshold reads are active */
-                const bool easy = !odd && g.G == 1 && tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 &&
-                                  (n_in > lane_threshold ? band_blocks <= BRX_LANE_W : brx_pack_eligible(ql, tl, cost, odd));
+                /* "easy" windows go to the throughput kernel: one window per LANE (k_win_lane) */
+                const bool easy = !odd && g.G == 1 && tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 && band_blocks <= BRX_LANE_W;
                 klass = easy ? MC_EASY : MC_HARD;
             }
             if (lane == 0) {
@@ -333,13 +331,13 @@ __global__ void __launch_bounds__(64, 8) k_mut_epilogue(BrxDev d, RS *rs, MS *ms
  * k_pass_lists: one read per lane -- the lists of the pass's window kernels and of the next pass
  * -----------------------------------------------------------------------------------------------
  * Every read of the pass enters the list its state names: the next pass's input (parked or hungry), the lane kernel's list of its
- * band class (or the packed kernel's one list), the wave kernel's list, the whole-read kernel's list.  An append is
+ * band class, the wave kernel's list, the whole-read kernel's list.  An append is
  * `atomicAdd(counter, pred)` by EVERY lane on a wave-uniform address: the compiler turns that into one atomic per wave and a prefix
  * over the lanes.  (Rounds 2-5 appended from one lane of a wave per read: three to four device-scope atomics per read and pass on
  * two cache lines -- at 11.4 ns per atomic on a line, profiles/r06_atomic_bench.jsonl, the first pass of a 65536-read batch could
  * not take less than 2.2 ms whatever its waves did: the pass kernel of those rounds was waiting for THIS 60 % of its time.) */
 __global__ void __launch_bounds__(64) k_pass_lists(const MS *msv, const uint32_t *active_in, const uint32_t *n_in_ptr, uint32_t *active_out,
-                                                    uint32_t *ctr, uint32_t *lane_cls, const MutAux aux, uint32_t n_reads, uint32_t lane_mode) {
+                                                    uint32_t *ctr, uint32_t *lane_cls, const MutAux aux, uint32_t n_reads) {
     const uint32_t idx = blockIdx.x * 64u + (uint32_t)lane_id();
     const bool in = idx < *n_in_ptr;
     const uint32_t r = in ? active_in[idx] : 0u;
@@ -351,21 +349,12 @@ __global__ void __launch_bounds__(64) k_pass_lists(const MS *msv, const uint32_t
         const uint32_t at = atomicAdd(&ctr[MC_OUT], p ? 1u : 0u);
         if (p) active_out[at] = r;
     }
-    if (lane_mode) {
 #pragma unroll
-        for (uint32_t cc = 0; cc < (uint32_t)BRX_LANE_CLASSES; ++cc) {
-            const bool p = parked && klass == (uint32_t)MC_EASY && cls == cc;
-            if (__ballot(p) == 0ull) continue;
-            const uint32_t at = atomicAdd(&lane_cls[cc * BRX_CLS_STRIDE], p ? 1u : 0u);
-            if (p) aux.req_easy[(size_t)cc * n_reads + at] = r;
-        }
-    }
-    {
-        const bool p = parked && klass == (uint32_t)MC_EASY;
-        if (__ballot(p) != 0ull) {
-            const uint32_t at = atomicAdd(&ctr[MC_EASY], p ? 1u : 0u);
-            if (p && !lane_mode) aux.req_easy[at] = r;
-        }
+    for (uint32_t cc = 0; cc < (uint32_t)BRX_LANE_CLASSES; ++cc) {
+        const bool p = parked && klass == (uint32_t)MC_EASY && cls == cc;
+        if (__ballot(p) == 0ull) continue;
+        const uint32_t at = atomicAdd(&lane_cls[cc * BRX_CLS_STRIDE], p ? 1u : 0u);
+        if (p) aux.req_easy[(size_t)cc * n_reads + at] = r;
     }
     {
         const bool p = parked && klass == (uint32_t)MC_HARD;

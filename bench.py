@@ -254,10 +254,10 @@ def aligner_lane_model(stats):
     lanes = np.full_like(bw, 64.0)
     quad_bits = int(os.environ.get('BRX_FIN_QUAD', '1') or 0)
     if quad_bits:
-        # four reads per wave (k_fin_quad, csrc/brx_quad.h): a row of 16 lanes x 1 word up to 13 x 32 diagonals (the default), x 2 words
-        # up to 13 x 64 (BRX_FIN_QUAD=3); reads with symbols outside ACGT keep to the whole wave: not visible in the statistics, a few per thousand
+        # four reads per wave (k_fin_quad<1>, csrc/brx_quad.h): a row of 16 lanes x 1 word up to 13 x 32 diagonals; reads with symbols
+        # outside ACGT keep to the whole wave: not visible in the statistics, a few per thousand
         quad1 = (bw <= 13.0 * 32.0) & (bw > 88.0) & live & bool(quad_bits & 1)      # (up to 88 diagonals: the one-read-per-lane class)
-        quad2 = (bw > 13.0 * 32.0) & (bw <= 13.0 * 64.0) & live & bool(quad_bits & 2)
+        quad2 = np.zeros_like(quad1)                                                  # (a two-word class existed in round 5 and lost: removed)
         if int((quad1 | quad2).sum()) < int(os.environ.get('BRX_QUAD_MIN_READS', '4096')):      # a small class keeps to whole waves (brx_hip.hip)
             quad1 = quad2 = np.zeros_like(live)
         lanes = np.where(quad1 | quad2, 16.0, lanes)

@@ -269,9 +269,9 @@ uint32_t brx_last_mutate_passes(const brx_ctx *ctx);
  * average launch duration ms / launches is what a rocprofv3 kernel trace reports for the same kernel. */
 enum { BRX_KERN_PLAN = 0,        /* k_plan_count + k_scan_plan + k_plan_fill                                   */
        BRX_KERN_BUILD = 1,       /* k_build                                                                    */
-       BRX_KERN_MUTATE_SEG = 2,  /* k_mut_apply (round 6; k_mutate_seg<false> under BRX_PASS_SEG=1): bulk passes   */
-       BRX_KERN_MUTATE_RUN = 3,  /* k_mutate_seg<true>: reads run to completion with in-place window alignments */
-       BRX_KERN_WIN_LANE = 4,    /* k_win_lane / k_win_pack: parked window alignments of a bulk pass            */
+       BRX_KERN_MUTATE_SEG = 2,  /* k_mut_apply: the sequential half of the bulk passes, one read per lane (round 6)  */
+       BRX_KERN_MUTATE_RUN = 3,  /* k_mutate_seg: reads run to completion with in-place window alignments        */
+       BRX_KERN_WIN_LANE = 4,    /* k_win_lane: parked window alignments of a bulk pass, one window per lane    */
        BRX_KERN_WIN_WAVE = 5,    /* k_win_wave                                                                 */
        BRX_KERN_FIN_JOIN = 6,
        BRX_KERN_FIN_ALIGN1 = 7,  /* k_fin_align<1,1,1>                                                         */
@@ -282,9 +282,8 @@ enum { BRX_KERN_PLAN = 0,        /* k_plan_count + k_scan_plan + k_plan_fill    
        BRX_KERN_EMIT = 12,       /* k_recsize + k_scan_rec + k_emit + k_stats                                  */
        BRX_KERN_FIN_LANES = 13,  /* k_fin_lanes: final alignments with a band of up to four blocks, one read per lane */
        BRX_KERN_FIN_QUAD1 = 14,  /* k_fin_quad<1>: bands of up to 13 superblocks of one word, four reads per wave      */
-       BRX_KERN_FIN_QUAD2 = 15,  /* k_fin_quad<2>: ... of two words                                                    */
-       BRX_KERN_MUT_POST = 16,   /* k_mut_post: parking / epilogue / proposals ahead of the bulk passes (round 6)       */
-       BRX_KERN_COUNT = 17 };
+       BRX_KERN_MUT_POST = 15,   /* k_mut_post + k_pass_lists + k_mut_epilogue: parking, proposals ahead, lists, epilogues of the bulk passes (round 6) */
+       BRX_KERN_COUNT = 16 };
 typedef struct {
     uint32_t launches;
     float ms;                  /* sum of the launches' event durations                                          */

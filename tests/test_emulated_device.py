@@ -72,20 +72,16 @@ def test_aligner_band_classes_iupac_and_hints():
 
 
 ROUTES = [
-    {},                                                        # defaults: pass pipeline (all head here: few reads), windowed store
+    {},                                                        # defaults: few reads, all head -- every read run to completion in place (k_mutate_seg), windowed store
     {'BRX_TB_WINDOW': -1},                                     # 8-row traceback window: most reads repeat (phase 1)
     {'BRX_TB_WINDOW': 0, 'BRX_WIDE_STREAM': 0},                # full store, no third stream for the widest class
-    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0},         # bulk passes only: every window through the lane kernel (band state in registers)
-    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 1000000},   # bulk passes only: eight windows per wave (k_win_pack), the rest through the wave kernel
-    {'BRX_TAIL_READS': 6, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_FIN_HEAD_READS': 9},   # passes with packed windows, a 6-read in-place tail, final stage in two sets
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0},         # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 1000000, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
-    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0, 'BRX_WAVES_PER_CU': 2},       # lane passes; four slab-owning waves per band class reuse their slabs
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_FIN_SPREAD': 0},       # the bulk set's band classes one after the other on its own stream
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_FIN_LANES': 0},        # no read aligned by lane in the final stage (short nanopore reads are, by default)
-    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 0},       # pass waves never stage a read in LDS: 2-bit codes from global memory, changed test on repl[]
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_LANE_THRESHOLD': 0, 'BRX_STAGE_WORDS': 120},   # a slice of 120 words: reads up to 1.2 kb staged, longer ones beside them from global memory
-    {'BRX_FIN_LANES': 0, 'BRX_FIN_QUAD': 3, 'BRX_QUAD_MIN_READS': 0},   # narrow bands too go four per wave, a row of 16 lanes each (k_fin_quad), instead of one read per lane; both word classes
+    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0},                # bulk passes only: k_mut_apply / k_mut_post / k_pass_lists, windows through the lane and the wave kernel
+    {'BRX_TAIL_READS': 6, 'BRX_FIN_HEAD_READS': 9},            # passes, a 6-read in-place tail that takes reads over in any state, final stage in two sets
+    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9},                # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
+    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
+    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_WAVES_PER_CU': 2},       # passes; four slab-owning waves per band class reuse their slabs
+    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_FIN_SPREAD': 0, 'BRX_FIN_LANES': 0},   # the bulk set's band classes one after the other on its own stream, no read aligned by lane
+    {'BRX_FIN_LANES': 0, 'BRX_QUAD_MIN_READS': 0},             # narrow bands too go four per wave, a row of 16 lanes each (k_fin_quad), instead of one read per lane
     {'BRX_FIN_LANES': 0, 'BRX_TB_WINDOW': -1, 'BRX_QUAD_MIN_READS': 0},   # ... and the misses of an 8-row traceback window are repeated by k_fin_align with the full store
     {'BRX_FIN_QUAD': 0, 'BRX_FIN_LANES': 0},                   # every final alignment on a whole wave
 ]
@@ -109,13 +105,13 @@ def test_pipeline_routes_equal_the_oracle(env, monkeypatch):
         assert eng.mutate_passes() > 3
 
 
-MUTATE_ROUTES = {'default': {}, 'lanes': {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 0}, 'packed': {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANE_THRESHOLD': 1000000}}
+MUTATE_ROUTES = {'default': {}, 'passes': {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0}, 'passes_tail': {'BRX_TAIL_READS': 4, 'BRX_HEAD_READS': 3}}
 
 
 @pytest.mark.parametrize('route', sorted(MUTATE_ROUTES))
 def test_pipeline_other_models_and_fragment_kinds(route, monkeypatch):
     """random / ideal models (k = 1), low identity, chimeras, junk and random reads, glitches, N runs and hairpins;
-    through the in-place chain (few reads: all head), the lane-per-window passes and the packed-window passes."""
+    through the in-place chain (few reads: all head), the bulk passes, and passes with a head chain and an in-place tail."""
     for k, v in MUTATE_ROUTES[route].items():
         monkeypatch.setenv(k, str(v))
     pref, _ = H.small_reference(with_n=True)
@@ -129,6 +125,30 @@ def test_pipeline_other_models_and_fragment_kinds(route, monkeypatch):
         for f in STAT_FIELDS:
             assert (st_h[f] == st_o[f]).all(), (em, f)
         assert H.first_diff(out_h, out_o) < 0, em
+
+
+@pytest.mark.parametrize('tail', [0, 5])
+def test_bulk_passes_with_nearly_empty_survivor_rings(tail, monkeypatch):
+    """brx_passes.h: k_mut_post proposes ahead into a ring of survivors per read and k_mut_apply consumes it; a read whose ring runs
+    empty before its 25th change goes HUNGRY -- it takes part in the next pass without an alignment.  A build that stocks two
+    survivors per ring makes that the common case (and, with a tail, hands hungry reads over to k_mutate_seg): same bytes and
+    statistics as the oracle, and more passes than the shipped stock needs."""
+    import emu_engine as EE
+    monkeypatch.setenv('BRX_HEAD_READS', '0')
+    monkeypatch.setenv('BRX_TAIL_READS', str(tail))
+    pref, _ = H.small_reference(with_n=True)
+    p = SimParams(frag_mean=1400, frag_stdev=900, identity_mode=0, id_max=0.90)
+    orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
+    out_o, st_o = orc.simulate_batch(77, 10, 24)
+    passes = []
+    for defines in ((), ('-DBRX_SV_STOCK=2u', '-DBRX_POST_U=1')):
+        eng = H.configure(EE.EmuEngine(1 << 29, defines=defines), pref, 'nanopore2023', 'nanopore2023', p)
+        out_h, st_h = eng.simulate_batch(77, 10, 24)
+        for f in STAT_FIELDS:
+            assert (st_h[f] == st_o[f]).all(), (defines, f)
+        assert H.first_diff(out_h, out_o) < 0, defines
+        passes.append(eng.mutate_passes())
+    assert passes[1] > passes[0] > 3, passes
 
 
 def test_sequence_fragment_golden_vectors_from_the_running_reference():
@@ -232,18 +252,17 @@ def test_narrow_bands_one_read_per_lane(lanes, monkeypatch):
     assert (by_lane > 0.8 * float(st_h['frag_len'].sum())) if lanes else by_lane == 0
 
 
-@pytest.mark.parametrize('case', ['one_word', 'two_words', 'long'])
+@pytest.mark.parametrize('case', ['one_word', 'long'])
 def test_four_final_alignments_per_wave(case, monkeypatch):
-    """k_fin_quad (csrc/brx_quad.h): reads whose band is at most 13 superblocks -- of one word for up to 416 diagonals, of two for
-    up to 832 -- are aligned four per wave, one per row of 16 lanes, from LDS rings of target bytes and query planes that are
+    """k_fin_quad (csrc/brx_quad.h): reads whose band is at most 13 superblocks of one word (416 diagonals) are aligned four per
+    wave, one per row of 16 lanes, from LDS rings of target bytes and query planes that are
     refilled every 32 loop trips.  Same bytes and statistics as the oracle; the class really takes the reads; the reads are long
     enough for several refills per ring (a ring holds 1024 target bytes / 64 query words)."""
     pref, _ = H.small_reference(with_n=False)
     p, n, kern = {'one_word': (SimParams(frag_mean=2500, frag_stdev=1500, identity_mode=1, id_a=20.0, id_b=2.0, id_max=0.98), 16, 'k_fin_quad<1>'),
-                  'two_words': (SimParams(frag_mean=3000, frag_stdev=1000, identity_mode=0, id_max=0.80), 10, 'k_fin_quad<2>'),
                   'long': (SimParams(frag_mean=9000, frag_stdev=500, identity_mode=0, id_max=0.97), 5, 'k_fin_quad<1>')}[case]
     orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
-    eng = H.configure(emu_engine(monkeypatch, BRX_FIN_LANES=0 if case == 'one_word' else 1, BRX_FIN_QUAD=3 if case == 'two_words' else 1, BRX_QUAD_MIN_READS=0), pref, 'nanopore2023', 'nanopore2023', p)
+    eng = H.configure(emu_engine(monkeypatch, BRX_FIN_LANES=0 if case == 'one_word' else 1, BRX_QUAD_MIN_READS=0), pref, 'nanopore2023', 'nanopore2023', p)
     eng.set_kernel_timing(True)
     out_o, st_o = orc.simulate_batch(5, 0, n)
     out_h, st_h = eng.simulate_batch(5, 0, n)
@@ -253,7 +272,7 @@ def test_four_final_alignments_per_wave(case, monkeypatch):
     assert eng.kernel_stats()[kern][2] > 0.5 * float(st_h['frag_len'].sum())
 
 
-@pytest.mark.parametrize('quad,small', [(0, 20 << 20), (3, 0)])      # (3: both word classes of k_fin_quad; the default is the one-word class)
+@pytest.mark.parametrize('quad,small', [(0, 20 << 20), (1, 0)])
 def test_final_stage_with_fewer_slabs_than_reads(quad, small, monkeypatch):
     """The traceback stores of the final stage are slabs owned by the waves of the align kernels, sized by queue position
     (brx_hip.hip, launch_final_phase).  An arena that holds the largest store but not one slab per read (per group of four reads
@@ -267,7 +286,7 @@ def test_final_stage_with_fewer_slabs_than_reads(quad, small, monkeypatch):
         # (with four reads per wave the slabs fit any arena that holds the rest of the batch: there the second engine is limited to
         #  one slab-owning wave per CU of the two-CU interpreted chip instead)
         eng = H.configure(emu_engine(monkeypatch, scratch=scratch or 1 << 29, BRX_TB_WINDOW=0, BRX_WIN_KB=128, BRX_FIN_LANES=0, BRX_FIN_QUAD=quad,
-                                     BRX_QUAD_MIN_READS=0, BRX_QUAD_WAVES_PER_CU=4 if scratch else 1), pref, 'nanopore2023', 'nanopore2023', p)
+                                     BRX_QUAD_MIN_READS=0, BRX_WAVES_PER_CU=16 if scratch else 1), pref, 'nanopore2023', 'nanopore2023', p)
         out_h, st_h = eng.simulate_batch(8, 0, 28)
         slabs.append(eng.final_launches())
         for f in STAT_FIELDS:

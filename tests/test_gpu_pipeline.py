@@ -87,21 +87,14 @@ def test_sequence_fragments_matches_oracle():
     assert H.first_diff(res_h[0][0], frags[0]) < 0
 
 
-@pytest.mark.parametrize('env', [{'BRX_TB_WINDOW': '0'}, {'BRX_TB_WINDOW': '-1'}, {'BRX_TB_WINDOW': '1'}, {'BRX_MUTATE_INLINE': '1'},
-                                 {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0'},          # bulk passes, lane kernel
-                                 {'BRX_LANE_THRESHOLD': '1000000', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0'},    # bulk passes, packed windows (k_win_pack)
-                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_LANE_THRESHOLD': '0'},        # two chains + in-place tail
-                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1', 'BRX_WIDE_STREAM': '0'},
-                                 {'BRX_TAIL_READS': '16', 'BRX_LANE_THRESHOLD': '100', 'BRX_FIN_HEAD_READS': '64'},   # lane passes, then packed passes, then the tail
-                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_FIN_SPREAD': '0'},                              # bulk band classes on one stream
-                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_FIN_LANES': '0'},                               # no final alignment by lane
-                                 {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0', 'BRX_STAGE_WORDS': '0'},    # pass waves never stage a read in LDS
-                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_STAGE_WORDS': '500'},   # short reads staged, long ones not
-                                 {'BRX_LANE_THRESHOLD': '0', 'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0', 'BRX_WAVES_PER_CU': '1'},      # 256 slab-owning waves per band class
-                                 {'BRX_FIN_LANES': '0', 'BRX_FIN_QUAD': '3', 'BRX_QUAD_MIN_READS': '0'},                               # narrow bands four per wave (k_fin_quad) instead of one per lane; both word classes
-                                 {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '-1', 'BRX_QUAD_MIN_READS': '0'},     # ... their window misses repeated by k_fin_align
-                                 {'BRX_FIN_QUAD': '0'},                                                        # no final alignment four per wave
-                                 {'BRX_FIN_QUAD': '1', 'BRX_QUAD_WAVES_PER_CU': '1', 'BRX_QUAD_MIN_READS': '0'}])                         # one-word quads only, one slab-owning wave per CU
+@pytest.mark.parametrize('env', [{'BRX_TB_WINDOW': '0'}, {'BRX_TB_WINDOW': '-1'}, {'BRX_TB_WINDOW': '1'},
+                                 {'BRX_TAIL_READS': '1000000'},                                      # every read runs to completion in place (k_mutate_seg)
+                                 {'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '0'},                     # bulk passes only: k_mut_apply / k_mut_post / k_pass_lists / k_win_lane / k_win_wave
+                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32'},                   # two chains + an in-place tail that takes reads over from the passes
+                                 {'BRX_HEAD_READS': '64', 'BRX_TAIL_READS': '32', 'BRX_TB_WINDOW': '-1', 'BRX_WIDE_STREAM': '0', 'BRX_FIN_SPREAD': '0'},
+                                 {'BRX_HEAD_READS': '0', 'BRX_TAIL_READS': '16', 'BRX_FIN_HEAD_READS': '64', 'BRX_WAVES_PER_CU': '1'},      # 256 slab-owning waves per band class
+                                 {'BRX_FIN_LANES': '0', 'BRX_QUAD_MIN_READS': '0'},                  # narrow bands four per wave (k_fin_quad) instead of one per lane
+                                 {'BRX_FIN_LANES': '0', 'BRX_FIN_QUAD': '0'}])                       # every final alignment on a whole wave
 def test_alternative_kernel_routes_give_the_same_bytes(env, monkeypatch):
     """The optional routes (full / 8-row / narrow traceback window of the final alignment -- the 8-row window
     makes most reads miss and repeat with the full store --, in-place mutate alignments, lane- or wave-per-window

@@ -75,7 +75,7 @@ def test_pmc_traffic_all_carries_every_kernel_that_may_rank_first(tmp_path):
     other this round, so profiles/pmc_traffic.json holds all of them (tools/pmc_traffic.py --all)."""
     import json
     rows = ['kernel,counter,sum,dispatches']
-    for name, fetch, write, disp in (('void k_mutate_seg<false, false, 4>', 1000.0, 500.0, 128), ('void k_mutate_seg<true, false, 4>', 4000.0, 2000.0, 5),
+    for name, fetch, write, disp in (('void k_mut_post<2>', 1000.0, 500.0, 128), ('void k_mutate_seg<false, 4>', 4000.0, 2000.0, 5),
                                      ('k_win_lane', 300.0, 200.0, 128), ('void k_fin_align<1, 1, 1>', 900.0, 600.0, 3), ('k_build', 1.0, 1.0, 3)):
         rows.append(f'"{name}",FETCH_SIZE,{fetch},{disp}')
         rows.append(f'"{name}",WRITE_SIZE,{write},{disp}')
@@ -86,15 +86,15 @@ def test_pmc_traffic_all_carries_every_kernel_that_may_rank_first(tmp_path):
     rec = json.loads(out)
     assert rec['reads_per_step'] == 65536 and rec['workload'] == 'human' and len(rec['csrc_sha16']) == 16
     k = rec['kernels']
-    assert set(k) == {'k_mutate_seg<false>', 'k_mutate_seg<true>', 'k_win_lane', 'k_fin_align<1,1,1>'}
-    assert abs(k['k_mutate_seg<false>']['hbm_bytes_per_launch'] - (2 * 1000.0 + 500.0) * 1024 / 128) < 1e-6      # per pass: every dispatch
-    assert abs(k['k_mutate_seg<true>']['hbm_bytes_per_launch'] - (2 * 4000.0 + 2000.0) * 1024 / 4) < 1e-6          # the priming launch is not a full-size one
+    assert set(k) == {'k_mut_post', 'k_mutate_seg', 'k_win_lane', 'k_fin_align<1,1,1>'}
+    assert abs(k['k_mut_post']['hbm_bytes_per_launch'] - (2 * 1000.0 + 500.0) * 1024 / 128) < 1e-6      # per pass: every dispatch
+    assert abs(k['k_mutate_seg']['hbm_bytes_per_launch'] - (2 * 4000.0 + 2000.0) * 1024 / 4) < 1e-6          # the priming launch is not a full-size one
     assert abs(k['k_fin_align<1,1,1>']['hbm_bytes_per_launch'] - (2 * 900.0 + 600.0) * 1024 / 2) < 1e-6
 
 
 TRACE = """Kernel_Name,Start_Timestamp,End_Timestamp,Queue_Id
 "k_plan_count(BrxDev, RS*)",1000000,1100000,4
-"k_mutate_seg<false, false, 4>(BrxDev)",1200000,3200000,4
+"k_mut_apply(BrxDev)",1200000,3200000,4
 "void k_fin_align<16, 8, 65535>(BrxDev)",3300000,9300000,2
 "void k_fin_align<1, 1, 1>(BrxDev)",5000000,12000000,4
 "void k_fin_quad<1>(BrxDev)",5100000,6100000,1

@@ -19,26 +19,22 @@ from badread_amd.engine import SimParams  # noqa: E402
 
 MODELS = ['random', 'nanopore2018', 'nanopore2020', 'nanopore2023', 'pacbio2016', 'pacbio2021']
 QMODELS = ['random', 'ideal', 'nanopore2018', 'nanopore2020', 'nanopore2023', 'pacbio2016', 'pacbio2021']
-ROUTES = [{}, {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '0'}, {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '1000000'},
-          {'BRX_TB_WINDOW': '-1'}, {'BRX_TB_WINDOW': '0'}, {'BRX_TB_WINDOW': '1'}, {'BRX_MUTATE_INLINE': '1'},
+ROUTES = [{}, {'BRX_TAIL_READS': '0', 'BRX_HEAD_READS': '0'}, {'BRX_TAIL_READS': '5', 'BRX_HEAD_READS': '0'},
+          {'BRX_TB_WINDOW': '-1'}, {'BRX_TB_WINDOW': '0'}, {'BRX_TB_WINDOW': '1'},
           {'BRX_TAIL_READS': '3'}, {'BRX_WAVES_PER_CU': '1'}, {'BRX_WAVES_PER_CU': '2', 'BRX_TB_WINDOW': '-1'},      # few slabs per band class
-          {'BRX_LANE_WAVES': '1', 'BRX_TAIL_READS': '0', 'BRX_HEAD_READS': '0', 'BRX_LANE_THRESHOLD': '0'},
-          {'BRX_FIN_LANES': '0'}, {'BRX_TAIL_READS': '2', 'BRX_HEAD_READS': '2', 'BRX_FIN_LANES': '0'},
-          {'BRX_TAIL_READS': '0', 'BRX_HEAD_READS': '0', 'BRX_STAGE_WORDS': '0'},                                   # pass waves never stage a read in LDS
-          {'BRX_TAIL_READS': '2', 'BRX_HEAD_READS': '3', 'BRX_STAGE_WORDS': '60'},           # short reads staged, the others beside them
-          {'BRX_TAIL_READS': '0', 'BRX_LANE_THRESHOLD': '0', 'BRX_STAGE_WORDS': '2560'}]
-# routes of the final stage with four alignments per wave (k_fin_quad; on by default): without the one-read-per-lane class so that
-# narrow bands go through it too, one word class only, window misses repeated by k_fin_align, few slabs, and switched off
-QUAD_ROUTES = [{'BRX_FIN_LANES': '0', 'BRX_FIN_QUAD': '3'}, {'BRX_FIN_QUAD': '3'}, {'BRX_FIN_QUAD': '2', 'BRX_FIN_LANES': '0'}, {'BRX_FIN_QUAD': '0'},
-               {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '-1'}, {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '0', 'BRX_QUAD_WAVES_PER_CU': '1', 'BRX_WAVES_PER_CU': '1'},
+          {'BRX_FIN_LANES': '0'}, {'BRX_TAIL_READS': '2', 'BRX_HEAD_READS': '2', 'BRX_FIN_LANES': '0'}]
+# routes of the final stage with four alignments per wave (k_fin_quad<1>; on by default): without the one-read-per-lane class so that
+# narrow bands go through it too, window misses repeated by k_fin_align, few slabs, and switched off
+QUAD_ROUTES = [{'BRX_FIN_LANES': '0'}, {'BRX_FIN_QUAD': '1'}, {'BRX_FIN_QUAD': '0'},
+               {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '-1'}, {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '0', 'BRX_WAVES_PER_CU': '1'},
                {'BRX_FIN_LANES': '0', 'BRX_TB_WINDOW': '1', 'BRX_TAIL_READS': '2', 'BRX_HEAD_READS': '3'}]
 for _r in QUAD_ROUTES:
     _r.setdefault('BRX_QUAD_MIN_READS', '0')          # the class is used only when it holds thousands of reads by default
 ROUTES += QUAD_ROUTES
-# round 6: the bulk passes as {k_mut_apply, k_mut_post} (brx_passes.h) -- every read through the passes, passes with an in-place
-# tail that takes reads over in any state, both window kernels; `defines` builds a variant of the kernels whose rings are kept
-# nearly empty, so that reads go hungry (a pass without an alignment) all the time
-PASS_ROUTES = [{'BRX_TAIL_READS': t, 'BRX_HEAD_READS': h, 'BRX_LANE_THRESHOLD': l} for t in ('0', '2', '5') for h in ('0', '2') for l in ('0', '1000000')]
+# round 6: the bulk passes as {k_mut_apply, k_mut_post, k_pass_lists} (brx_passes.h) -- every read through the passes, passes with
+# an in-place tail that takes reads over in any state; `defines` builds a variant of the kernels whose rings are kept nearly
+# empty, so that reads go hungry (a pass without an alignment) all the time
+PASS_ROUTES = [{'BRX_TAIL_READS': t, 'BRX_HEAD_READS': h} for t in ('0', '2', '5') for h in ('0', '2')]
 PASS_DEFINES = [(), ('-DBRX_SV_STOCK=3u', '-DBRX_SV_CAP=128u', '-DBRX_POST_U=1'), ('-DBRX_SV_STOCK=1u', '-DBRX_SV_CAP=256u', '-DBRX_POST_U=3')]
 
 

@@ -42,17 +42,17 @@ def main():
     if len(sys.argv) > 3 and sys.argv[3] == '--all':
         workload = sys.argv[4] if len(sys.argv) > 4 else 'human'
         names = sorted({row['kernel'] for row in csv.DictReader(open(path)) if row['counter'] == 'FETCH_SIZE'})
-        per_pass = ('k_mutate_seg<false', 'k_win_lane', 'k_win_wave', 'k_win_pack')
+        per_pass = ('k_mut_apply', 'k_mut_post', 'k_pass_lists', 'k_win_lane', 'k_win_wave')
         out = {}
         for name in names:
             bare = name.replace('void ', '')
-            label = ('k_mutate_seg<false>' if 'k_mutate_seg<false' in bare else 'k_mutate_seg<true>' if 'k_mutate_seg<true' in bare
-                     else bare.replace(' ', ''))
-            if not label.startswith(('k_mutate_seg', 'k_win_lane', 'k_fin_align', 'k_fin_qscore')) or '_Z' in label or label in out:
+            # names as badread_amd.engine.KERNEL_NAMES has them (bench.py looks the run's top kernel up by that name)
+            label = ('k_mutate_seg' if bare.startswith('k_mutate_seg<') else 'k_mut_post' if bare.startswith('k_mut_post<') else bare.replace(' ', ''))
+            if not label.startswith(('k_mutate_seg', 'k_mut_', 'k_win_lane', 'k_fin_align', 'k_fin_qscore', 'k_fin_quad', 'k_fin_lanes')) or '_Z' in label or label in out:
                 continue
-            # few-launches-per-batch kernels: the two batches' full-size launches (k_mutate_seg<true>: head + tail each; the others one or two)
-            # (the 64-read priming call of bench.py launches k_mutate_seg<true>, k_fin_align<1,1,1> and <2,2,2> once each: not counted)
-            primed = ('k_mutate_seg<true', 'k_fin_align<1, 1, 1>', 'k_fin_align<2, 2, 2>')
+            # few-launches-per-batch kernels: the two batches' full-size launches (k_mutate_seg: head + tail each; the others one or two)
+            # (the 64-read priming call of bench.py launches k_mutate_seg, k_fin_align<1,1,1> and <2,2,2> once each: not counted)
+            primed = ('k_mutate_seg<', 'k_fin_align<1, 1, 1>', 'k_fin_align<2, 2, 2>')
             n_disp = max(int(row['dispatches']) for row in csv.DictReader(open(path)) if row['kernel'] == name and row['counter'] == 'FETCH_SIZE')
             full = None if any(x in bare for x in per_pass) else (max(n_disp - 1, 1) if any(x in bare for x in primed) else None)
             try:
