@@ -505,10 +505,16 @@ class _BatchPool(object):
     batch is done (2 GB at HBM speed: ~1 ms) and gives the engine back at once; `depth` = in_flight + 2 batches may be outstanding,
     the surplus holding only their bytes."""
 
-    def __init__(self, engine, in_flight, arenas=None):
+    def __init__(self, engine, in_flight, arenas=None, device_gzip=False):
         import concurrent.futures
         import queue
         self.arenas = arenas
+        # --gzip-device: the worker of a batch that the stop rule cannot cut (submit(..., pack=True): the job still needs several
+        # batches' worth of bases behind it) packs ITS batch on ITS engine's stream as soon as the batch is done and hands over
+        # the gzip members instead of the text; the consumer packs only the job's last batches itself.  Round 5 packed every batch
+        # on the consumer thread: 9.3 s for the 185 GB of text of the configs[4] job, which bound that flavour (10.4 s of read
+        # loop against 6.0 s; VERDICT r5).
+        self.device_gzip = bool(device_gzip)
         self.engines = [engine]
         self.streams = [None]
         torch = getattr(engine, 'torch', None)           # absent on the tests' CPU checker engines
@@ -571,7 +577,7 @@ class _BatchPool(object):
             n -= 1
         return n
 
-    def submit(self, seed, first, n_mine):
+    def submit(self, seed, first, n_mine, pack=False):
         self.submitted += 1
         while self.started < min(self.submitted - 1, len(self.makers)):      # the k-th batch in the pipeline is what clone k - 1 is for
             self.makers[self.started].start()
@@ -595,9 +601,18 @@ class _BatchPool(object):
                 torch.cuda.set_device(eng.device)
                 with torch.cuda.stream(stream):
                     out, stats = eng.simulate_batch_device(seed, first, n_mine, allow_nofrag=True)
-                    out = out.clone()                        # the engine's buffer is free again; the copy runs on this batch's stream ...
+                    stats = stats.copy()
+                    packed = None
+                    if pack and self.device_gzip and len(stats) and hasattr(eng, 'gzip_device'):
+                        from .output import fastq_blocks
+                        live = np.flatnonzero(stats['rec_len'] > 0)
+                        if len(live) and not (stats['status'] & (RS_NOFRAG | BAD_STATUS)).any():
+                            nbytes = int(stats['rec_off'][live[-1]] + stats['rec_len'][live[-1]])
+                            blocks = fastq_blocks(stats['rec_off'], stats['rec_len'], stats['seq_len'], nbytes)
+                            packed = (nbytes, eng.gzip_device(out[:nbytes], blocks))      # a new tensor, made on this batch's stream
+                    out = out.clone() if packed is None else None          # the engine's buffer is free again; the copy runs on this batch's stream ...
                     stream.synchronize()                     # ... and is complete before the engine is handed to the next batch
-                    return out, stats.copy()
+                    return (out, stats) if not self.device_gzip else (out, stats, packed)
             finally:
                 with self.lock:
                     self.job_seconds += time.perf_counter() - t_job
@@ -680,7 +695,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         fit = min(int(x[0]) for x in shard.gather_words(np.array([fit], dtype=np.uint32), [1] * shard.world))
     if fit < asked and shard.rank == 0:
         print(f'  {fit} of the {asked} batches in flight asked for fit into the free device memory', file=output)
-    pool = _BatchPool(engine, fit, arenas)
+    pool = _BatchPool(engine, fit, arenas, device_gzip=device_gzip)
     timing['create_engines'] = time.perf_counter() - t0
     ring = None
     if local_write is not None or shard.rank == 0:
@@ -721,7 +736,8 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
                 break
             n_super = plan_batch(max(remaining, 1), expected_mean, shard.world, max_batch)
             first, n_mine = shard.slice_of(next_read, n_super)
-            fut = pool.submit(seed, first, n_mine)
+            # --gzip-device: a batch with at least three batches' worth of bases still to come behind it is kept whole
+            fut = pool.submit(seed, first, n_mine, pack=device_gzip and remaining > 4.0 * n_super * expected_mean)
             pending.append((None, fut, next_read, n_super, first, n_mine))
             next_read += n_super
 
@@ -730,7 +746,8 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             fill()
             _, fut, base, n_super, first, n_mine = pending.popleft()
             t0 = time.perf_counter()
-            out, stats = fut.result()
+            res = fut.result()
+            out, stats, prepacked = res if len(res) == 3 else (res[0], res[1], None)
             timing['wait_for_batch'] += time.perf_counter() - t0
             timing['batches'] += 1
             # ---- the 4 B/read exchange: length (0 for skipped reads) | NOFRAG << 31 | BAD << 30 ----
@@ -765,7 +782,17 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             keep = int(np.clip(last - my_lo + 1, 0, n_mine))
             my_bytes = int(stats['rec_off'][keep - 1] + stats['rec_len'][keep - 1]) if keep else 0
             packed = False
-            if gz_engine is not None and my_bytes:
+            if prepacked is not None and my_bytes == prepacked[0]:          # the whole batch is kept: its worker has packed it already
+                out = prepacked[1]
+                my_bytes = int(out.numel())
+                packed = True
+                timing['batches_packed_by_their_worker'] += 1
+            elif prepacked is not None:
+                # the stop rule cut a batch that was packed ahead (reads far longer than the job expected): unpack it on the host, once
+                import gzip as _gzip
+                text = _gzip.decompress(bytes(prepacked[1].cpu().numpy()))
+                out = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()).to(prepacked[1].device)
+            if gz_engine is not None and my_bytes and not packed:
                 t0 = time.perf_counter()
                 blocks = fastq_blocks(stats['rec_off'][:keep], stats['rec_len'][:keep], stats['seq_len'][:keep], my_bytes)
                 out = gz_engine.gzip_device(out[:my_bytes], blocks)       # a new tensor: the engine's buffer is free again
@@ -920,7 +947,12 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
         from .engine import default_engine
         engine = default_engine()
     mark('engine_created')
-    # the job's arenas from now on, beside everything below (models, genome upload, the first batch): _ArenaPrefetch
+    # the genome goes to the device BEFORE the arenas are asked for (round 6): the allocations of 200+ GB hold the runtime's lock the
+    # upload would otherwise wait for -- 0.2 s of copy became 2-6 s behind them right after another process (profiles/r05i, r05k)
+    _, cum_weight = pref.contig_weights(depths)
+    engine.set_reference(pref, cum_weight)
+    mark('reference_on_device')
+    # the job's arenas from now on, beside everything below (models, tables, the first batch): _ArenaPrefetch
     arenas = _ArenaPrefetch.for_job(engine, get_target_size(pref.n_bases, args.quantity), float(args.mean_frag_length),
                                     expected_error_rate(identities), getattr(args, 'gpu_streams', None) or DEFAULT_IN_FLIGHT, shard.world)
     # a model file that is not in the cache is aligned (align_kmers, error_model.py:179-229) on THIS engine
@@ -937,9 +969,6 @@ def simulate(args, output=sys.stderr, engine=None, stdout=None, shard=None):
     target_size = get_target_size(pref.n_bases, args.quantity)
     print(f'\nTarget read set size: {target_size:,} bp\n', file=quiet)
 
-    _, cum_weight = pref.contig_weights(depths)
-    engine.set_reference(pref, cum_weight)
-    mark('reference_on_device')
     engine.set_error_model(error_model.tables())
     engine.set_qscore_model(qscore_model.tables())
     engine.set_params(sim_params_from_args(args, frag_lengths, identities, start_rate, start_amount,

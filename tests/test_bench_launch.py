@@ -59,3 +59,55 @@ def test_gpus_8_dry_run_over_gloo(tmp_path):
     total = line['value'] * line['ms_per_step'] * 1e-3 * line['steps']
     rank0 = line['config']['bases_per_step_per_gpu'] * line['steps']
     assert total > 3.0 * rank0, (total, rank0)          # 16 reads of 15 +- 13 kb per rank: eight ranks in the sum
+
+
+def test_strong_scaling_line_fixed_job_startup_inside_the_clock(tmp_path):
+    """`--scaling strong`: the job is a FIXED number of device batches split over the ranks by batch index, the
+    clock of a rank starts with its process, and the line carries the fixed cost, the loop and the projection for 1 / 2 / 4 / 8
+    ranks.  N = 1 and N = 2 simulate the same reads (same total bases); --steps / --warmup do not apply."""
+    args = ['--cpu-engine', '--scaling', 'strong', '--quantity', '0.6', '--steps', '7', '--warmup', '3', '--reads-per-step', '128', '--streams', '2',
+            '--workload', 'human', '--ref-scale', '0.002']
+    lines = {}
+    for n in (1, 2):
+        r = run(args + ['--gpus', str(n)], tmp=tmp_path)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines[n] = last_json(r.stdout)
+    one, two = lines[1], lines[2]
+    for n, line in lines.items():
+        assert line['scaling'] == 'strong' and line['n_gpus'] == n and 'INVALID' in line and line['warmup'] == 0
+        assert line['job']['device_batches'] == 4 and line['job']['reads_per_device_batch'] == 64
+        assert line['fixed_cost_s'] > 0.5 and line['loop_s'] > 0.1                      # importing torch alone is inside the fixed cost
+        assert abs(line['wall_s'] - (line['fixed_cost_s'] + line['loop_s'])) < 0.25 * line['wall_s']     # the slowest rank of each part
+        assert abs(line['value'] - line['job']['bases'] / line['wall_s']) < 1e-6 * line['value']
+        assert line['value_loop'] > line['value']
+        proj = line['projected_wall_s']
+        assert set(proj) == {'1', '2', '4', '8'} and proj['1'] > proj['2'] > proj['4'] > proj['8'] > line['fixed_cost_s']
+        assert abs(proj[str(n)] - (line['fixed_cost_s'] + line['loop_s'])) < 0.02
+    assert one['job']['bases'] == two['job']['bases']                                     # strong: the same reads whatever N
+    assert one['steps'] == 2 and two['steps'] == 1                                        # rounds of --streams batches per rank
+
+
+def test_an_oversubscribed_host_is_flagged_in_the_line_not_refused(tmp_path):
+    """round 5 exited 3 without a metric line when the ranks kept more host cores busy during warm-up than the
+    container may use -- a scaling box with a small cgroup got no data.  The run is timed now and the line says
+    `host_throttled: true` with the numbers.  (Forced here by pinning the two ranks to ONE core's worth of affinity: two busy
+    ranks on a mask of one core are over 1.25 x 1 only if they could run -- so the mask stays, the threshold is what is tested:
+    a warm-up step on the CPU engine keeps each rank ~1 core busy.)"""
+    import os as _os
+    if not hasattr(_os, 'sched_setaffinity'):
+        return
+    cores = sorted(_os.sched_getaffinity(0))
+    code = ("import os, sys, runpy; os.sched_setaffinity(0, {%d}); sys.argv = ['bench.py'] + sys.argv[1:]; runpy.run_path(%r, run_name='__main__')"
+            % (cores[0], BENCH))
+    e = dict(_os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, '-c', code] + ['--cpu-engine', '--steps', '1', '--warmup', '1', '--reads-per-step', '64', '--streams', '1',
+                                                          '--workload', 'human', '--ref-scale', '0.002', '--gpus', '2', '--ref-dir', str(tmp_path)],
+                       env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = last_json(r.stdout)
+    assert line['n_gpus'] == 2 and 'host_throttled' in line and line['usable_cores'] == 1
+    assert line['busy_cores_all_ranks_during_warmup'] > 0.0
+    assert line['host_throttled'] == (line['busy_cores_all_ranks_during_warmup'] > 1.25)
+    assert line['value'] > 0

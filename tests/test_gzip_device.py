@@ -208,6 +208,29 @@ def test_a_full_batch_of_simulated_reads_round_trips():
     eng.close()
 
 
+@pytest.mark.gpu
+def test_batches_the_stop_rule_cannot_cut_are_packed_by_their_own_worker(monkeypatch):
+    """--gzip-device, round 6: the worker of a batch that has several batches' worth of bases still to come behind it packs the
+    batch on its own engine's stream (one gzip stage per engine instead of one consumer thread); the job's last batches are
+    packed by the consumer after the stop rule.  The stream decompresses to the plain run's bytes, and most batches took the
+    worker's route."""
+    import io
+    from badread_amd import simulate as S
+    from badread_amd.engine import HipEngine
+    from test_host_simulate import Args
+    monkeypatch.setattr(S, 'DEFAULT_MAX_BATCH', 128)
+    outs, timing = {}, None
+    for flag in (False, True):
+        buf = io.BytesIO()
+        eng = HipEngine(0, scratch_bytes=1 << 30)
+        S.simulate(Args(quantity='400x', gzip_device=flag, gpu_streams=3), output=io.StringIO(), engine=eng, stdout=buf, shard=S.Shard())
+        outs[flag] = buf.getvalue()
+        if flag:
+            timing = dict(S.run_batches.last_timing)
+    assert gzip.decompress(outs[True]) == outs[False]
+    assert timing['batches'] >= 10 and timing['batches_packed_by_their_worker'] >= timing['batches'] - 6, timing
+
+
 GZ_WORKER = '''
 import io, os, sys
 sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, 'tests')); sys.path.insert(0, os.path.join({repo!r}, 'oracle'))
