@@ -1008,7 +1008,7 @@ __global__ void __launch_bounds__(64, 4) k_fin_lanes(BrxDev d, RS *rs, const uin
                 o->n_cols = ncols; o->n_match = nmatch;
             }
             uint64_t *ck = clk + (uint64_t)r * 8;
-            ck[3] = __builtin_amdgcn_s_memtime() - t_begin; ck[7] = (uint64_t)(s.klass & 0xFFFFu);
+            ck[3] = __builtin_amdgcn_s_memtime() - t_begin; ck[7] = (uint64_t)(s.klass & 0xFFFFu) | 0x20000u;     /* bit 17: aligned one read per lane */
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);                      /* the slab is written again by the next group */

@@ -249,9 +249,10 @@ enum { BRX_STAGE_PLAN = 0, BRX_STAGE_BUILD = 1, BRX_STAGE_MUTATE = 2, BRX_STAGE_
 int brx_last_stage_ms(const brx_ctx *ctx, float ms[BRX_STAGE_COUNT]);
 /* Shader-clock cycles (s_memtime) each read of the last pipeline call spent in the two heavy
  * kernels, 8 x u64 per read, copied to HOST memory h_out (valid until the next call on ctx):
- *   [0] k_mutate_seg total over all passes  [1] passes (alignments) of the read  [2] 1 if the final traceback left the stored window
+ *   [0] k_mutate_seg / k_mut_post total over all passes  [1] passes (alignments) of the read  [2] 1 if the final traceback left the stored window
  *   [3] k_fin_align total   [4] final alignment forward    [5] final traceback   [6] k_fin_qscore
- *   [7] words per lane (G) of the final alignment's band geometry                                */
+ *   [7] words per lane (G) of the final alignment's band geometry in bits 0-15; bit 16: the read was aligned as one of four per
+ *       wave (k_fin_quad), bit 17: one read per lane (k_fin_lanes) -- a read repeated in the second phase carries k_fin_align's word */
 int brx_last_read_cycles(brx_ctx *ctx, uint64_t *h_out, uint32_t n_reads);
 /* number of scratch chunks (sets of final-stage launches) and of mutate passes of the last call */
 /* With BRX_PROFILE=1 in the environment at brx_create the mutate kernels time their phases (shader clock, per read,

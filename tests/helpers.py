@@ -132,3 +132,36 @@ def identity_tolerance_check(engine, models=('random', 'nanopore2018', 'nanopore
                 assert abs(statistics.mean(ids) - target) <= 0.05 * err + 1e-12, (model, target, length, statistics.mean(ids))
                 checked += trials
     return checked
+
+
+def recipe_fragment(seed, length, with_n=False):
+    """The fragment of a digest case of tests/golden/sequence_fragment_bound.json.gz (tools/make_golden.py holds the same function):
+    base i = splitmix64(seed << 32 | i) >> 62, one base in 256 an N if with_n.  Returns codes 0-4 (uint8)."""
+    x = (np.uint64(seed) << np.uint64(32)) + np.arange(length, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    codes = (x >> np.uint64(62)).astype(np.uint8)
+    if with_n:
+        codes[((x >> np.uint64(20)) & np.uint64(255)) == 0] = 4
+    return codes
+
+
+def check_digest_cases(engine_of, cases):
+    """Every digest case through `engine_of(em, qm)` (an engine configured with that model pair): sha256 of the sequence and of the
+    qualities, the identity as the same double, the loop count."""
+    import hashlib
+    for c in cases:
+        eng = engine_of(c['em'], c['qm'])
+        res, st = eng.sequence_fragments(c['seed'], c['read'], [recipe_fragment(c['seed'], c['length'], c['with_n'])], [c['target']])
+        tag = (c['em'], c['length'], c['target'], c['seed'])
+        seq = ''.join('ACGTN'[x] for x in res[0][0])
+        assert len(seq) == c['seq_len'] and hashlib.sha256(seq.encode()).hexdigest() == c['seq_sha256'], tag
+        assert hashlib.sha256(res[0][1].tobytes()).hexdigest() == c['qual_sha256'], tag
+        identity = st['n_match'][0] / st['n_cols'][0] if st['n_cols'][0] else 0.0
+        assert identity == c['identity'], tag
+        assert st['loop_count'][0] in (c['iterations'], c['iterations'] + 1), tag
+        if c['length'] > 1000:                    # (the replay counts window draws: a fragment of up to ALIGNMENT_SIZE is aligned whole, without one)
+            assert st['n_alignments'][0] == c['alignments'], tag

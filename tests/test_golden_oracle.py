@@ -161,6 +161,32 @@ def test_sequence_fragment_replay_bit_exact():
         assert st['loop_count'][0] in (c['iterations'], c['iterations'] + 1), tag
 
 
+def test_sequence_fragment_digest_cases_bound_the_power_difference():
+    """VERDICT r5 item 6c.  The reference computes `estimated_identity ** 1.5` (simulate.py:321: libm pow), the oracle and the
+    kernels `est * sqrt(est)`.  tests/golden/sequence_fragment_bound.json.gz holds 524 more replays of the UNMODIFIED
+    sequence_fragment with our draws (tools/make_golden.py sequence_fragment_bound) -- 24 of them 50 kb fragments at 80-90 %
+    identity, where the power is taken thousands of times at estimates far below 1 -- as digests; the oracle reproduces every
+    one, and tests/golden/pow15.json records how often the two expressions differ at all on this libm."""
+    import json
+    g = load('sequence_fragment_bound.json.gz')
+    assert len(g['cases']) >= 500
+    long_rough = [c for c in g['cases'] if c['length'] == 50000]
+    assert len(long_rough) >= 20 and all(0.80 <= c['target'] <= 0.90 for c in long_rough)
+    assert sum(c['iterations'] for c in g['cases']) > 3_000_000           # uses of the power: one per applied change, ~9 % of these
+    engines = {}
+
+    def engine_of(em, qm):
+        if (em, qm) not in engines:
+            e = H.oracle_engine()
+            e.set_error_model(ErrorModel(em, NULL).tables())
+            e.set_qscore_model(QScoreModel(qm, NULL).tables())
+            engines[(em, qm)] = e
+        return engines[(em, qm)]
+    H.check_digest_cases(engine_of, g['cases'])
+    p15 = json.load(open(os.path.join(GOLDEN, 'pow15.json')))
+    assert p15['doubles'] == 10_000_000 and p15['largest_difference_ulps'] <= 1 and p15['differ'] == round(p15['rate'] * p15['doubles'])
+
+
 # ------------------------------------------------------------------------------------------------
 CIGAR = '=XID'
 

@@ -159,7 +159,16 @@ def test_configs3_and_4_every_read_of_a_full_batch_equals_the_oracle(wlname, tmp
     out, st = eng.simulate_batch(SEED, 0, n)
     out, st = out.copy(), st.copy()
     assert getattr(eng, 'retries', 0) == 0, 'the shipped arena must hold a shipped batch without a retry'
+    route = eng.read_cycles(n)[:, 7]
     eng.close()
+    # the routes of the final stage carry reads at full size: four per wave (bit 16), one per lane (bit 17) -- a change
+    # of a threshold that sends everything back to k_fin_align must not pass silently
+    live_reads = int((st['rec_len'] > 0).sum())
+    by_quad, by_lane = int(((route >> 16) & 1).sum()), int(((route >> 17) & 1).sum())
+    if wlname == 'human':
+        assert by_quad >= 4096 and by_lane >= 1000, (by_quad, by_lane)
+    else:
+        assert by_lane >= 0.9 * live_reads, (by_lane, live_reads)
     assert (st['status'] & ~np.uint32(RS_EMPTY) == 0).all()
     raw = out.tobytes()
     compare_with_oracle_slices(wlname, ref_dir, n, st, raw, tmp_path, ALL_FIELDS)

@@ -48,6 +48,22 @@ def test_sequence_fragment_golden_through_the_c_abi():
             assert abs(1.0 - st['qerr_sum'][0] / st['padded_len'][0] - c['identity_by_qscores']) < 1e-12, tag
 
 
+def test_sequence_fragment_digest_cases_through_the_c_abi():
+    """The 524 digest replays of the reference (tests/golden/sequence_fragment_bound.json.gz: incl. 24 fragments of 50 kb at
+    80-90 % identity) through the HIP path: sequence, qualities, identity and loop count of every one."""
+    g = load('sequence_fragment_bound.json.gz')
+    hip = H.hip_engine()
+    current = [None]
+
+    def engine_of(em, qm):
+        if current[0] != (em, qm):
+            hip.set_error_model(ErrorModel(em, NULL).tables())
+            hip.set_qscore_model(QScoreModel(qm, NULL).tables())
+            current[0] = (em, qm)
+        return hip
+    H.check_digest_cases(engine_of, sorted(g['cases'], key=lambda c: (c['em'], c['qm'])))
+
+
 def test_build_fragment_golden_through_the_c_abi():
     g = load('build_fragment.json.gz')
     pref = PackedReference.from_seqs(*load_fasta(os.path.join(GOLDEN, 'small_ref.fasta')))

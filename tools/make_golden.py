@@ -530,6 +530,81 @@ def make_sequence_fragment():
     dump('sequence_fragment.json.gz', {'cases': cases})
 
 
+def recipe_fragment(seed, length, with_n=False):
+    """A fragment as a pure function of (seed, length): base i = splitmix64(seed << 32 | i) -- the digest cases below keep the
+    recipe instead of the text (tests/helpers.py holds the same function)."""
+    import numpy as np
+    x = (np.uint64(seed) << np.uint64(32)) + np.arange(length, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    codes = (x >> np.uint64(62)).astype(np.uint8)
+    if with_n:                                           # one base in 256 is N
+        codes[((x >> np.uint64(20)) & np.uint64(255)) == 0] = 4
+    return ''.join('ACGTN'[c] for c in codes)
+
+
+def _bound_case(spec):
+    """One digest case (a worker process of make_sequence_fragment_bound)."""
+    import hashlib
+    import helpers as H
+    em_name, qm_name, length, target, seed, read, with_n = spec
+    engine = H.oracle_engine()
+    engine.set_error_model(ErrorModel(em_name, NULL).tables())
+    qtables = QScoreModel(qm_name, NULL).tables()
+    engine.set_qscore_model(qtables)
+    random.seed(12345)
+    ref_qmodel = ref_qm.QScoreModel(qm_name, NULL)
+    fragment = recipe_fragment(seed, length, with_n)
+    c = replay_sequence_fragment(engine, em_name, qm_name, ref_qmodel, qtables, fragment, target, seed=seed, read=read)
+    return {'em': em_name, 'qm': qm_name, 'length': length, 'with_n': with_n, 'target': target, 'seed': seed, 'read': read,
+            'seq_len': len(c['seq']), 'seq_sha256': hashlib.sha256(c['seq'].encode()).hexdigest(),
+            'qual_sha256': hashlib.sha256(c['qual'].encode()).hexdigest(), 'identity': c['identity'],
+            'identity_by_qscores': c['identity_by_qscores'], 'iterations': c['iterations'], 'alignments': c['alignments']}
+
+
+def make_sequence_fragment_bound():
+    """HOW OFTEN can `est ** 1.5` (the reference, libm pow: simulate.py:321) and `est * sqrt(est)` (the oracle
+    and the kernels) part ways?  500+ more replays of the UNMODIFIED sequence_fragment with our draws -- 24 of them 50 kb fragments
+    at 80-90 % identity (up to 140 000 loop iterations and 9 000 uses of the power each) -- kept as digests (sha256 of sequence and
+    qualities, identity, iterations, alignments) with the recipe of the fragment; and the rate at which the two expressions differ
+    on THIS libm over 10^7 doubles of [0.5, 1] (tests/golden/pow15.json)."""
+    import math
+    import multiprocessing
+    import platform
+    rng = random.Random(77)
+    specs = []
+    for i in range(24):                                  # long, rough reads: many iterations at estimates far below 1
+        specs.append(('nanopore2023', 'nanopore2023', 50000, round(rng.uniform(0.80, 0.90), 3), 5000 + i, 11 * i + 3, False))
+    for i in range(500):
+        em_name, qm_name = (('nanopore2023', 'nanopore2023'), ('pacbio2021', 'pacbio2021'), ('random', 'random'), ('nanopore2018', 'nanopore2018'))[i % 4]
+        length = int(rng.choice([200, 600, 1200, 2500, 5000, 9000]) * rng.uniform(0.7, 1.3))
+        specs.append((em_name, qm_name, length, round(rng.uniform(0.78, 0.99), 3), 7000 + i, 13 * i + 5, i % 7 == 0))
+    with multiprocessing.Pool(min(8, os.cpu_count() or 1)) as pool:
+        cases = pool.map(_bound_case, specs, chunksize=4)
+    dump('sequence_fragment_bound.json.gz', {'cases': cases})
+    print(f'  {len(cases)} digest cases, {sum(c["iterations"] for c in cases)} loop iterations, {sum(c["alignments"] for c in cases)} alignments')
+    # ---- the two expressions on this libm
+    n, differ, worst = 10_000_000, 0, 0
+    import struct
+    r2 = random.Random(99)
+    for _ in range(n):
+        x = 0.5 + 0.5 * r2.random()
+        a, b = x ** 1.5, x * math.sqrt(x)
+        if a != b:
+            differ += 1
+            ua, ub = struct.unpack('<q', struct.pack('<d', a))[0], struct.unpack('<q', struct.pack('<d', b))[0]
+            worst = max(worst, abs(ua - ub))
+    dump('pow15.json', {'doubles': n, 'interval': [0.5, 1.0], 'differ': differ, 'rate': differ / n, 'largest_difference_ulps': worst,
+                        'libc': list(platform.libc_ver()), 'python': platform.python_version(),
+                        'note': 'x ** 1.5 (CPython float_pow -> libm pow) against x * math.sqrt(x); a difference of one ulp in the scale of ONE '
+                                'applied change moves `errors` by ~1e-16 relative -- it changes a result only if it flips one of the '
+                                'comparisons est <= target / the rounded identity of a later alignment: none of the replays above did'})
+    print(f'  pow15: {differ} of {n} differ ({differ / n:.3%}), at most {worst} ulp')
+
+
 def make_random_change():
     """Counts of the reference's own add_one_random_change (error_model.py:163-176) over 240 000 calls per k-mer, under
     random.seed(2024): the empirical law tests/test_golden_host.py::test_random_change_law_against_the_reference holds
@@ -675,6 +750,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'random_change':
         make_random_change()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'sequence_fragment_bound':
+        make_sequence_fragment_bound()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'sequence_fragment':
         make_sequence_fragment()
         sys.exit(0)
@@ -689,3 +767,4 @@ if __name__ == '__main__':
     make_random_change()
     make_qscore_top_rows()
     make_model_builders()
+    make_sequence_fragment_bound()
