@@ -562,7 +562,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
      * needs the sum of the first W suffix maxima (W = waves of the class) instead of the sum over all its reads
      * (measured model, configs[3]: 51.7 -> 19 GB per batch at 4096 / 1024 / 256 / 64 waves).  A set that does not fit
      * halves the waves of its fattest class until it does; only when ONE wave per class does not fit is the arena short.
-     * col_of[] (k_fin_qscore: 4 bytes per read base) stays per read, in front of the slabs. */
+     * (Rounds 1-5 kept col_of[] -- 4 bytes per read base for k_fin_qscore -- per read in front of the slabs; round 6 scores by column.) */
     auto launch_final_phase = [&](FinalSet &S, int phase) -> int {
         const uint32_t ns = S.e - S.b;
         constexpr int NCLS = 7;                     /* [4]: the narrow-band class (k_fin_lanes), its units are per GROUP of 64 reads; [5], [6]: four
@@ -578,7 +578,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         const bool use_quad = n_quad_flagged >= c->quad_min_reads;
         for (uint32_t i = S.b; i < S.e; ++i) {
             const RS &r = h_rs[h_order[i]];
-            const uint64_t col_units = r.n ? ((((uint64_t)r.m * 4 + 7) / 8 + 2 + 31) & ~31ull) : 0;
+            const uint64_t col_units = 0;      /* (rounds 1-5: col_of[], 4 bytes per read base, for k_fin_qscore -- 4 GB of a human batch's arena; round 6 scores by column) */
             h_tboff[i] = col_total * 8;                       /* RS.tb_off: byte offset of the read's col_of[] in the set's region */
             col_total += col_units;
             if (!r.n) continue;

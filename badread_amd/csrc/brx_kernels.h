@@ -1126,7 +1126,8 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
     __shared__ uint32_t qhist[256];
     __shared__ uint32_t hot_thr[BRX_QS_HOT_MAX], hot_score[BRX_QS_HOT_MAX];
     __shared__ uint8_t hot_idx[256];
-    __shared__ uint32_t pend_sp[BRX_QS_PEND], pend_h[BRX_QS_PEND];          /* windows waiting for the slow path (a ring) */
+    __shared__ uint32_t pend_sp[BRX_QS_PEND], pend_h[BRX_QS_PEND], pend_c[BRX_QS_PEND];          /* windows waiting for the slow path (a ring): base, half width, column */
+    __shared__ uint32_t draw_lds[512];                                      /* the draws of two chunks of 256 bases */
     const int lane = lane_id();
     const brx_qscore_model &qm = d.qm;
     /* The full-width window of matches ('=' x k: 89 % of all lookups with nanopore2023) keeps its row in LDS: no hash
@@ -1166,20 +1167,10 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
         uint8_t *seq = seqbuf + s.seq_off;
         uint8_t *qual = seq + (((uint64_t)m + 16 + 15) & ~15ull);
         const uint8_t *ops_end = opsbuf + s.ops_off + (uint64_t)n + (uint64_t)m;
-        uint32_t *col_of = reinterpret_cast<uint32_t *>(tb_base + s.tb_off);       /* the set's col_of[] region, RS.tb_off = this read's share */
         const bool ok = !(s.status & BRX_RS_BAND);
         const uint32_t ncols = s.n_cols;
         const uint8_t *ops = ops_end - ncols;
 
-        /* column of every read base (qscore_model.py:46-52) */
-        uint32_t run = 0;
-        for (uint32_t base = 0; base < ncols; base += 64) {
-            uint32_t c = base + lane;
-            uint32_t nd = (c < ncols && ops[c] != BRX_OP_D) ? 1u : 0u;
-            uint32_t inc = wave_incl_scan(nd);
-            if (nd) col_of[run + inc - 1] = c;
-            run += wave_bcast_u32(inc, 63);
-        }
         for (int b = lane; b < 256; b += 64) qhist[b] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
@@ -1188,19 +1179,26 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
         const uint32_t margin = (uint32_t)(qm.k - 1) / 2;
         const uint32_t maxrun = (1u << qm.gap_bits) - 1u;
         bool qmiss = false;
-        /* Two speeds.  89 % of the windows are the full-width all-match window and take the LDS row; the others need the key, the
-           hash probe, a search in global memory and sometimes narrower windows -- ~350 instructions that the wave used to issue in
-           EVERY group of 64 bases for the seven lanes that needed them.  Those lanes now only queue their window (centre, half
-           width, ops and gaps of the widest window: 24 bytes in LDS) and the slow path runs when 64 are waiting: full lanes. */
+        /* Round 6: ONE pass over the alignment's COLUMNS, 64 per step, with the next steps' op bytes in flight.  (Rounds 1-5 walked
+           the read's BASES: a first pass wrote the column of every base to col_of[] -- 4 bytes per base -- and every step of the
+           second loaded two of them and THEN the twelve op bytes behind the first: two dependent round trips per 64 bases, 240 steps
+           per 15 kb read, in a wave that has nothing else to do -- the kernel sat in s_waitcnt 75 % of its time,
+           profiles/r05_pmc_per_kernel.csv.)  A lane owns a column; the base it holds, if any, has index = bases before the step +
+           rank among the step's non-'D' columns.  Two speeds, as before: the full-width all-match window (89 % of the windows;
+           qscore_model.py:273 finds its row at the first try) is recognised from the '=' masks of three neighbouring steps --
+           the 2 margin + 1 columns around the lane are all '=' -- by wave-uniform shifts, and takes the row in LDS; every other
+           window waits in an LDS ring with its centre column and 64 of them walk their ops, probe the hash and search their
+           rows together. */
         uint32_t q_head = 0, q_tail = 0;                                   /* ring of BRX_QS_PEND entries, wave-uniform */
-        auto slow_lane = [&](uint32_t sp, uint32_t h) {
-            /* ops and D-runs of the widest window (2 h + 1 read bases around sp): 2 bits per op, op i at bits 2 i; 4 bits per gap
-               (saturated), the gap after op i at bits 4 i */
+        auto slow_lane = [&](uint32_t sp, uint32_t h, uint32_t c) {
+            /* ops and D-runs of the widest window (2 h + 1 read bases around sp, whose column is c): 2 bits per op, op i at bits
+               2 i; 4 bits per gap (saturated), the gap after op i at bits 4 i */
             uint64_t opsbits = 0, gapbits = 0;
             {
-                const uint32_t c0 = col_of[sp - h], c1 = col_of[sp + h];
+                uint32_t c0 = c;                                           /* column of base sp - h: h bases to the left */
+                for (uint32_t left = 0; left < h; ) { c0 -= 1u; if (ops[c0] != BRX_OP_D) left += 1u; }
                 uint32_t idx = 0, rn = 0;
-                for (uint32_t cc = c0; cc <= c1; ++cc) {
+                for (uint32_t cc = c0; idx < 2u * h + 1u; ++cc) {
                     const uint32_t op = ops[cc];
                     if (op == BRX_OP_D) { rn += 1; continue; }
                     if (idx > 0) { const uint32_t code = rn >= maxrun ? maxrun : rn; gapbits |= (uint64_t)code << (4 * (idx - 1)); }
@@ -1245,60 +1243,73 @@ __global__ void __launch_bounds__(64) k_fin_qscore(BrxDev d, RS *rs, const uint3
             __syncthreads();
             if ((uint32_t)lane < count) {
                 const uint32_t e = (q_head + (uint32_t)lane) & (BRX_QS_PEND - 1u);
-                slow_lane(pend_sp[e], pend_h[e]);
+                slow_lane(pend_sp[e], pend_h[e], pend_c[e]);
             }
             q_head += count;
             __syncthreads();                                               /* the slots may be written again */
         };
-        /* The draw of base sp is word sp & 3 of block sp >> 2 (qscore_model.py:54-71 draws once per base): 256 bases share 64
-           blocks, so the wave computes ONE block per lane per 256 bases and every 64-base step fetches its word from the lane
-           that holds it (four shuffles), instead of four lanes computing the same block in every step. */
-        uint32_t blk_w[4] = {0u, 0u, 0u, 0u};
-        if (ok) for (uint32_t sp0 = 0; sp0 < m; sp0 += 64) {
-            if ((sp0 & 255u) == 0u) brx_draw4(d.seed, read, BRX_ST_QS, (uint64_t)(sp0 >> 2) + (uint64_t)lane, blk_w);
-            const int src = (int)(((sp0 & 255u) >> 2) + ((uint32_t)lane >> 2));        /* lane that drew the block of base sp0 + lane */
-            const uint32_t u0 = wave_bcast_u32(blk_w[0], src), u1 = wave_bcast_u32(blk_w[1], src);
-            const uint32_t u2 = wave_bcast_u32(blk_w[2], src), u3 = wave_bcast_u32(blk_w[3], src);
-            const uint32_t u_step = (lane & 2) ? ((lane & 1) ? u3 : u2) : ((lane & 1) ? u1 : u0);
-            const uint32_t sp = sp0 + (uint32_t)lane;
-            const bool valid = sp < m;
-            uint32_t h = margin;
-            bool hot = false;
-            if (valid) {
-                if (sp < h) h = sp;
-                if (m - 1 - sp < h) h = m - 1 - sp;
-                /* the all-match window of full width (the LDS row): its 2 margin + 1 bases sit in consecutive columns -- no 'D'
-                   between them -- and those columns' ops are all '=' (code 0): two column numbers and twelve op bytes, not a
-                   walk over the window.  Every other window is queued with its centre and half width; the lanes of a drain
-                   walk theirs together. */
-                if (hot_n && h == margin) {
-                    const uint32_t c0 = col_of[sp - h], c1 = col_of[sp + h];
-                    if (c1 - c0 == 2u * margin) {
-                        const BrxB16x3 o3 = *reinterpret_cast<const BrxB16x3 *>(ops + c0);       /* ops is followed by the slack of its buffer */
-                        const uint32_t nb = 2u * margin + 1u;                                     /* <= 12 for k <= 11: asserted at load */
-                        const uint32_t last = nb > 8u ? (nb >= 12u ? 0xFFFFFFFFu : (1u << (8u * (nb - 8u))) - 1u) : 0u;
-                        const uint64_t first8 = nb >= 8u ? ~0ull : (1ull << (8u * nb)) - 1ull;
-                        hot = ((((uint64_t)o3.y << 32) | (uint64_t)o3.x) & first8) == 0ull && (o3.z & last) == 0u;
+        /* The draw of base sp is word sp & 3 of block sp >> 2 (qscore_model.py:54-71 draws once per base).  The wave computes the
+           blocks of 256 bases at a time (one Philox block per lane) into one of two LDS slots; a step's bases lie in at most two
+           consecutive chunks of 256. */
+        uint32_t chunks_drawn = 0;                                         /* chunks [0, chunks_drawn) are or were in LDS: chunk q in slot q & 1 */
+        if (ok) {
+            const uint32_t nsteps = (ncols + 63u) >> 6;
+            auto load_step = [&](uint32_t step) -> uint32_t {              /* the op byte of this lane's column in `step` (0xFF: no column) */
+                const uint32_t c = 64u * step + (uint32_t)lane;
+                return (step < nsteps && c < ncols) ? (uint32_t)ops[c] : 0xFFu;
+            };
+            uint32_t op_cur = load_step(0), op_next = load_step(1);
+            unsigned long long e_prev = 0ull, e_cur = __ballot(op_cur == 0u), e_next = 0ull;
+            uint32_t sp_base = 0;                                          /* read bases in the columns before this step */
+            for (uint32_t step = 0; step < nsteps; ++step) {
+                const uint32_t op_nn = load_step(step + 2u);               /* in flight over two steps */
+                e_next = __ballot(op_next == 0u);
+                const unsigned long long base_m = __ballot(op_cur != BRX_OP_D && op_cur != 0xFFu);
+                /* columns whose 2 margin + 1 neighbourhood is all '=' (wave-uniform) */
+                unsigned long long hot_m = e_cur;
+                for (uint32_t dd = 1; dd <= margin; ++dd)
+                    hot_m &= ((e_cur >> dd) | (e_next << (64u - dd))) & ((e_cur << dd) | (e_prev >> (64u - dd)));
+                /* the draws of this step's bases: chunks (sp_base >> 8) and possibly the next */
+                while (chunks_drawn <= ((sp_base + 63u) >> 8)) {
+                    uint32_t w4[4];
+                    brx_draw4(d.seed, read, BRX_ST_QS, (uint64_t)(chunks_drawn * 64u) + (uint64_t)lane, w4);
+                    uint32_t *slot = draw_lds + (chunks_drawn & 1u) * 256u + 4u * (uint32_t)lane;
+                    slot[0] = w4[0]; slot[1] = w4[1]; slot[2] = w4[2]; slot[3] = w4[3];
+                    chunks_drawn += 1u;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __syncthreads();
+                }
+                const bool valid = ((base_m >> lane) & 1ull) != 0ull;
+                const uint32_t sp = sp_base + (uint32_t)__popcll(base_m & ((1ull << lane) - 1ull));
+                uint32_t h = margin;
+                bool hot = false;
+                if (valid) {
+                    if (sp < h) h = sp;
+                    if (m - 1 - sp < h) h = m - 1 - sp;
+                    hot = hot_n && h == margin && ((hot_m >> lane) & 1ull) != 0ull;
+                }
+                if (hot) {
+                    const uint32_t u = draw_lds[((sp >> 8) & 1u) * 256u + (sp & 255u)];
+                    uint32_t e = hot_idx[u >> 24];             /* first entry whose cumulative threshold exceeds the draw, else the last one */
+                    while (e < hot_n - 1u && u >= hot_thr[e]) e += 1u;
+                    const uint32_t score = hot_score[e];
+                    qual[sp] = (uint8_t)(score + 33);
+                    atomicAdd(&qhist[score & 255u], 1u);
+                }
+                const bool slow = valid && !hot;
+                const unsigned long long sm = __ballot(slow);
+                if (sm) {
+                    if (slow) {
+                        const uint32_t e = (q_tail + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))) & (BRX_QS_PEND - 1u);
+                        pend_sp[e] = sp; pend_h[e] = h; pend_c[e] = 64u * step + (uint32_t)lane;
                     }
+                    q_tail += (uint32_t)__popcll(sm);
+                    if (q_tail - q_head >= 64u) drain(64u);
                 }
-            }
-            if (hot) {
-                const uint32_t u = u_step;
-                uint32_t e = hot_idx[u >> 24];                 /* first entry whose cumulative threshold exceeds the draw, else the last one */
-                while (e < hot_n - 1u && u >= hot_thr[e]) e += 1u;
-                const uint32_t score = hot_score[e];
-                qual[sp] = (uint8_t)(score + 33);
-                atomicAdd(&qhist[score & 255u], 1u);
-            }
-            const bool slow = valid && !hot;
-            const unsigned long long sm = __ballot(slow);
-            if (sm) {
-                if (slow) {
-                    const uint32_t e = (q_tail + (uint32_t)__popcll(sm & ((1ull << lane) - 1ull))) & (BRX_QS_PEND - 1u);
-                    pend_sp[e] = sp; pend_h[e] = h;
-                }
-                q_tail += (uint32_t)__popcll(sm);
-                if (q_tail - q_head >= 64u) drain(64u);
+                sp_base += (uint32_t)__popcll(base_m);
+                e_prev = e_cur; e_cur = e_next;
+                op_cur = op_next; op_next = op_nn;
             }
         }
         if (q_tail != q_head) drain(q_tail - q_head);

@@ -304,13 +304,13 @@ class BrxError(RuntimeError):
 
 def arena_estimate(n_reads, mean_length, error_rate=None):
     """Bytes of scratch arena for device batches of `n_reads` reads of `mean_length` bases (HipEngine.presize): fragment,
-    replacement words, read + qualities + ops, col_of[] = 13.5 B per base; traceback slabs by the edits per base (35 B per base at
+    replacement words, read + qualities + ops = 9.5 B per base (round 6: no col_of[]); traceback slabs by the edits per base (35 B per base at
     the 5 % of nanopore2023 defaults up to ~20 GB -- the final align kernels hold at most 2048 / 1024 / 512 / 256 slabs --, ~2 B
     at Q30 reads since the narrow-band class walks its traceback in strips: measured, profiles/r05d: 6.4 GB per 65536-read batch of
     configs[4] including col_of[]); per-wave window scratch and move-code stores of the mutate stage."""
     bases = float(n_reads) * (float(mean_length) + 14.0)
     per_base = 35.0 if error_rate is None else min(35.0, max(3.0, 35.0 * float(error_rate) / 0.05))
-    return int(13.5 * bases + min(per_base * bases, 20e9) + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 512.0) * 6.6e6 + (64 << 20))
+    return int(9.5 * bases + min(per_base * bases, 20e9) + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 512.0) * 6.6e6 + (64 << 20))
 
 
 class HipEngine(EngineBase):
@@ -483,9 +483,20 @@ class HipEngine(EngineBase):
             return out_bytes.value
         raise BrxError(E_SCRATCH, 'could not size scratch/output buffers after 8 attempts')
 
+    def expected_record_bytes(self):
+        """FASTQ bytes per read the engine's parameters lead to expect, with 6 % of margin: sequence + qualities of a read whose
+        fragments chain with the chimera rate (a read is 1 / (1 - rate) fragments on average) plus the header's share.  34 kB at
+        the defaults (what rounds 1-5 assumed for every job); --chimeras 25 makes reads a third longer, and a guess that is short
+        costs every engine of a job one repeated batch (brx_simulate_batch reports BRX_E_OUTPUT with the size it needs)."""
+        p = self._structs.get('params')
+        if p is None:
+            return 34000.0
+        chain = 1.0 / max(1.0 - min(float(p.chimera_rate), 0.9), 0.1)
+        return 1.06 * chain * (2.1 * float(p.frag_mean) + 400.0)
+
     def simulate_batch_device(self, seed, first_read, n_reads, expected_bytes=None, allow_nofrag=False):
         """Returns (device uint8 tensor view of the FASTQ bytes, stats as numpy structured array)."""
-        guess = expected_bytes or (n_reads * 34000 + (1 << 16))
+        guess = expected_bytes or (int(n_reads * self.expected_record_bytes()) + (1 << 16))
         nbytes = self._retry(lambda o, cap, st, ob: self.lib.brx_simulate_batch(
             self.ctx, seed, first_read, n_reads, o, cap, st, ob, self._stream()), n_reads, guess, allow_nofrag)
         stats = self._stats[:n_reads * READ_STATS_DTYPE.itemsize].cpu().numpy().view(READ_STATS_DTYPE)

@@ -683,7 +683,7 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
             engine.presize(first_batch, expected_mean)
         else:                                    # the job's identity law: arenas for Q30 reads are half those of 95 % reads
             engine.presize(first_batch, expected_mean, expected_error)
-        out_bytes = int(first_batch * (2.1 * expected_mean + 400.0))
+        out_bytes = int(first_batch * (engine.expected_record_bytes() if hasattr(engine, 'expected_record_bytes') else 2.1 * expected_mean + 400.0))
     else:
         out_bytes = 0
     asked = fit = max(1, int(in_flight))

@@ -404,12 +404,28 @@ def main():
         first = configure(HipEngine(local, scratch_bytes=int(args.scratch_gb * (1 << 30))), wl)
         torch.cuda.synchronize()
         ref_timing['h2d_tables_s'] = round(time.perf_counter() - t_up, 2)
-        engines = [first] + [first.clone() for _ in range(C - 1)]       # clones share the device tables: ONE replica of the reference per GPU
+        engines = [first] + [None] * (C - 1)               # clones share the device tables: ONE replica of the reference per GPU
         streams = [torch.cuda.Stream(device=local) for _ in range(C)]
-        for e, st_ in zip(engines, streams):              # prime every context (lazy module load, buffers) -- not a step
-            e.set_kernel_timing(True)
-            with torch.cuda.stream(st_):
-                e.simulate_batch_device(SEED, 2 ** 40, 64, expected_bytes=R * 36000)
+        boot_errors = []
+
+        def boot(i):                                       # a thread per context, as the CLI's pool makes its clones: arena, context, priming batch
+            try:
+                torch.cuda.set_device(local)
+                if i:
+                    engines[i] = first.clone()
+                engines[i].set_kernel_timing(True)
+                with torch.cuda.stream(streams[i]):        # prime the context (lazy module load, buffers) -- not a step
+                    engines[i].simulate_batch_device(SEED, 2 ** 40, 64, expected_bytes=int(R * first.expected_record_bytes() * 1.05))
+                    streams[i].synchronize()
+            except BaseException as ex:
+                boot_errors.append(ex)
+        boots = [threading.Thread(target=boot, args=(i,)) for i in range(C)]
+        for th in boots:
+            th.start()
+        for th in boots:
+            th.join()
+        if boot_errors:
+            raise boot_errors[0]
         torch.cuda.synchronize()
     marks['engines'] = time.perf_counter()
     # --scaling strong: the job as device batches; batch b covers read indices [b R, (b + 1) R) and belongs to rank b % world
@@ -421,7 +437,7 @@ def main():
         if dry:
             _, stats = e.simulate_batch(SEED, first_read, R)
             return stats
-        _, stats = e.simulate_batch_device(SEED, first_read, R, expected_bytes=R * 36000)
+        _, stats = e.simulate_batch_device(SEED, first_read, R, expected_bytes=int(R * e.expected_record_bytes() * 1.05))
         return stats
 
     def run_steps(step_indices, indices=None):
