@@ -43,6 +43,9 @@ struct brx_ctx {
     hipEvent_t ev_b[BRX_STAGE_COUNT], ev_e[BRX_STAGE_COUNT];   /* begin / end of each stage on the launch stream */
     float stage_ms[BRX_STAGE_COUNT];
     uint32_t final_launches, mutate_passes;
+    uint32_t lanes_cycles;
+    int mutate_passes_route;     /* BRX_MUTATE_PASSES=1: the bulk set through host-driven passes {k_mut_apply, k_mut_post, k_pass_lists, k_win_lane, k_win_wave}
+                                    and an in-place tail (rounds 2-6a) instead of one launch of k_mut_lanes */
     uint32_t tail_reads;         /* BRX_TAIL_READS: this few reads left in the mutate stage -> one in-place launch (0xFFFFFFFF = not set: n_reads / 8, at least 1024;
                                     measured on configs[3]: 1024 of 16384, 4096 of 49152) */
     int tb_hmul;                 /* BRX_TB_WINDOW: window of the final traceback store in sqrt(ub) units (2; 0 = full store; -1 = 8 rows, test) */
@@ -190,6 +193,8 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return create_fail(c, "hipEventCreate", e);
     { const char *pf = getenv("BRX_PROFILE"); c->profile = (pf && atoi(pf)) ? 1 : 0; }
     { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
+    { const char *v = getenv("BRX_MUTATE_PASSES"); c->mutate_passes_route = v && atoi(v) != 0; }
+    { const char *v = getenv("BRX_LANES_CYCLES"); c->lanes_cycles = v ? (uint32_t)atoi(v) : 64u; }       /* alignment cycles a read spends in k_mut_lanes before the in-place kernel takes it over (0: all) */
     { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 0xFFFFFFFFu; }   /* unset: an eighth of the batch, at least 1024 */
     c->err[0] = 0;
     *out = c;
@@ -456,7 +461,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *F2buf = (uint32_t *)A.take(((size_t)f_bytes / 16 + 16) * 4);       /* the fragments as 2-bit codes: word F_off / 16 (k_build) */
     uint32_t *Cbuf = (uint32_t *)A.take(((size_t)f_bytes / 16 + 16) * 4);        /* a bit per base: replaced (same index) */
     const uint32_t side_waves = std::min<uint32_t>(n_reads, 4096u);                 /* wave-level window aligner / legacy */
-    const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, 512u);   /* lane-level window aligner: one 6.4 MB store of move codes per wave */
+    const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, c->mutate_passes_route ? 512u : 1024u);   /* lane-level window aligner: one 6.4 MB store of move codes per wave */
     uint8_t *win = (uint8_t *)A.take((size_t)(side_waves + 1) * c->win_bytes);      /* one slot per wave */
     MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
     uint32_t *mctr = (uint32_t *)A.take(8 * MC_WORDS * sizeof(uint32_t));   /* pass counters 0/1, 2 first bulk input, 3 bulk legacy, 4 head input, 5 head legacy, 6 head pass */
@@ -472,8 +477,10 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint2 *lane_tb = (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
     /* the bulk passes' survivor rings (brx_passes.h): 20 bytes per entry, BRX_SV_CAP entries per read */
     PQ *pq = (PQ *)A.take((size_t)n_reads * sizeof(PQ));
-    uint4 *sv_a = (uint4 *)A.take((size_t)n_reads * BRX_SV_CAP * sizeof(uint4));
-    uint32_t *sv_z = (uint32_t *)A.take((size_t)n_reads * BRX_SV_CAP * sizeof(uint32_t));
+    /* k_mut_lanes: ring of read r at F_off / 8 + 128 r, n / 8 + 128 entries (brx_ring_base); the passes: BRX_SV_CAP entries per read */
+    const size_t sv_entries = c->mutate_passes_route ? (size_t)n_reads * BRX_SV_CAP : ((size_t)f_bytes >> BRX_RING_SHIFT) + (size_t)BRX_RING_MIN * (size_t)n_reads + 256;
+    uint4 *sv_a = (uint4 *)A.take(sv_entries * sizeof(uint4));
+    uint32_t *sv_z = (uint32_t *)A.take(sv_entries * sizeof(uint32_t));
     const uint32_t tail_eff = c->tail_reads != 0xFFFFFFFFu ? c->tail_reads : std::max<uint32_t>(1024u, n_reads / 8u);
     const bool all_head = n_reads <= tail_eff;      /* the whole batch in one run-to-completion launch */
     if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
@@ -924,9 +931,33 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         if (n_mb) HIPCHK(c, hipEventRecord(c->ev_head_mut, s_head));
         c->mutate_passes = 1;
     }
-    /* ---- bulk chain: passes ---- */
+    /* ---- bulk chain ---- */
     int rc2 = BRX_OK;
-    if (n_mb) {
+    if (n_mb && !c->mutate_passes_route) {
+        /* round 6b: ONE launch -- a wave keeps 64 reads (neighbours in the order by expected changes) from the first iteration to the
+           last (k_mut_lanes); their survivors are proposed ahead, all of them, by k_mut_fill; the epilogues follow */
+        const uint32_t post_waves = std::min<uint64_t>(n_mb, (uint64_t)c->n_cu * 32u);
+        const uint32_t groups = (n_mb + 63u) / 64u;
+        {
+            KTIMED(BRX_KERN_MUT_POST, st);
+            hipLaunchKernelGGL((k_mut_fill<BRX_POST_U>), dim3(post_waves), dim3(64), 0, st, dev, rs, pq, order + n_mh, n_mb, Fbuf, F2buf, Cbuf, sv_a, sv_z);
+        }
+        uint32_t *left_ctr = mctr + MC_OUT;                 /* block 0: [MC_QUEUE] the tail's queue, [MC_OUT] reads the lane kernel leaves */
+        {
+            KTIMED(BRX_KERN_MUTATE_SEG, st);
+            hipLaunchKernelGGL((k_mut_lanes<BRX_POST_U>), dim3(std::min(groups, lane_waves)), dim3(64), 0, st, dev, rs, msv, pq, order + n_mh, n_mb, h_aux[0],
+                               Fbuf, repl, F2buf, Cbuf, sv_a, sv_z, lane_tb, c->lanes_cycles ? c->lanes_cycles : 0xFFFFFFFFu, active_a, left_ctr);
+        }
+        if (c->lanes_cycles) {                             /* what is left of the reads with the most cycles: in place, one wave per read */
+            launch_run(st, std::min<uint32_t>(n_mb, 8192u), active_a, left_ctr, mctr, aux_dev);
+            c->mutate_passes += 1;
+        }
+        {
+            KTIMED(BRX_KERN_MUT_POST, st);
+            hipLaunchKernelGGL(k_mut_epilogue, dim3(post_waves), dim3(64), 0, st, dev, rs, msv, order + n_mh, n_mb, h_aux[0], Fbuf, repl);
+        }
+        c->mutate_passes += 1;
+    } else if (n_mb) {
         const uint32_t post_waves = std::min<uint64_t>(n_mb, (uint64_t)c->n_cu * 32u);      /* k_mut_post: eight waves per SIMD, grid-stride over the pass's reads */
         uint32_t *h_ctr = reinterpret_cast<uint32_t *>(c->h_totals + 8);          /* pinned */
         uint32_t *legacy_ctr = mctr + 3 * MC_WORDS;                                 /* [0] count, [1] queue; not reset per pass */

@@ -65,13 +65,12 @@ __device__ __forceinline__ uint32_t brx_loop_cap32(uint32_t n) {
 /* -------------------------------------------------------------------------------------------------
  * k_mut_apply: one read per lane
  * ----------------------------------------------------------------------------------------------- */
-__global__ void __launch_bounds__(64, 8) k_mut_apply(BrxDev d, const RS *rs, MS *msv, PQ *pq, const uint32_t *active_in, const uint32_t *n_in_ptr,
-                                                      const uint4 *sv_a, const uint32_t *sv_z, uint32_t *repl, uint32_t *Cbuf) {
-    const uint32_t idx = blockIdx.x * 64u + (uint32_t)lane_id();
-    if (idx >= *n_in_ptr) return;
-    const uint32_t r = active_in[idx];
+/* The sequential half of the loop for read r, by the calling LANE: its survivors from the ring until the 25th change, the end of
+   the loop or an empty ring.  Returns the outcome (MP_PARK / MP_FINISH / MP_HUNGRY; 0 for an empty read) and leaves it in MS.phase. */
+__device__ inline uint32_t brx_apply_read(const BrxDev &d, const RS *rs, MS *msv, PQ *pq, const uint32_t r,
+                                          const uint4 *ra, const uint32_t *rz, const uint32_t ring_cap, uint32_t *repl, uint32_t *Cbuf) {
     const uint32_t n = rs[r].n;
-    if (n == 0u) return;
+    if (n == 0u) return 0u;
     const brx_error_model &em = d.em;
     const int k = em.k;
     const uint64_t F_off = rs[r].F_off;
@@ -109,15 +108,13 @@ __global__ void __launch_bounds__(64, 8) k_mut_apply(BrxDev d, const RS *rs, MS 
         }
     }
     PQ q = pq[r];
-    const uint4 *ra = sv_a + (size_t)r * BRX_SV_CAP;
-    const uint32_t *rz = sv_z + (size_t)r * BRX_SV_CAP;
+    uint32_t slot = q.head % ring_cap;
     while (!over) {
         if (q.head == q.tail) {
             if (q.next_t >= cap) { outcome = MP_FINISH; loops = cap + 1u; }                               /* :280-281 */
             else { outcome = MP_HUNGRY; t_at = q.next_t; }
             break;
         }
-        const uint32_t slot = q.head & (BRX_SV_CAP - 1u);
         const uint4 e = ra[slot];
         const uint32_t pz = rz[slot];
         const uint32_t t = e.x, i0 = e.y, px = e.z, py = e.w;
@@ -154,6 +151,7 @@ __global__ void __launch_bounds__(64, 8) k_mut_apply(BrxDev d, const RS *rs, MS 
         }
         if (parked) { outcome = MP_PARK; t_at = t; break; }                                               /* the entry stays: the next pass resumes in it */
         q.head += 1u;
+        slot = slot + 1u == ring_cap ? 0u : slot + 1u;
         j0 = 0u;
         if (applies || !fresh) {                    /* top-of-loop tests of the iteration behind this survivor (:285-291) */
             const double est2 = 1.0 - errors / dn;
@@ -167,6 +165,15 @@ __global__ void __launch_bounds__(64, 8) k_mut_apply(BrxDev d, const RS *rs, MS 
     if (outcome == MP_FINISH) mp->round_loops = (uint64_t)loops;
     else { mp->round_loops = (uint64_t)(t_at & ~63u); mp->surv_lane = t_at & 63u; mp->j_next = outcome == MP_PARK ? jn : 0u; }
     mp->phase = outcome;
+    return outcome;
+}
+
+__global__ void __launch_bounds__(64, 8) k_mut_apply(BrxDev d, const RS *rs, MS *msv, PQ *pq, const uint32_t *active_in, const uint32_t *n_in_ptr,
+                                                      const uint4 *sv_a, const uint32_t *sv_z, uint32_t *repl, uint32_t *Cbuf) {
+    const uint32_t idx = blockIdx.x * 64u + (uint32_t)lane_id();
+    if (idx >= *n_in_ptr) return;
+    const uint32_t r = active_in[idx];
+    (void)brx_apply_read(d, rs, msv, pq, r, sv_a + (size_t)r * BRX_SV_CAP, sv_z + (size_t)r * BRX_SV_CAP, BRX_SV_CAP, repl, Cbuf);
 }
 
 /* -------------------------------------------------------------------------------------------------
@@ -195,6 +202,52 @@ __device__ __forceinline__ bool brx_propose_iter(const BrxDev &d, uint64_t read,
     } else pr = dev_propose_row(em, row, w[2], w[3]);
     *ipos_out = ipos; *out = pr;
     return pr.y != 0u;
+}
+
+/* Propose ahead for read r, by the whole WAVE: survivors of the next iterations into the ring, in iteration order, until it holds
+   `stock` of them (or cannot take another trip's worth, or the loop cap is reached). */
+template <int U>
+__device__ inline void brx_propose_ahead(const BrxDev &d, const uint32_t r, const RS *rs, PQ *pq, const uint8_t *Fbuf, const uint32_t *F2buf,
+                                         const uint32_t *Cbuf, uint4 *ra, uint32_t *rz, const uint32_t ring_cap, const uint32_t stock) {
+    const int lane = lane_id();
+    const uint32_t n = uni(rs[r].n);
+    if (n == 0u) return;
+    const uint64_t F_off = uni(rs[r].F_off);
+    const int k = d.em.k;
+    const uint8_t *F = Fbuf + F_off;
+    PQ q = pq[r];
+    q.head = uni(q.head); q.tail = uni(q.tail); q.next_t = uni(q.next_t);
+    const uint32_t tail0 = q.tail, next0 = q.next_t;
+    const uint32_t cap = brx_loop_cap32(n);
+    const uint32_t max_i1 = n - (uint32_t)k;                   /* max_kmer_index + 1 (simulate.py:270) */
+    const uint32_t *f2g = F2buf + (F_off >> 4);
+    const uint32_t nw2 = (n + 15u) >> 4, nwc = (n + 31u) >> 5;
+    const bool coded = uni(f2g[nw2] == 0u);
+    const uint32_t *oddg = Cbuf + (F_off >> 4) + nwc;
+    uint32_t have = q.tail - q.head;
+    while (have < stock && have + 64u * (uint32_t)U <= ring_cap && q.next_t < cap) {
+        uint32_t ip[U]; BrxProp pr[U]; bool sv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t t = q.next_t + 64u * (uint32_t)u + (uint32_t)lane;
+            sv[u] = false; ip[u] = 0u; pr[u].x = pr[u].y = pr[u].z = 0u;
+            if (t < cap) sv[u] = brx_propose_iter(d, d.first_read + r, t, max_i1, f2g, oddg, coded, F, &ip[u], &pr[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long m = __ballot(sv[u]);
+            if (sv[u]) {
+                const uint32_t slot = (q.tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % ring_cap;
+                ra[slot] = make_uint4(q.next_t + 64u * (uint32_t)u + (uint32_t)lane, ip[u], pr[u].x, pr[u].y);
+                rz[slot] = pr[u].z;
+            }
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            q.tail += cnt; have += cnt;
+        }
+        const uint32_t room = cap - q.next_t;
+        q.next_t += room < 64u * (uint32_t)U ? room : 64u * (uint32_t)U;
+    }
+    if (lane == 0 && (q.tail != tail0 || q.next_t != next0)) { pq[r].tail = q.tail; pq[r].next_t = q.next_t; }
 }
 
 template <int U>
@@ -252,42 +305,7 @@ __global__ void __launch_bounds__(64, 8) k_mut_post(BrxDev d, RS *rs, MS *msv, P
         } else if (ms.phase == (uint32_t)MP_FINISH) {
             /* the loop is over: the epilogue waits for k_mut_epilogue, once, behind the last pass */
         } else goes_on = true;                      /* not started (the fill before the first pass) or hungry */
-        if (goes_on) {
-            /* ---- propose ahead: survivors of the next iterations into the ring, in iteration order ---- */
-            PQ q = pq[r];
-            const uint32_t cap = brx_loop_cap32(n);
-            const uint32_t max_i1 = n - (uint32_t)k;                   /* max_kmer_index + 1 (simulate.py:270) */
-            const uint32_t *f2g = F2buf + (s.F_off >> 4);
-            const uint32_t nw2 = (n + 15u) >> 4, nwc = (n + 31u) >> 5;
-            const bool coded = uni(f2g[nw2] == 0u);
-            const uint32_t *oddg = Cbuf + (s.F_off >> 4) + nwc;
-            uint4 *ra = sv_a + (size_t)r * BRX_SV_CAP;
-            uint32_t *rz = sv_z + (size_t)r * BRX_SV_CAP;
-            uint32_t have = q.tail - q.head;
-            while (have < BRX_SV_STOCK && have + 64u * (uint32_t)U <= BRX_SV_CAP && q.next_t < cap) {
-                uint32_t ip[U]; BrxProp pr[U]; bool sv[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t t = q.next_t + 64u * (uint32_t)u + (uint32_t)lane;
-                    sv[u] = false; ip[u] = 0u; pr[u].x = pr[u].y = pr[u].z = 0u;
-                    if (t < cap && t >= q.next_t) sv[u] = brx_propose_iter(d, d.first_read + r, t, max_i1, f2g, oddg, coded, F, &ip[u], &pr[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const unsigned long long m = __ballot(sv[u]);
-                    if (sv[u]) {
-                        const uint32_t slot = (q.tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (BRX_SV_CAP - 1u);
-                        ra[slot] = make_uint4(q.next_t + 64u * (uint32_t)u + (uint32_t)lane, ip[u], pr[u].x, pr[u].y);
-                        rz[slot] = pr[u].z;
-                    }
-                    const uint32_t cnt = (uint32_t)__popcll(m);
-                    q.tail += cnt; have += cnt;
-                }
-                const uint32_t room = cap - q.next_t;
-                q.next_t += room < 64u * (uint32_t)U ? room : 64u * (uint32_t)U;
-            }
-            if (lane == 0) { pq[r].tail = q.tail; pq[r].next_t = q.next_t; }
-        }
+        if (goes_on) brx_propose_ahead<U>(d, r, rs, pq, Fbuf, F2buf, Cbuf, sv_a + (size_t)r * BRX_SV_CAP, sv_z + (size_t)r * BRX_SV_CAP, BRX_SV_CAP, BRX_SV_STOCK);
         if (lane == 0) ck[0] += __builtin_amdgcn_s_memtime() - t_begin;
     }
 }
@@ -368,6 +386,231 @@ __global__ void __launch_bounds__(64) k_pass_lists(const MS *msv, const uint32_t
         if (__ballot(p) != 0ull) {
             const uint32_t at = atomicAdd(aux.legacy_ctr, p ? 1u : 0u);
             if (p) aux.req_legacy[at] = r;
+        }
+    }
+}
+
+/* =================================================================================================
+ * k_mut_lanes: the whole mutate loop of 64 reads in ONE wave, from the first iteration to the last
+ * =================================================================================================
+ * The passes above regroup the reads between kernels (lists by band class, a launch per step, the host in between).  Nothing in
+ * the loop needs that: a read's survivors are in its ring (proposed ahead, all of them, by k_mut_fill before this kernel starts), the
+ * sequential half is one lane's work (brx_apply_read), a window's alignment is one lane's work (brx_lanes_align: the band in
+ * registers), and so -- this round -- is its parking (brx_lane_park: the lane joins its own 1000 positions and packs both strings
+ * into bit planes as it goes).  A wave therefore keeps its 64 reads (neighbours in the order by expected changes: equal work) and
+ * turns the crank until the last of them is done: apply -> park -> align -> apply ..., no launch, no list, no atomic, no host.
+ * What a lane cannot do alone is taken by the whole wave for that one read: a window the lane aligner does not take (symbols outside
+ * ACGT, more than eight band blocks) goes through wave_park + brx_wave_align as in k_win_wave; a ring that runs empty is refilled by
+ * brx_propose_ahead; a window that overflows its slot sends the read to the whole-read kernel.
+ * Instructions per read and alignment cycle: ~3 k (apply 60, park 250, align 1.9-2.6 k as 1/64 of the wave's) against ~69 k of the
+ * in-place kernel (k_mutate_seg: 61 k of them one window on a whole wave) and ~8 k + 1.9 k of the passes.
+ *
+ * Ring of read r: entries [ring_base(r), + ring_cap(r)) of sv_a / sv_z with ring_base = F_off / 8 + 128 r, ring_cap = n / 8 + 128:
+ * the fragment offsets are a prefix sum over the reads already, so no layout pass is needed; n / 8 entries hold every survivor of a
+ * read down to ~88 % identity, a rougher read wraps around and is refilled. */
+#ifndef BRX_RING_SHIFT
+#define BRX_RING_SHIFT 3                                 /* ring entries per read: n >> BRX_RING_SHIFT ... */
+#define BRX_RING_MIN 128u                                /* ... + BRX_RING_MIN (at least a trip's 64 U; the tests build tiny rings) */
+#endif
+__device__ __forceinline__ uint64_t brx_ring_base(const RS *rs, uint32_t r) { return (rs[r].F_off >> BRX_RING_SHIFT) + (uint64_t)BRX_RING_MIN * (uint64_t)r; }
+__device__ __forceinline__ uint32_t brx_ring_cap(const RS *rs, uint32_t r) { return (rs[r].n >> BRX_RING_SHIFT) + BRX_RING_MIN; }
+
+/* Survivors a read is expected to need over its whole loop: every change adds at least target^1.5 errors while the loop runs
+   (simulate.py:321), a survivor applies at least ... most of the time one change; 10 % and a round on top. */
+__device__ __forceinline__ uint32_t brx_ring_want(uint32_t n, double target) {
+    const double need = (double)n * (1.0 - target);
+    if (need < 0.5) return 0u;
+    const double t = target > 0.05 ? target : 0.05;
+    const double s = 1.1 * need / (t * brx_sqrt(t)) + 64.0;
+    return s > 4.0e9 ? 0xF0000000u : (uint32_t)s;
+}
+
+/* all the survivors a read is expected to need, before the loop starts (a wave per read; many rounds each, U in flight) */
+template <int U>
+__global__ void __launch_bounds__(64, 8) k_mut_fill(BrxDev d, const RS *rs, PQ *pq, const uint32_t *list, uint32_t n_list, const uint8_t *Fbuf,
+                                                     const uint32_t *F2buf, const uint32_t *Cbuf, uint4 *sv_a, uint32_t *sv_z) {
+    for (uint32_t qi = blockIdx.x; qi < n_list; qi += gridDim.x) {
+        const uint32_t r = uni(list[qi]);
+        const uint32_t n = uni(rs[r].n);
+        if (n == 0u) continue;
+        const uint64_t base = uni(brx_ring_base(rs, r));
+        const uint32_t cap = uni(brx_ring_cap(rs, r));
+        uint32_t want = brx_ring_want(n, rs[r].target);
+        want = uni(want);
+        const uint32_t room = cap - 64u * (uint32_t)U;
+        brx_propose_ahead<U>(d, r, rs, pq, Fbuf, F2buf, Cbuf, sv_a + base, sv_z + base, cap, want < room ? want : room);
+    }
+}
+
+/* The window [a, b) of read r, parked by ONE lane: query planes pl[0, 32) / pl[32, 64) and target planes pl[64, ...) / pl[64 + TW, ...)
+   as wave_park<true> writes them (bit x of word x / 32: symbol x; lo = bit 0 of the code, hi = bit 1), joined length, edit bound
+   and "a symbol outside ACGT".  Target planes are written for the first BRX_LANE_TMAX symbols only (a longer window is not the
+   lane aligner's). */
+__device__ inline void brx_lane_park(const brx_error_model &em, const uint8_t *F, const uint32_t *rp, const uint32_t a, const uint32_t b,
+                                     uint32_t *pl, uint32_t *tl_out, uint32_t *cost_out, bool *odd_out) {
+    constexpr uint32_t TW = BRX_LANE_TMAX / 32;
+    uint32_t tl = 0, cost = 0;
+    bool odd = false;
+    uint32_t qlo = 0, qhi = 0, tlo = 0, thi = 0;
+    const uint32_t ql = b - a;
+    for (uint32_t x0 = 0; x0 < ql; x0 += 16u) {
+        const uint32_t p0 = a + x0;
+        const uint32_t nv = ql - x0 < 16u ? ql - x0 : 16u;
+        const BrxB16 f = *reinterpret_cast<const BrxB16 *>(F + p0);              /* F holds 16 bytes behind the read */
+        const uint32_t fw[4] = {f.x, f.y, f.z, f.w};
+        uint32_t rw[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const BrxU4 r4 = *reinterpret_cast<const BrxU4 *>(rp + p0 + 4u * (uint32_t)q);
+            rw[4 * q] = r4.x; rw[4 * q + 1] = r4.y; rw[4 * q + 2] = r4.z; rw[4 * q + 3] = r4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if ((uint32_t)i < nv) {
+                const uint32_t x = x0 + (uint32_t)i;
+                const uint32_t sym = (fw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                const uint32_t w = rw[i];
+                odd |= (sym & 0xFCu) != 0u;
+                qlo |= (sym & 1u) << (x & 31u); qhi |= ((sym >> 1) & 1u) << (x & 31u);
+                if ((x & 31u) == 31u || x + 1u == ql) { pl[x >> 5] = qlo; pl[32u + (x >> 5)] = qhi; qlo = 0u; qhi = 0u; }
+                const uint32_t len = w ? (w >> 24) & 0x7Fu : 1u;
+                bool has = false;
+                for (uint32_t y = 0; y < len; ++y) {
+                    const uint32_t ch = w ? (uint32_t)rep_char(em, w, y) : sym;
+                    if (w) { odd |= ch > 3u; has |= ch == sym; }
+                    if (tl < BRX_LANE_TMAX) {
+                        tlo |= (ch & 1u) << (tl & 31u); thi |= ((ch >> 1) & 1u) << (tl & 31u);
+                        if ((tl & 31u) == 31u) { pl[64u + (tl >> 5)] = tlo; pl[64u + TW + (tl >> 5)] = thi; tlo = 0u; thi = 0u; }
+                    }
+                    tl += 1u;
+                }
+                if (w) cost += len < 2u ? 1u : len - (has ? 1u : 0u);                   /* rep_cost */
+            }
+        }
+    }
+    if (tl <= BRX_LANE_TMAX && (tl & 31u) != 0u) { pl[64u + (tl >> 5)] = tlo; pl[64u + TW + (tl >> 5)] = thi; }
+    *tl_out = tl; *cost_out = cost; *odd_out = odd;
+}
+
+template <int U>
+__global__ void __launch_bounds__(64, 4) k_mut_lanes(BrxDev d, RS *rs, MS *msv, PQ *pq, const uint32_t *list, uint32_t n_list, const MutAux aux,
+                                                      const uint8_t *Fbuf, uint32_t *repl, const uint32_t *F2buf, uint32_t *Cbuf,
+                                                      uint4 *sv_a, uint32_t *sv_z, uint2 *tbw_base, uint32_t max_cycles,
+                                                      uint32_t *left_list, uint32_t *left_ctr) {
+    const int lane = lane_id();
+    const brx_error_model &em = d.em;
+    uint2 *tbw = tbw_base + (uint64_t)blockIdx.x * BRX_LANE_TB_UNITS;
+    uint2 *tb_wave = reinterpret_cast<uint2 *>(aux.scr_base + (uint64_t)blockIdx.x * aux.scr_bytes);      /* the wave aligner's store (hard windows) */
+    for (uint32_t grp = blockIdx.x; 64u * grp < n_list; grp += gridDim.x) {
+        const uint32_t idx = 64u * grp + (uint32_t)lane;
+        const uint32_t r = idx < n_list ? list[idx] : 0u;
+        bool active = idx < n_list && rs[r].n != 0u;
+        const uint64_t base = active ? brx_ring_base(rs, r) : 0ull;
+        const uint32_t cap = active ? brx_ring_cap(rs, r) : 1u;
+        const uint32_t n = active ? rs[r].n : 0u;
+        const uint8_t *F = Fbuf + (active ? rs[r].F_off : 0ull);
+        uint32_t *rp = repl + (active ? rs[r].F_off : 0ull);
+        uint32_t *pl = reinterpret_cast<uint32_t *>(aux.winbuf + (uint64_t)r * BRX_WIN_STRIDE + BRX_WIN_PLANES);
+        uint64_t t_last = __builtin_amdgcn_s_memtime();
+        /* at most max_cycles alignment cycles here: a lane walks its window's 1000 columns alone (~1.4 ms a cycle whatever the chip
+           does beside it), and the reads with the most cycles are the batch's critical path -- what is left of them is run to
+           completion by k_mutate_seg, one wave per read (0.2-0.4 ms a cycle), which takes a read over in any state */
+        for (uint32_t cyc = 0; cyc < max_cycles && __ballot(active) != 0ull; ++cyc) {
+            /* ---- the sequential half, every lane its own read ---- */
+            uint32_t outcome = 0u;
+            if (active) outcome = brx_apply_read(d, rs, msv, pq, r, sv_a + base, sv_z + base, cap, repl, Cbuf);
+            if (outcome == (uint32_t)MP_FINISH) active = false;                      /* epilogue: k_mut_epilogue, behind this kernel */
+            /* ---- a ring that ran empty: the wave proposes ahead for that read (rare: the rings are filled for the whole loop) ---- */
+            {
+                unsigned long long hungry = __ballot(active && outcome == (uint32_t)MP_HUNGRY);
+                while (hungry) {
+                    const int l = __ffsll((long long)hungry) - 1;
+                    hungry &= hungry - 1;
+                    const uint32_t rr = wave_bcast_u32(r, l);
+                    const uint64_t bb = wave_bcast_u64(base, l);
+                    const uint32_t cc = wave_bcast_u32(cap, l);
+                    const uint32_t room = cc - 64u * (uint32_t)U;
+                    brx_propose_ahead<U>(d, rr, rs, pq, Fbuf, F2buf, Cbuf, sv_a + bb, sv_z + bb, cc, room < 256u ? room : 256u);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);                                        /* the new entries are read by the reads' own lanes */
+            }
+            /* ---- park: every lane the window of its own read (simulate.py:325-343) ---- */
+            const bool parking = active && outcome == (uint32_t)MP_PARK;
+            uint32_t a = 0, b = 0, tl = 0, cost = 0;
+            bool odd = false;
+            if (parking) {
+                b = n;
+                const uint32_t nal = msv[r].nalign;
+                if (n > BRX_ALIGN_SIZE) {
+                    uint32_t ww[4];
+                    brx_draw4(d.seed, d.first_read + r, BRX_ST_WIN, (uint64_t)nal, ww);
+                    a = (uint32_t)brx_mulhi64(((uint64_t)ww[1] << 32) | ww[0], (uint64_t)n - BRX_ALIGN_SIZE + 1);
+                    b = a + BRX_ALIGN_SIZE;
+                }
+                brx_lane_park(em, F, rp, a, b, pl, &tl, &cost, &odd);
+                MS *o = &msv[r];
+                o->nalign = nal + 1u; o->passes += 1u;
+                o->win_a = a; o->win_b = b; o->tl = tl; o->cost = cost; o->res_ncols = 0; o->res_nmatch = 0;
+                o->phase = tl <= BRX_WIN_TMAX ? 1u : 3u;
+            }
+            const uint32_t ql = b - a;
+            bool easy = false;
+            if (parking && tl <= BRX_WIN_TMAX) {
+                const BrxGeom g = brx_make_geom((int)ql, (int)tl, (int)cost);
+                easy = !odd && g.G == 1 && tl <= BRX_LANE_TMAX && ql > 0 && tl > 0 && (g.dhi - g.dlo) / 32 + 2 <= BRX_LANE_W;
+            }
+            /* a window that does not fit its slot: the whole-read kernel starts the read over (k_mutate) */
+            if (parking && tl > BRX_WIN_TMAX) { aux.req_legacy[atomicAdd(aux.legacy_ctr, 1u)] = r; active = false; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);                                            /* planes and MS of every lane are in place */
+            /* ---- windows the lane aligner does not take: one at a time on the whole wave (k_win_wave's way) ---- */
+            {
+                unsigned long long hard = __ballot(parking && tl <= BRX_WIN_TMAX && !easy);
+                while (hard) {
+                    const int l = __ffsll((long long)hard) - 1;
+                    hard &= hard - 1;
+                    const uint32_t rr = wave_bcast_u32(r, l);
+                    const RS s2 = rs[rr];
+                    const uint32_t a2 = wave_bcast_u32(a, l), b2 = wave_bcast_u32(b, l);
+                    uint8_t *qb = aux.winbuf + (uint64_t)rr * BRX_WIN_STRIDE, *tbuf = qb + BRX_WIN_Q;
+                    uint32_t cost2 = 0; bool odd2 = false;
+                    const uint32_t tl2 = wave_park<false>(em, Fbuf + s2.F_off, repl + s2.F_off, a2, b2, qb, tbuf, BRX_WIN_TMAX, &cost2, &odd2);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_s_waitcnt(0);                                    /* the aligner reads the bytes back */
+                    int ncols = 0, nmatch = 0; bool nospace = false;
+                    const bool ok = brx_wave_align<1>(qb, (int)(b2 - a2), tbuf, (int)tl2, (int)cost2, tb_wave, aux.scr_bytes / 8, nullptr,
+                                                      &ncols, &nmatch, &nospace);
+                    if (lane == 0) {
+                        msv[rr].res_ncols = (uint32_t)ncols; msv[rr].res_nmatch = (uint32_t)nmatch;
+                        if (!ok && !nospace) msv[rr].status |= BRX_RS_BAND;
+                        if (nospace) { atomicOr(&aux.flags[0], 1u); aux.flags[8] = rr; aux.flags[9] = b2 - a2; aux.flags[10] = tl2; aux.flags[11] = cost2; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_s_waitcnt(0);
+                }
+            }
+            /* ---- every other window: one per lane, the band in registers (brx_lanes_align) ---- */
+            if (__ballot(easy) != 0ull) {
+                uint32_t ncols = 0, nmatch = 0; bool ok = false;
+                brx_lanes_align<BRX_LANE_TMAX / 32>(easy, pl, (int)ql, (int)tl, (int)cost, tbw, &ncols, &nmatch, &ok);
+                if (easy) {
+                    msv[r].res_ncols = ncols; msv[r].res_nmatch = nmatch;
+                    if (!ok) msv[r].status |= BRX_RS_BAND;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);                                        /* the store of move codes is written again next cycle */
+            }
+            if (idx < n_list && n != 0u) {                                            /* brx_last_read_cycles: the wave's time, charged to its reads while they run */
+                const uint64_t now = __builtin_amdgcn_s_memtime();
+                if (active || outcome != 0u) aux.clk[(uint64_t)r * 8] += now - t_last;
+                t_last = now;
+            }
+        }
+        /* the reads that are not done: parked with their alignment's result (phase 1) or between two survivors (MP_HUNGRY) */
+        {
+            const uint32_t at = atomicAdd(left_ctr, active ? 1u : 0u);                /* one atomic per wave (the compiler's wave reduction) */
+            if (active) left_list[at] = r;
         }
     }
 }

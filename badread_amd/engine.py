@@ -81,7 +81,7 @@ RS_NOFRAG, RS_TOO_MANY_SEGS, RS_BAND, RS_QMISS, RS_EMPTY = 1, 2, 4, 8, 16
 E_SCRATCH, E_OUTPUT, E_NOFRAG = -3, -4, -5
 STAGE_NAMES = ('plan', 'build', 'mutate', 'scan', 'final', 'emit', 'align1', 'qscore')
 # kernel classes of brx_last_kernel_stats (include/brx.h: BRX_KERN_*), with the names a rocprofv3 kernel trace shows
-KERNEL_NAMES = ('k_plan_*', 'k_build', 'k_mut_apply', 'k_mutate_seg', 'k_win_lane', 'k_win_wave', 'k_fin_join',
+KERNEL_NAMES = ('k_plan_*', 'k_build', 'k_mut_lanes', 'k_mutate_seg', 'k_win_lane', 'k_win_wave', 'k_fin_join',
                 'k_fin_align<1,1,1>', 'k_fin_align<2,2,2>', 'k_fin_align<4,4,4>', 'k_fin_align<16,8,65535>', 'k_fin_qscore',
                 'k_emit+k_recsize', 'k_fin_lanes', 'k_fin_quad<1>', 'k_mut_post')
 

@@ -75,11 +75,15 @@ ROUTES = [
     {},                                                        # defaults: few reads, all head -- every read run to completion in place (k_mutate_seg), windowed store
     {'BRX_TB_WINDOW': -1},                                     # 8-row traceback window: most reads repeat (phase 1)
     {'BRX_TB_WINDOW': 0, 'BRX_WIDE_STREAM': 0},                # full store, no third stream for the widest class
-    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0},                # bulk passes only: k_mut_apply / k_mut_post / k_pass_lists, windows through the lane and the wave kernel
-    {'BRX_TAIL_READS': 6, 'BRX_FIN_HEAD_READS': 9},            # passes, a 6-read in-place tail that takes reads over in any state, final stage in two sets
-    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9},                # two chains: 9 head reads run to completion, 31 in bulk passes with a 6-read tail
+    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0},                # every read in the bulk set: k_mut_fill + ONE launch of k_mut_lanes (a wave keeps its 64 reads to the end)
+    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9},                # two chains: 9 head reads run to completion in place, 31 in k_mut_lanes
+    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANES_CYCLES': 3},   # ... which hands every read over to the in-place kernel after three alignment cycles (parked or hungry)
+    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_LANES_CYCLES': 0},   # ... or keeps them to the end, whatever their cycles
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_TB_WINDOW': -1},   # ... both sets with a retry phase
-    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_WAVES_PER_CU': 2},       # passes; four slab-owning waves per band class reuse their slabs
+    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_MUTATE_PASSES': 1},          # the bulk set through host-driven passes: k_mut_apply / k_mut_post / k_pass_lists / k_win_lane / k_win_wave
+    {'BRX_TAIL_READS': 6, 'BRX_FIN_HEAD_READS': 9, 'BRX_HEAD_READS': 0, 'BRX_MUTATE_PASSES': 1},   # passes, a 6-read in-place tail that takes reads over in any state, final stage in two sets
+    {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_MUTATE_PASSES': 1},          # head chain + passes + tail
+    {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0, 'BRX_WAVES_PER_CU': 2},       # four slab-owning waves per band class reuse their slabs
     {'BRX_TAIL_READS': 6, 'BRX_HEAD_READS': 9, 'BRX_FIN_SPREAD': 0, 'BRX_FIN_LANES': 0},   # the bulk set's band classes one after the other on its own stream, no read aligned by lane
     {'BRX_FIN_LANES': 0, 'BRX_QUAD_MIN_READS': 0},             # narrow bands too go four per wave, a row of 16 lanes each (k_fin_quad), instead of one read per lane
     {'BRX_FIN_LANES': 0, 'BRX_TB_WINDOW': -1, 'BRX_QUAD_MIN_READS': 0},   # ... and the misses of an 8-row traceback window are repeated by k_fin_align with the full store
@@ -101,17 +105,18 @@ def test_pipeline_routes_equal_the_oracle(env, monkeypatch):
     assert H.first_diff(out_h, out_o) < 0, env
     if env.get('BRX_TB_WINDOW') == -1:
         assert eng.window_misses() >= 3                     # the retry phase ran (short reads: few windows are narrower than the band)
-    if env.get('BRX_TAIL_READS') == 0:
+    if env.get('BRX_TAIL_READS') == 0 and env.get('BRX_MUTATE_PASSES'):
         assert eng.mutate_passes() > 3
 
 
-MUTATE_ROUTES = {'default': {}, 'passes': {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0}, 'passes_tail': {'BRX_TAIL_READS': 4, 'BRX_HEAD_READS': 3}}
+MUTATE_ROUTES = {'default': {}, 'lanes': {'BRX_TAIL_READS': 0, 'BRX_HEAD_READS': 0}, 'head_lanes': {'BRX_TAIL_READS': 4, 'BRX_HEAD_READS': 3},
+                 'passes_tail': {'BRX_TAIL_READS': 4, 'BRX_HEAD_READS': 3, 'BRX_MUTATE_PASSES': 1}}
 
 
 @pytest.mark.parametrize('route', sorted(MUTATE_ROUTES))
 def test_pipeline_other_models_and_fragment_kinds(route, monkeypatch):
     """random / ideal models (k = 1), low identity, chimeras, junk and random reads, glitches, N runs and hairpins;
-    through the in-place chain (few reads: all head), the bulk passes, and passes with a head chain and an in-place tail."""
+    through the in-place chain (few reads: all head), k_mut_lanes for every read, a head chain beside it, and the host-driven passes with a tail."""
     for k, v in MUTATE_ROUTES[route].items():
         monkeypatch.setenv(k, str(v))
     pref, _ = H.small_reference(with_n=True)
@@ -136,6 +141,7 @@ def test_bulk_passes_with_nearly_empty_survivor_rings(tail, monkeypatch):
     import emu_engine as EE
     monkeypatch.setenv('BRX_HEAD_READS', '0')
     monkeypatch.setenv('BRX_TAIL_READS', str(tail))
+    monkeypatch.setenv('BRX_MUTATE_PASSES', '1')
     pref, _ = H.small_reference(with_n=True)
     p = SimParams(frag_mean=1400, frag_stdev=900, identity_mode=0, id_max=0.90)
     orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
@@ -149,6 +155,30 @@ def test_bulk_passes_with_nearly_empty_survivor_rings(tail, monkeypatch):
         assert H.first_diff(out_h, out_o) < 0, defines
         passes.append(eng.mutate_passes())
     assert passes[1] > passes[0] > 3, passes
+
+
+@pytest.mark.parametrize('head,cycles', [(0, 0), (3, 0), (0, 2)])
+def test_one_wave_keeps_its_reads_to_the_end_with_rings_that_run_empty(head, cycles, monkeypatch):
+    """k_mut_lanes (brx_passes.h): a wave keeps 64 reads from the first iteration to the last -- apply, park and align by lane, no
+    launch in between -- with every survivor proposed ahead by k_mut_fill.  A build whose rings hold 72 entries whatever the read
+    (n >> 12 + 72 instead of n >> 3 + 128) makes them run empty again and again, so the in-kernel refill (the wave proposes ahead
+    for one read) and the wrap of the ring carry the loop; reads with N runs take the whole-wave aligner for their windows.  Same
+    bytes and statistics as the oracle, with and without a head chain beside it."""
+    import emu_engine as EE
+    monkeypatch.setenv('BRX_HEAD_READS', str(head))
+    monkeypatch.setenv('BRX_TAIL_READS', '0')
+    monkeypatch.setenv('BRX_LANES_CYCLES', str(cycles))              # 0: to the end; 2: the in-place kernel takes the reads over after two cycles
+    pref, _ = H.small_reference(with_n=True)
+    p = SimParams(frag_mean=1600, frag_stdev=1100, identity_mode=0, id_max=0.88)
+    orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
+    out_o, st_o = orc.simulate_batch(91, 40, 70)                  # two waves: 64 reads + 6
+    for defines in ((), ('-DBRX_RING_SHIFT=12', '-DBRX_RING_MIN=72u', '-DBRX_POST_U=1')):
+        eng = H.configure(EE.EmuEngine(1 << 29, defines=defines), pref, 'nanopore2023', 'nanopore2023', p)
+        out_h, st_h = eng.simulate_batch(91, 40, 70)
+        for f in STAT_FIELDS:
+            assert (st_h[f] == st_o[f]).all(), (defines, f)
+        assert H.first_diff(out_h, out_o) < 0, defines
+        assert eng.mutate_passes() <= 3                            # one launch for the bulk set (+ the head chain's, + the in-place takeover)
 
 
 def test_sequence_fragment_golden_vectors_from_the_running_reference():
