@@ -945,8 +945,12 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         uint32_t *left_ctr = mctr + MC_OUT;                 /* block 0: [MC_QUEUE] the tail's queue, [MC_OUT] reads the lane kernel leaves */
         {
             KTIMED(BRX_KERN_MUTATE_SEG, st);
-            hipLaunchKernelGGL((k_mut_lanes<BRX_POST_U>), dim3(std::min(groups, lane_waves)), dim3(64), 0, st, dev, rs, msv, pq, order + n_mh, n_mb, h_aux[0],
-                               Fbuf, repl, F2buf, Cbuf, sv_a, sv_z, lane_tb, c->lanes_cycles ? c->lanes_cycles : 0xFFFFFFFFu, active_a, left_ctr);
+            if (c->profile)
+                hipLaunchKernelGGL((k_mut_lanes<BRX_POST_U, true>), dim3(std::min(groups, lane_waves)), dim3(64), 0, st, dev, rs, msv, pq, order + n_mh, n_mb, h_aux[0],
+                                   Fbuf, repl, F2buf, Cbuf, sv_a, sv_z, lane_tb, c->lanes_cycles ? c->lanes_cycles : 0xFFFFFFFFu, active_a, left_ctr);
+            else
+                hipLaunchKernelGGL((k_mut_lanes<BRX_POST_U, false>), dim3(std::min(groups, lane_waves)), dim3(64), 0, st, dev, rs, msv, pq, order + n_mh, n_mb, h_aux[0],
+                                   Fbuf, repl, F2buf, Cbuf, sv_a, sv_z, lane_tb, c->lanes_cycles ? c->lanes_cycles : 0xFFFFFFFFu, active_a, left_ctr);
         }
         if (c->lanes_cycles) {                             /* what is left of the reads with the most cycles: in place, one wave per read */
             launch_run(st, std::min<uint32_t>(n_mb, 8192u), active_a, left_ctr, mctr, aux_dev);

@@ -445,54 +445,80 @@ __global__ void __launch_bounds__(64, 8) k_mut_fill(BrxDev d, const RS *rs, PQ *
 /* The window [a, b) of read r, parked by ONE lane: query planes pl[0, 32) / pl[32, 64) and target planes pl[64, ...) / pl[64 + TW, ...)
    as wave_park<true> writes them (bit x of word x / 32: symbol x; lo = bit 0 of the code, hi = bit 1), joined length, edit bound
    and "a symbol outside ACGT".  Target planes are written for the first BRX_LANE_TMAX symbols only (a longer window is not the
-   lane aligner's). */
-__device__ inline void brx_lane_park(const brx_error_model &em, const uint8_t *F, const uint32_t *rp, const uint32_t a, const uint32_t b,
-                                     uint32_t *pl, uint32_t *tl_out, uint32_t *cost_out, bool *odd_out) {
+   lane aligner's).
+   32 positions per step: their fragment bytes become a query plane word by multiplication (brx_byte_bits), and the TARGET is that
+   word with the step's replacements spliced in -- the run of untouched positions in front of a replaced one is appended as a bit
+   range, then the replacement's characters.  Which positions are replaced comes from the read's changed map (one word per 32
+   positions, kept by brx_apply_read), so the replacement words and the pool are read for the ~5 % of positions that have one,
+   not for all 1000.  (A first version walked position by position over the bytes and the replacement words: 4 KB of loads and
+   ~20 k instructions per window, a third of the wave's cycle: profiles/r06_lanes_phase_probe.json.) */
+__device__ inline void brx_lane_park(const brx_error_model &em, const uint8_t *__restrict__ F, const uint32_t *__restrict__ rp,
+                                     const uint32_t *__restrict__ cm, const uint32_t a, const uint32_t b,
+                                     uint32_t *__restrict__ pl, uint32_t *tl_out, uint32_t *cost_out, bool *odd_out) {
     constexpr uint32_t TW = BRX_LANE_TMAX / 32;
     uint32_t tl = 0, cost = 0;
     bool odd = false;
-    uint32_t qlo = 0, qhi = 0, tlo = 0, thi = 0;
+    uint32_t tlo = 0, thi = 0;                     /* the target word being filled: bits [0, tl & 31) */
     const uint32_t ql = b - a;
-    for (uint32_t x0 = 0; x0 < ql; x0 += 16u) {
-        const uint32_t p0 = a + x0;
-        const uint32_t nv = ql - x0 < 16u ? ql - x0 : 16u;
-        const BrxB16 f = *reinterpret_cast<const BrxB16 *>(F + p0);              /* F holds 16 bytes behind the read */
-        const uint32_t fw[4] = {f.x, f.y, f.z, f.w};
-        uint32_t rw[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const BrxU4 r4 = *reinterpret_cast<const BrxU4 *>(rp + p0 + 4u * (uint32_t)q);
-            rw[4 * q] = r4.x; rw[4 * q + 1] = r4.y; rw[4 * q + 2] = r4.z; rw[4 * q + 3] = r4.w;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if ((uint32_t)i < nv) {
-                const uint32_t x = x0 + (uint32_t)i;
-                const uint32_t sym = (fw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                const uint32_t w = rw[i];
-                odd |= (sym & 0xFCu) != 0u;
-                qlo |= (sym & 1u) << (x & 31u); qhi |= ((sym >> 1) & 1u) << (x & 31u);
-                if ((x & 31u) == 31u || x + 1u == ql) { pl[x >> 5] = qlo; pl[32u + (x >> 5)] = qhi; qlo = 0u; qhi = 0u; }
-                const uint32_t len = w ? (w >> 24) & 0x7Fu : 1u;
-                bool has = false;
-                for (uint32_t y = 0; y < len; ++y) {
-                    const uint32_t ch = w ? (uint32_t)rep_char(em, w, y) : sym;
-                    if (w) { odd |= ch > 3u; has |= ch == sym; }
-                    if (tl < BRX_LANE_TMAX) {
-                        tlo |= (ch & 1u) << (tl & 31u); thi |= ((ch >> 1) & 1u) << (tl & 31u);
-                        if ((tl & 31u) == 31u) { pl[64u + (tl >> 5)] = tlo; pl[64u + TW + (tl >> 5)] = thi; tlo = 0u; thi = 0u; }
-                    }
-                    tl += 1u;
-                }
-                if (w) cost += len < 2u ? 1u : len - (has ? 1u : 0u);                   /* rep_cost */
+    /* append `nb` (1..32) symbols given as plane bits (zero above nb) to the target */
+    auto append = [&](uint32_t lo, uint32_t hi, uint32_t nb) {
+        const uint32_t sh = tl & 31u;
+        if (tl < BRX_LANE_TMAX) {
+            tlo |= lo << sh; thi |= hi << sh;
+            if (sh + nb >= 32u) {
+                pl[64u + (tl >> 5)] = tlo; pl[64u + TW + (tl >> 5)] = thi;
+                tlo = sh ? lo >> (32u - sh) : 0u; thi = sh ? hi >> (32u - sh) : 0u;
             }
         }
+        tl += nb;
+    };
+    for (uint32_t x0 = 0; x0 < ql; x0 += 32u) {
+        const uint32_t p0 = a + x0;
+        const uint32_t nv = ql - x0 < 32u ? ql - x0 : 32u;
+        const BrxB16 f0 = *reinterpret_cast<const BrxB16 *>(F + p0);             /* F holds 16 bytes behind the read; a window's last step may read 16 more: inside the buffers' slack */
+        const BrxB16 f1 = *reinterpret_cast<const BrxB16 *>(F + p0 + 16u);
+        const uint32_t m0 = cm[p0 >> 5], m1 = cm[(p0 >> 5) + 1u];                 /* the word behind the map is the map of odd symbols: readable */
+        const uint32_t live = nv >= 32u ? 0xFFFFFFFFu : (1u << nv) - 1u;
+        uint32_t changed = (uint32_t)(((((uint64_t)m1) << 32) | (uint64_t)m0) >> (p0 & 31u)) & live;
+        const uint32_t fw[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        uint32_t qlo = 0, qhi = 0, oddbits = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            qlo |= brx_byte_bits(fw[q], 0) << (4 * q); qhi |= brx_byte_bits(fw[q], 1) << (4 * q);
+            oddbits |= (fw[q] & 0xFCFCFCFCu) ? (0xFu << (4 * q)) : 0u;           /* some byte of these four is outside ACGT (which one: below) */
+        }
+        qlo &= live; qhi &= live;
+        if (oddbits & live) {                                                      /* rare: look at the bytes of the live positions */
+            for (uint32_t i = 0; i < nv; ++i) odd |= (((fw[i >> 2] >> (8u * (i & 3u))) & 0xFCu) != 0u);
+        }
+        pl[x0 >> 5] = qlo; pl[32u + (x0 >> 5)] = qhi;
+        uint32_t cur = 0;                                                          /* positions [0, cur) of this step are in the target */
+        while (changed) {
+            const uint32_t c = (uint32_t)__ffs((int)changed) - 1u;
+            changed &= changed - 1u;
+            if (c > cur) { const uint32_t g = c - cur, mk = (1u << g) - 1u; append((qlo >> cur) & mk, (qhi >> cur) & mk, g); }
+            const uint32_t w = rp[p0 + c];
+            const uint32_t sym = (fw[c >> 2] >> (8u * (c & 3u))) & 0xFFu;
+            const uint32_t len = (w >> 24) & 0x7Fu;
+            bool has = false;
+            for (uint32_t y = 0; y < len; ++y) {
+                const uint32_t ch = (uint32_t)rep_char(em, w, y);
+                odd |= ch > 3u; has |= ch == sym;
+                append(ch & 1u, (ch >> 1) & 1u, 1u);
+            }
+            cost += len < 2u ? 1u : len - (has ? 1u : 0u);                          /* rep_cost */
+            cur = c + 1u;
+        }
+        if (nv > cur) { const uint32_t g = nv - cur, mk = g >= 32u ? 0xFFFFFFFFu : (1u << g) - 1u; append((qlo >> cur) & mk, (qhi >> cur) & mk, g); }
     }
     if (tl <= BRX_LANE_TMAX && (tl & 31u) != 0u) { pl[64u + (tl >> 5)] = tlo; pl[64u + TW + (tl >> 5)] = thi; }
     *tl_out = tl; *cost_out = cost; *odd_out = odd;
 }
 
-template <int U>
+/* PROFILE (BRX_PROFILE=1): shader-clock time of the wave per step of the cycle, added to phase[8 r0 + i] of the wave's first read:
+   0 apply   1 refill (rings that ran empty)   2 park   3 whole-wave windows   4 lane aligner   7 cycles run */
+#define BRX_LPH(i) do { if constexpr (PROFILE) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); lph[i] += now_ - lph_t; lph_t = now_; } } while (0)
+template <int U, bool PROFILE = false>
 __global__ void __launch_bounds__(64, 4) k_mut_lanes(BrxDev d, RS *rs, MS *msv, PQ *pq, const uint32_t *list, uint32_t n_list, const MutAux aux,
                                                       const uint8_t *Fbuf, uint32_t *repl, const uint32_t *F2buf, uint32_t *Cbuf,
                                                       uint4 *sv_a, uint32_t *sv_z, uint2 *tbw_base, uint32_t max_cycles,
@@ -512,6 +538,7 @@ __global__ void __launch_bounds__(64, 4) k_mut_lanes(BrxDev d, RS *rs, MS *msv, 
         uint32_t *rp = repl + (active ? rs[r].F_off : 0ull);
         uint32_t *pl = reinterpret_cast<uint32_t *>(aux.winbuf + (uint64_t)r * BRX_WIN_STRIDE + BRX_WIN_PLANES);
         uint64_t t_last = __builtin_amdgcn_s_memtime();
+        uint64_t lph[6] = {0, 0, 0, 0, 0, 0}, lph_t = t_last;
         /* at most max_cycles alignment cycles here: a lane walks its window's 1000 columns alone (~1.4 ms a cycle whatever the chip
            does beside it), and the reads with the most cycles are the batch's critical path -- what is left of them is run to
            completion by k_mutate_seg, one wave per read (0.2-0.4 ms a cycle), which takes a read over in any state */
@@ -520,6 +547,7 @@ __global__ void __launch_bounds__(64, 4) k_mut_lanes(BrxDev d, RS *rs, MS *msv, 
             uint32_t outcome = 0u;
             if (active) outcome = brx_apply_read(d, rs, msv, pq, r, sv_a + base, sv_z + base, cap, repl, Cbuf);
             if (outcome == (uint32_t)MP_FINISH) active = false;                      /* epilogue: k_mut_epilogue, behind this kernel */
+            BRX_LPH(0);
             /* ---- a ring that ran empty: the wave proposes ahead for that read (rare: the rings are filled for the whole loop) ---- */
             {
                 unsigned long long hungry = __ballot(active && outcome == (uint32_t)MP_HUNGRY);
@@ -535,6 +563,7 @@ __global__ void __launch_bounds__(64, 4) k_mut_lanes(BrxDev d, RS *rs, MS *msv, 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_s_waitcnt(0);                                        /* the new entries are read by the reads' own lanes */
             }
+            BRX_LPH(1);
             /* ---- park: every lane the window of its own read (simulate.py:325-343) ---- */
             const bool parking = active && outcome == (uint32_t)MP_PARK;
             uint32_t a = 0, b = 0, tl = 0, cost = 0;
@@ -548,7 +577,7 @@ __global__ void __launch_bounds__(64, 4) k_mut_lanes(BrxDev d, RS *rs, MS *msv, 
                     a = (uint32_t)brx_mulhi64(((uint64_t)ww[1] << 32) | ww[0], (uint64_t)n - BRX_ALIGN_SIZE + 1);
                     b = a + BRX_ALIGN_SIZE;
                 }
-                brx_lane_park(em, F, rp, a, b, pl, &tl, &cost, &odd);
+                brx_lane_park(em, F, rp, Cbuf + (rs[r].F_off >> 4), a, b, pl, &tl, &cost, &odd);
                 MS *o = &msv[r];
                 o->nalign = nal + 1u; o->passes += 1u;
                 o->win_a = a; o->win_b = b; o->tl = tl; o->cost = cost; o->res_ncols = 0; o->res_nmatch = 0;
@@ -564,6 +593,7 @@ __global__ void __launch_bounds__(64, 4) k_mut_lanes(BrxDev d, RS *rs, MS *msv, 
             if (parking && tl > BRX_WIN_TMAX) { aux.req_legacy[atomicAdd(aux.legacy_ctr, 1u)] = r; active = false; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);                                            /* planes and MS of every lane are in place */
+            BRX_LPH(2);
             /* ---- windows the lane aligner does not take: one at a time on the whole wave (k_win_wave's way) ---- */
             {
                 unsigned long long hard = __ballot(parking && tl <= BRX_WIN_TMAX && !easy);
@@ -590,6 +620,7 @@ __global__ void __launch_bounds__(64, 4) k_mut_lanes(BrxDev d, RS *rs, MS *msv, 
                     __builtin_amdgcn_s_waitcnt(0);
                 }
             }
+            BRX_LPH(3);
             /* ---- every other window: one per lane, the band in registers (brx_lanes_align) ---- */
             if (__ballot(easy) != 0ull) {
                 uint32_t ncols = 0, nmatch = 0; bool ok = false;
@@ -601,11 +632,17 @@ __global__ void __launch_bounds__(64, 4) k_mut_lanes(BrxDev d, RS *rs, MS *msv, 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_s_waitcnt(0);                                        /* the store of move codes is written again next cycle */
             }
+            BRX_LPH(4);
+            if constexpr (PROFILE) lph[5] += 1;
             if (idx < n_list && n != 0u) {                                            /* brx_last_read_cycles: the wave's time, charged to its reads while they run */
                 const uint64_t now = __builtin_amdgcn_s_memtime();
                 if (active || outcome != 0u) aux.clk[(uint64_t)r * 8] += now - t_last;
                 t_last = now;
             }
+        }
+        if constexpr (PROFILE) {
+            const uint32_t r0 = wave_bcast_u32(r, 0);
+            if (lane < 6) aux.phase[(uint64_t)r0 * 8 + (lane == 5 ? 7u : (uint32_t)lane)] += lane == 0 ? lph[0] : lane == 1 ? lph[1] : lane == 2 ? lph[2] : lane == 3 ? lph[3] : lane == 4 ? lph[4] : lph[5];
         }
         /* the reads that are not done: parked with their alignment's result (phase 1) or between two survivors (MP_HUNGRY) */
         {
