@@ -194,7 +194,8 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *pf = getenv("BRX_PROFILE"); c->profile = (pf && atoi(pf)) ? 1 : 0; }
     { const char *tw = getenv("BRX_TB_WINDOW"); c->tb_hmul = tw ? atoi(tw) : 2; }
     { const char *v = getenv("BRX_MUTATE_PASSES"); c->mutate_passes_route = v && atoi(v) != 0; }
-    { const char *v = getenv("BRX_LANES_CYCLES"); c->lanes_cycles = v ? (uint32_t)atoi(v) : 64u; }       /* alignment cycles a read spends in k_mut_lanes before the in-place kernel takes it over (0: all) */
+    { const char *v = getenv("BRX_LANES_CYCLES"); c->lanes_cycles = v ? (uint32_t)atoi(v) : 96u; }       /* alignment cycles a read spends in k_mut_lanes before the in-place kernel takes it over (0: all).
+                                                                                                          Measured, configs[3], six batches in flight (profiles/r06s, r06w): 32: 5.26, 48: 5.74, 64: 6.18-6.24, 96: 6.27-6.40, 128: 6.23, all: 5.51 Gbases/s */
     { const char *tr = getenv("BRX_TAIL_READS"); c->tail_reads = tr ? (uint32_t)atoi(tr) : 0xFFFFFFFFu; }   /* unset: an eighth of the batch, at least 1024 */
     c->err[0] = 0;
     *out = c;

@@ -364,23 +364,43 @@ __global__ void __launch_bounds__(64) k_scan_plan(uint32_t n_reads, RS *rs, uint
  * wide as its changes: both the passes a read needs and the class of its final alignment follow the changes, not the length
  * (rounds 1-3 sorted by length: a 22 kb read at 85 % identity -- 130 cycles -- sat among reads that are done after 35). */
 #define BRX_ORDER_BUCKETS 1024
+#define BRX_ORDER_IDBINS 16
+/* Secondary key (round 6): the error rate 1 - target in bins of 2 %.  k_mut_lanes keeps 64 neighbours of this order in one wave and its
+   lane aligner computes, for every lane, as many band blocks per column as the wave's WIDEST window needs -- a window's band is its
+   edit bound, ~1000 (1 - identity): among 64 reads taken as the beta law deals them there is nearly always one below 90 %.  Inside a
+   bucket of equal expected changes (equal work: what the primary key is for) the reads are therefore listed by error rate. */
 __device__ __forceinline__ uint32_t brx_order_key(const RS &s) {
     const double e = (double)s.n * (1.0 - s.target);
     uint32_t key = e > 0.0 ? (uint32_t)(e * (1.0 / 32.0)) : 0u;
     if (s.n == 0) key = 0;
-    return key > BRX_ORDER_BUCKETS - 1u ? BRX_ORDER_BUCKETS - 1u : key;
+    key = key > BRX_ORDER_BUCKETS - 1u ? BRX_ORDER_BUCKETS - 1u : key;
+    const double er = (1.0 - s.target) * 50.0;
+    uint32_t idb = er > 0.0 ? (uint32_t)er : 0u;
+    idb = idb > BRX_ORDER_IDBINS - 1u ? BRX_ORDER_IDBINS - 1u : idb;
+    return key * BRX_ORDER_IDBINS + (s.n == 0 ? 0u : idb);
 }
 __global__ void __launch_bounds__(64) k_order(uint32_t n_reads, const RS *rs, uint32_t *order) {
-    __shared__ uint32_t hist[BRX_ORDER_BUCKETS];
+    constexpr uint32_t NB = BRX_ORDER_BUCKETS * BRX_ORDER_IDBINS;
+    __shared__ uint32_t hist[NB];
+    __shared__ uint32_t part[64];
     const int lane = lane_id();
-    for (int b = lane; b < BRX_ORDER_BUCKETS; b += 64) hist[b] = 0;
+    for (uint32_t b = lane; b < NB; b += 64) hist[b] = 0;
     __syncthreads();
-    for (uint32_t r = lane; r < n_reads; r += 64) atomicAdd(&hist[BRX_ORDER_BUCKETS - 1u - brx_order_key(rs[r])], 1u);
+    for (uint32_t r = lane; r < n_reads; r += 64) atomicAdd(&hist[NB - 1u - brx_order_key(rs[r])], 1u);
     __syncthreads();
-    if (lane == 0) { uint32_t run = 0; for (int b = 0; b < BRX_ORDER_BUCKETS; ++b) { uint32_t c = hist[b]; hist[b] = run; run += c; } }
+    {   /* exclusive prefix over the buckets: every lane its own stretch, then the stretches' starts */
+        constexpr uint32_t PER = NB / 64;
+        uint32_t sum = 0;
+        for (uint32_t b = (uint32_t)lane * PER; b < ((uint32_t)lane + 1u) * PER; ++b) sum += hist[b];
+        part[lane] = sum;
+        __syncthreads();
+        uint32_t run = 0;
+        for (int l = 0; l < lane; ++l) run += part[l];
+        for (uint32_t b = (uint32_t)lane * PER; b < ((uint32_t)lane + 1u) * PER; ++b) { const uint32_t c = hist[b]; hist[b] = run; run += c; }
+    }
     __syncthreads();
     for (uint32_t r = lane; r < n_reads; r += 64) {
-        uint32_t slot = atomicAdd(&hist[BRX_ORDER_BUCKETS - 1u - brx_order_key(rs[r])], 1u);
+        uint32_t slot = atomicAdd(&hist[NB - 1u - brx_order_key(rs[r])], 1u);
         order[slot] = r;
     }
 }

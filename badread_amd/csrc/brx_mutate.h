@@ -539,21 +539,17 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
  */
 __device__ __forceinline__ uint32_t brx_bfe_mask(uint32_t v, int b) { return (uint32_t)((int32_t)(v << (31 - b)) >> 31); }
 
-template <int TW>
-__device__ inline void brx_lanes_align(const bool valid, const uint32_t *__restrict__ pl, const int Q, const int T, const int kb,
-                                       uint2 *__restrict__ tbw, uint32_t *out_ncols, uint32_t *out_nmatch, bool *out_ok) {
-    constexpr int W = BRX_LANE_W;
+/* The forward pass with WB band slots per column, WB a compile-time constant: the slots of a column are one straight-line block,
+   so the independent parts of neighbouring slots (equality masks, stores, the move codes) overlap the carry chain that links them
+   -- a lone wave issues a DEPENDENT instruction every ~8 cycles and an independent one every ~2.  (As one loop with `if (x >= Wb)
+   break` -- rounds 2-5 -- every slot was a basic block of its own.) */
+template <int TW, int WB>
+__device__ __forceinline__ void brx_lanes_forward(const bool valid, const uint32_t *__restrict__ pl, const BrxGeom &g, const int NS, const int T,
+                                                  const int off, const int qb, const int JJ, uint2 *__restrict__ tbw) {
     const int lane = lane_id();
-    const BrxGeom g = brx_make_geom(Q > 0 ? Q : 1, T > 0 ? T : 1, kb);
-    const int NS = (Q + 31) >> 5;
-    const int Wb = (int)wave_max_u32(valid ? (uint32_t)((g.dhi - g.dlo) / 32 + 2) : 0u);      /* slots in use: the widest band of the wave */
-    const int off = (g.dlo - 1) & 31;                       /* jj = j + off; (j + dlo - 1) >> 5 = (jj >> 5) + qb */
-    const int qb = (g.dlo - 1 - off) >> 5;                  /* exact: dlo - 1 - off is a multiple of 32; negative */
-    const int JJ = (int)wave_max_u32(valid ? (uint32_t)(T + off) : 0u);
-
-    uint32_t P[W], M[W], QL[W], QH[W];
+    uint32_t P[WB], M[WB], QL[WB], QH[WB];
 #pragma unroll
-    for (int x = 0; x < W; ++x) {
+    for (int x = 0; x < WB; ++x) {
         P[x] = 0xFFFFFFFFu; M[x] = 0u;                      /* cells below the band grow by +1 per row */
         const bool in = valid && x < NS;
         QL[x] = in ? pl[x] : 0u; QH[x] = in ? pl[BRX_LANE_QW + x] : 0u;
@@ -567,10 +563,10 @@ __device__ inline void brx_lanes_align(const bool valid, const uint32_t *__restr
             const int bq = (jj >> 5) + qb;
             if (valid && bq >= 1) {
 #pragma unroll
-                for (int x = 0; x + 1 < W; ++x) { P[x] = P[x + 1]; M[x] = M[x + 1]; QL[x] = QL[x + 1]; QH[x] = QH[x + 1]; }
-                const int nb = bq + W - 1;
-                P[W - 1] = 0xFFFFFFFFu; M[W - 1] = 0u;
-                QL[W - 1] = nb < NS ? pl[nb] : 0u; QH[W - 1] = nb < NS ? pl[BRX_LANE_QW + nb] : 0u;
+                for (int x = 0; x + 1 < WB; ++x) { P[x] = P[x + 1]; M[x] = M[x + 1]; QL[x] = QL[x + 1]; QH[x] = QH[x + 1]; }
+                const int nb = bq + WB - 1;
+                P[WB - 1] = 0xFFFFFFFFu; M[WB - 1] = 0u;
+                QL[WB - 1] = nb < NS ? pl[nb] : 0u; QH[WB - 1] = nb < NS ? pl[BRX_LANE_QW + nb] : 0u;
                 slo = bq;
             }
             /* ---- target planes of the next 32 trips: bit t = target index (jj - off - 1) + t ---- */
@@ -590,10 +586,9 @@ __device__ inline void brx_lanes_align(const bool valid, const uint32_t *__restr
         const int b = jj & 31;
         const uint32_t m0 = brx_bfe_mask(TLw, b), m1 = brx_bfe_mask(THw, b);
         uint32_t hp = 1u, hm = 0u;                          /* above the band (and above row 1): +1 per column */
-        uint2 *dst = tbw + ((uint64_t)jj * (uint64_t)Wb) * 64u + (uint32_t)lane;
+        uint2 *dst = tbw + ((uint64_t)jj * (uint64_t)WB) * 64u + (uint32_t)lane;
 #pragma unroll
-        for (int x = 0; x < W; ++x) {
-            if (x >= Wb) break;
+        for (int x = 0; x < WB; ++x) {
             const uint32_t pv0 = P[x], mv0 = M[x];
             const uint32_t Eq = ~((QL[x] ^ m0) | (QH[x] ^ m1));
             const uint32_t Xv = Eq | mv0;
@@ -614,6 +609,29 @@ __device__ inline void brx_lanes_align(const bool valid, const uint32_t *__restr
             }
             hp = Ph >> 31; hm = Mh >> 31;                   /* the computed slots are 0 .. hi: every carry that is used was computed */
         }
+    }
+}
+
+template <int TW>
+__device__ inline void brx_lanes_align(const bool valid, const uint32_t *__restrict__ pl, const int Q, const int T, const int kb,
+                                       uint2 *__restrict__ tbw, uint32_t *out_ncols, uint32_t *out_nmatch, bool *out_ok) {
+    constexpr int W = BRX_LANE_W;
+    const int lane = lane_id();
+    const BrxGeom g = brx_make_geom(Q > 0 ? Q : 1, T > 0 ? T : 1, kb);
+    const int NS = (Q + 31) >> 5;
+    int Wb = (int)wave_max_u32(valid ? (uint32_t)((g.dhi - g.dlo) / 32 + 2) : 0u);      /* slots in use: the widest band of the wave */
+    Wb = Wb < 3 ? 3 : Wb;                                   /* (the narrowest instantiation; the store's row width follows) */
+    const int off = (g.dlo - 1) & 31;                       /* jj = j + off; (j + dlo - 1) >> 5 = (jj >> 5) + qb */
+    const int qb = (g.dlo - 1 - off) >> 5;                  /* exact: dlo - 1 - off is a multiple of 32; negative */
+    const int JJ = (int)wave_max_u32(valid ? (uint32_t)(T + off) : 0u);
+    static_assert(W == 8, "one instantiation of the forward pass per band width in use");
+    switch (Wb) {
+        case 3: brx_lanes_forward<TW, 3>(valid, pl, g, NS, T, off, qb, JJ, tbw); break;
+        case 4: brx_lanes_forward<TW, 4>(valid, pl, g, NS, T, off, qb, JJ, tbw); break;
+        case 5: brx_lanes_forward<TW, 5>(valid, pl, g, NS, T, off, qb, JJ, tbw); break;
+        case 6: brx_lanes_forward<TW, 6>(valid, pl, g, NS, T, off, qb, JJ, tbw); break;
+        case 7: brx_lanes_forward<TW, 7>(valid, pl, g, NS, T, off, qb, JJ, tbw); break;
+        default: brx_lanes_forward<TW, 8>(valid, pl, g, NS, T, off, qb, JJ, tbw); break;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);                          /* this wave's stores are visible to its loads below */
