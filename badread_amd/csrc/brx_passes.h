@@ -109,14 +109,23 @@ __device__ inline uint32_t brx_apply_read(const BrxDev &d, const RS *rs, MS *msv
     }
     PQ q = pq[r];
     uint32_t slot = q.head % ring_cap;
+    /* the entry behind the one being applied is in flight while it is: a survivor costs one dependent round trip (its map words),
+       not two */
+    uint4 e_next = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t pz_next = 0u;
+    if (!over && q.head != q.tail) { e_next = ra[slot]; pz_next = rz[slot]; }
     while (!over) {
         if (q.head == q.tail) {
             if (q.next_t >= cap) { outcome = MP_FINISH; loops = cap + 1u; }                               /* :280-281 */
             else { outcome = MP_HUNGRY; t_at = q.next_t; }
             break;
         }
-        const uint4 e = ra[slot];
-        const uint32_t pz = rz[slot];
+        const uint4 e = e_next;
+        const uint32_t pz = pz_next;
+        {
+            const uint32_t ns = slot + 1u == ring_cap ? 0u : slot + 1u;
+            if (q.head + 1u != q.tail) { e_next = ra[ns]; pz_next = rz[ns]; }
+        }
         const uint32_t t = e.x, i0 = e.y, px = e.z, py = e.w;
         /* the changed map of positions i0 .. i0 + k - 1 */
         const uint32_t wi = i0 >> 5, sh = i0 & 31u;
@@ -416,12 +425,12 @@ __device__ __forceinline__ uint64_t brx_ring_base(const RS *rs, uint32_t r) { re
 __device__ __forceinline__ uint32_t brx_ring_cap(const RS *rs, uint32_t r) { return (rs[r].n >> BRX_RING_SHIFT) + BRX_RING_MIN; }
 
 /* Survivors a read is expected to need over its whole loop: every change adds at least target^1.5 errors while the loop runs
-   (simulate.py:321), a survivor applies at least ... most of the time one change; 10 % and a round on top. */
+   (simulate.py:321) and a survivor applies one change or more. */
 __device__ __forceinline__ uint32_t brx_ring_want(uint32_t n, double target) {
     const double need = (double)n * (1.0 - target);
     if (need < 0.5) return 0u;
     const double t = target > 0.05 ? target : 0.05;
-    const double s = 1.1 * need / (t * brx_sqrt(t)) + 64.0;
+    const double s = 0.9 * need / (t * brx_sqrt(t)) + 32.0;              /* (measured: a read takes ~0.8 survivors per error it needs; what is short is refilled in the kernel) */
     return s > 4.0e9 ? 0xF0000000u : (uint32_t)s;
 }
 
