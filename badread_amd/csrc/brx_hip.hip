@@ -1117,6 +1117,14 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         }
         uint64_t all = 0, head_b = 0;
         for (uint32_t i = 0; i < n_reads; ++i) { all += h_rs[h_order[i]].n; if (i < n_head) head_b += h_rs[h_order[i]].n; }
+        if (n_mb && !c->mutate_passes_route && c->lanes_cycles) {      /* the reads k_mut_lanes left to the in-place kernel (statistics only) */
+            uint32_t left = 0;
+            if (hipMemcpy(&left, mctr + MC_OUT, 4, hipMemcpyDeviceToHost) == hipSuccess && left <= n_reads && left) {
+                std::vector<uint32_t> h_left(left);
+                if (hipMemcpy(h_left.data(), active_a, (size_t)left * 4, hipMemcpyDeviceToHost) == hipSuccess)
+                    for (uint32_t x : h_left) if (x < n_reads) tail_bases += h_rs[x].n;
+            }
+        }
         double by_class[4] = {0.0, 0.0, 0.0, 0.0};
         for (const FinalSet &S_ : sets) for (int k_ = 0; k_ < 4; ++k_) by_class[k_] += (double)S_.bases_by_class[k_];
         c->kstat[BRX_KERN_PLAN].bases = c->kstat[BRX_KERN_BUILD].bases = c->kstat[BRX_KERN_FIN_JOIN].bases =

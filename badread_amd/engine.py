@@ -307,10 +307,12 @@ def arena_estimate(n_reads, mean_length, error_rate=None):
     replacement words, read + qualities + ops = 9.5 B per base (round 6: no col_of[]); traceback slabs by the edits per base (35 B per base at
     the 5 % of nanopore2023 defaults up to ~20 GB -- the final align kernels hold at most 2048 / 1024 / 512 / 256 slabs --, ~2 B
     at Q30 reads since the narrow-band class walks its traceback in strips: measured, profiles/r05d: 6.4 GB per 65536-read batch of
-    configs[4] including col_of[]); per-wave window scratch and move-code stores of the mutate stage."""
+    configs[4] including col_of[]); per-wave window scratch and the move-code stores of the mutate stage (one per wave of k_mut_lanes:
+    1016 for a 65 536-read batch); the survivor rings."""
     bases = float(n_reads) * (float(mean_length) + 14.0)
     per_base = 35.0 if error_rate is None else min(35.0, max(3.0, 35.0 * float(error_rate) / 0.05))
-    return int(9.5 * bases + min(per_base * bases, 20e9) + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 512.0) * 6.6e6 + (64 << 20))
+    rings = 2.5 * bases + 2600.0 * n_reads            # survivor rings of k_mut_lanes: 20 B x (n / 8 + 128) entries per read
+    return int(9.5 * bases + rings + min(per_base * bases, 20e9) + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 1024.0) * 6.6e6 + (64 << 20))
 
 
 class HipEngine(EngineBase):
@@ -390,7 +392,13 @@ class HipEngine(EngineBase):
 
     def _ensure_scratch(self, nbytes):
         if self._scratch is None or self._scratch.numel() < nbytes:
+            had = self._scratch is not None and self._scratch.numel() >= (1 << 30)
             self._scratch = None
+            if had:
+                # an arena that grows gives its old block BACK TO THE DRIVER first: torch's caching allocator would keep the 20-40 GB
+                # beside the new block, six engines doing that fill the device, and the runtime then has nothing left for its own
+                # allocations (kernel scratch: HSA_STATUS_ERROR_OUT_OF_RESOURCES, 'Available Free mem : 0 MB' -- profiles/README.md, round 6)
+                self.torch.cuda.empty_cache()
             self._scratch = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
             self._check(self.lib.brx_set_scratch(self.ctx, ctypes.c_void_p(self._scratch.data_ptr()),
                                                  self._scratch.numel()))

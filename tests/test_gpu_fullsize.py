@@ -276,16 +276,18 @@ def test_off_default_parameters_full_batch_equals_the_oracle(tmp_path):
     compare_with_oracle_slices('rough', ref_dir, ROUGH_CHECKED, st, raw, tmp_path, ALL_FIELDS)
 
 
-def test_the_cli_sizes_arena_and_output_for_an_off_default_job(tmp_path):
-    """what a USER of those parameters gets is the CLI's sizing -- HipEngine.presize from the job's identity law
-    and the output buffer from its chimera rate -- not the bench's 40 GB.  A shipped batch through an engine sized that way: no
-    retry, and the same bytes as the engine with the bench's arena gives for the same reads."""
+@pytest.mark.parametrize('wlname,error_rate', [('rough', 0.10), ('human', 0.05), ('hifi', 0.001)])
+def test_the_cli_sizes_arena_and_output_for_the_job(wlname, error_rate, tmp_path):
+    """what a USER gets is the CLI's sizing -- HipEngine.presize from the job's identity law and the output buffer
+    from its chimera rate -- not the bench's 40 GB.  A shipped batch through an engine sized that way: NO retry (an arena that is
+    short is grown and the batch repeated: correct, but six engines growing 20 GB arenas once filled the device -- round 6, the
+    configs[4] job after the survivor rings were added), and the same bytes as the engine with the bench's arena gives."""
     import bench
     from badread_amd.engine import HipEngine
     ref_dir = bench.default_ref_dir()
-    wl = bench.build_workload(io.StringIO(), 'rough', ref_dir)
+    wl = bench.build_workload(io.StringIO(), wlname, ref_dir)
     eng = bench.configure(HipEngine(0, scratch_bytes=1 << 30), wl)
-    eng.presize(SHIPPED_BATCH, 15000.0, 0.10)                              # --identity 85,95,5: ten per cent of errors on average
+    eng.presize(SHIPPED_BATCH, 15000.0, error_rate)                        # e.g. --identity 85,95,5: ten per cent of errors on average
     assert eng.scratch_bytes() <= int(48 * (1 << 30))
     out, st = eng.simulate_batch(SEED, 0, SHIPPED_BATCH)
     digest = (len(out), int(st['seq_len'].sum()), int(st['n_match'].astype(np.int64).sum()))
