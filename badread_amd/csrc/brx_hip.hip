@@ -496,15 +496,16 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_BUILD], st));
 
     /* ---- stages: mutate + final, as TWO CHAINS per batch ------------------------------------------------------
-     * `order` lists the reads longest first.  The first n_head of them (the HEAD set: BRX_HEAD_READS, default 2048)
-     * are the batch's critical path: a 150 kb read is ~300 dependent {mutate segment, window alignment} cycles and
-     * then a final alignment with 8-16 band words per lane.  They run on the side stream from the start: one launch
-     * of k_mutate_seg<true> takes each of them to completion with in-place window alignments, and their final
-     * alignment + qscores follow on that stream as soon as they are done.  The BULK set (everything else) runs
-     * beside them on the caller's stream: passes of {k_mutate_seg<false>, k_win_lane, k_win_wave}, an in-place tail
-     * once few reads are left, then its own final stage.  The chains share nothing but read-only inputs and the
-     * arena's bump allocator (host side), and join before the records are written.  A batch that is small
-     * (n_reads <= BRX_TAIL_READS) or BRX_MUTATE_INLINE=1 is all head.  (Round 1 ran the sets one after the other:
+     * `order` lists the reads by expected changes, most first (and, inside a bucket of equal work, by error rate).  The first
+     * n_head of them (the HEAD set: BRX_HEAD_READS, default 512) are the batch's critical path: a 150 kb read is ~300 dependent
+     * {mutate segment, window alignment} cycles and then a final alignment with 8-16 band words per lane.  They run on the
+     * side stream from the start: one launch of k_mutate_seg takes each of them to completion with in-place window
+     * alignments, and their final alignment + qscores follow on that stream as soon as they are done.  The BULK set
+     * (everything else) runs beside them on the caller's stream: k_mut_fill, ONE launch of k_mut_lanes (a wave keeps 64 reads
+     * through their first BRX_LANES_CYCLES alignment cycles), k_mutate_seg for what is left, k_mut_epilogue -- or, under
+     * BRX_MUTATE_PASSES=1, host-driven passes with an in-place tail -- then its own final stage.  The chains share nothing but
+     * read-only inputs and the arena's bump allocator (host side), and join before the records are written.  A batch that is
+     * small (n_reads <= BRX_TAIL_READS) is all head.  (Round 1 ran the sets one after the other:
      * bulk passes, THEN the in-place tail, THEN all final kernels -- 930 ms per batch with 8 batches in flight, of
      * which 230 ms tail and 270 ms wide-band alignments during which the batch used a few dozen waves.) */
     uint32_t *const h_order = reinterpret_cast<uint32_t *>(c->h_stage + stg_order);      /* pinned: filled by k_copy_words */
@@ -910,7 +911,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         { int rcw_ = wait_stream(c, st, "mutate counters"); if (rcw_) return rcw_; }
     }
     /* reads taken to completion in ONE launch (the head set from the start; the last BRX_TAIL_READS of the bulk set):
-       k_mutate_seg<true>, every read aligning its own windows with a whole wave.  (Rounds 2 and 3 measured three ways of
+       k_mutate_seg, every read aligning its own windows with a whole wave.  (Rounds 2 and 3 measured three ways of
        taking these windows to a cheaper aligner -- workgroups of 8 reads with packed alignments, 8-wave pass kernels, a
        persistent launch with device queues -- and every one lost to this chain on the batch's critical path: DESIGN.md section 7.) */
     auto launch_run = [&](hipStream_t s, uint32_t count, const uint32_t *act_in, const uint32_t *n_in, uint32_t *ctr, const MutAux *aux) {

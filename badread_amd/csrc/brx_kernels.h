@@ -422,7 +422,7 @@ __device__ inline uint32_t ref_code_acgt(const brx_reference &r, const brx_conti
  * number whose digits are in the order error_model.py:135-160 indexes its table by), at word F_off / 16 of F2buf; the word
  * behind the last one says whether the read holds a symbol outside ACGT (then the mutate loop keeps to the bytes).
  * Cbuf (same index) is a bit per base: set when the position has been replaced (repl[p] != 0).  The proposal rounds of
- * k_mutate_seg read k-mers and the changed bits from THESE -- staged in LDS for reads that fit (brx_mutate.h) -- instead of
+ * the proposal rounds read k-mers from THESE, and brx_apply_read / brx_lane_park the changed bits (brx_passes.h), instead of
  * seven byte loads and a 4-byte word at a random position of a 15-60 KB read. */
 __global__ void __launch_bounds__(64) k_build(BrxDev d, const RS *rs, const PSeg *segs, uint8_t *Fbuf, uint32_t *repl,
                                               uint32_t *F2buf, uint32_t *Cbuf) {

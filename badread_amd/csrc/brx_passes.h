@@ -1,5 +1,5 @@
 /*
- * brx_passes.h -- the BULK passes of the mutate loop (/root/reference/badread/simulate.py:272-346), round 6, included by
+ * brx_passes.h -- the mutate loop of the BULK set (/root/reference/badread/simulate.py:272-346), round 6, included by
  * brx_kernels.h behind brx_mutate.h.
  *
  * What the loop looks like from the hardware's side.  An iteration draws a position i, reads the k-mer of the ORIGINAL
@@ -11,26 +11,34 @@
  *
  * Rounds 2-5 ran both halves in one wave per read (k_mutate_seg<false>): 64 proposals, then the survivors one after the other
  * by the wave -- seven of its 64 lanes take part in an application, one lane's worth of double arithmetic decides what follows --
- * with three dependent table loads per round in front of every application.  profiles/r05_pmc_per_kernel.csv: 25.9 % of the
- * path's wave-cycles, issuing in 34 % of them, 16.7 instructions per simulated base.  Here the halves are separate kernels, each
- * shaped for what it does:
+ * with three dependent table loads per round in front of every application, and three to four device-scope atomics per read and
+ * pass on two cache lines for its lists (11.4 ns each, chip-wide: what the kernel really waited for).  Here the loop is cut into
+ * device functions, each shaped for what it does:
  *
- *   k_mut_post   1 wave = 1 read.  (a) What a wave is good at: parking the window of a read whose 25th change has just been
- *                applied (wave_park: 64 lanes x 16 positions, planes by ballot), or the epilogue of a finished read.  (b) PROPOSE
- *                AHEAD: 64 iterations per lane-round, BRX_POST_U rounds per trip with their table loads in flight together; the
- *                survivors are appended, in iteration order, to the read's RING (BRX_SV_CAP entries of 20 bytes) until it holds
- *                BRX_SV_STOCK of them.  No LDS staging, no loop state: the wave holds a handful of registers and many of them
- *                fit a SIMD, so the three dependent loads of a proposal wait beside other waves' instead of in front of the
- *                read's own next step.  A survivor that is not consumed in this pass stays in the ring: nothing is proposed twice.
- *   k_mut_apply  1 LANE = 1 read.  Plain sequential code: take the read's survivors from its ring in order, test the changed
- *                map, write replacement words, update the estimate -- until the 25th change (ask k_mut_post for a window), the end of
- *                the loop (ask for the epilogue) or an empty ring (ask for more: "hungry", the read takes part in the next pass
- *                without an alignment).  A read's map, replacement words and ring are touched by ONE lane, so program order is
- *                all the ordering there is: no fences, no LDS.  64 reads share every instruction the old kernel issued for one.
+ *   brx_propose_ahead   the WAVE, for one read: 64 iterations per lane-round, BRX_POST_U rounds per trip with their table loads in
+ *                       flight together; the survivors are appended, in iteration order, to the read's RING (20 bytes an entry).
+ *                       No loop state.  A survivor that is not consumed stays in the ring: nothing is proposed twice.
+ *   brx_apply_read      one LANE, for its read: plain sequential code -- take the survivors from the ring in order, test the changed
+ *                       map, write replacement words, update the estimate -- until the 25th change (MP_PARK), the end of the loop
+ *                       (MP_FINISH) or an empty ring (MP_HUNGRY).  A read's map, replacement words and ring are touched by ONE
+ *                       lane, so program order is all the ordering there is: no fences, no LDS.
+ *   brx_lane_park       one LANE, for its read: the window's two strings as bit planes, the replacements spliced into the
+ *                       fragment's plane words as bit ranges, guided by the changed map.
+ *   brx_lanes_align     (brx_mutate.h) one LANE per window: band in registers, 2-bit move codes, canonical walk.
  *
- * The pass is then {k_mut_apply, k_mut_post, k_pass_lists, k_win_lane, k_win_wave}.  Results are identical to the sequential
- * loop, and to k_mutate_seg<true> (which still runs the head set and the in-place tail and takes reads over in any state:
- * MS keeps its meaning -- round_loops / surv_lane / j_next name the survivor to resume in).
+ * and two ways of driving them:
+ *
+ *   k_mut_fill + k_mut_lanes (the default)   every survivor a read is expected to need is proposed before the loop starts; then ONE
+ *                       launch in which a wave keeps 64 reads (neighbours in the order by expected changes / error rate) through
+ *                       up to BRX_LANES_CYCLES alignment cycles: apply -> park -> align -> apply ..., no launch, no list, no atomic,
+ *                       no host.  What is left of the reads with the most cycles is run to completion by k_mutate_seg.
+ *   host-driven passes (BRX_MUTATE_PASSES=1)  {k_mut_apply, k_mut_post, k_pass_lists, k_win_lane, k_win_wave} per pass, the windows
+ *                       regrouped by band class between the kernels, an in-place tail of BRX_TAIL_READS reads: the route of the
+ *                       round's first half, kept for the A/B of DESIGN.md section 7 and as a second witness of the takeover
+ *                       (k_mutate_seg picks a read up parked or hungry).
+ *
+ * Results are identical to the sequential loop either way, and to k_mutate_seg (MS keeps its meaning: round_loops / surv_lane /
+ * j_next name the survivor to resume in).
  */
 #ifndef BRX_PASSES_H
 #define BRX_PASSES_H
@@ -51,7 +59,7 @@ static_assert((BRX_SV_CAP & (BRX_SV_CAP - 1u)) == 0u && BRX_SV_CAP >= 64u * BRX_
 struct PQ { uint32_t head, tail, next_t, pad; };
 
 /* MS.phase between the kernels of a pass (0-3 as in brx_mutate.h) */
-enum { MP_HUNGRY = 4,      /* ring empty, no alignment pending: resume at iteration round_loops (k_mutate_seg<true>: a resumed round without blending) */
+enum { MP_HUNGRY = 4,      /* ring empty, no alignment pending: resume at iteration round_loops (k_mutate_seg: a resumed round without blending) */
        MP_PARK = 5,        /* k_mut_apply -> k_mut_post: park the window; surv_lane / j_next say where the loop stopped */
        MP_FINISH = 6 };    /* k_mut_apply -> k_mut_post: the loop is over (round_loops = loop_count), write the epilogue */
 

@@ -236,8 +236,9 @@ int brx_align_batch(brx_ctx *ctx, uint32_t n_pairs,
  * kernels (host work between stages is not included):
  *   PLAN    k_plan_count, k_scan_plan, k_plan_fill (includes one small size read-back)
  *   BUILD   k_build (+ k_copy_frags), k_order
- *   MUTATE  all passes of {k_mutate_seg, k_win_lane, k_win_wave} (+ k_mutate for overflow reads),
- *           including the host round trips between passes; brx_last_mutate_passes() gives the count
+ *   MUTATE  k_mut_fill, k_mut_lanes, k_mutate_seg, k_mut_epilogue (+ k_mutate for overflow reads) -- or, under BRX_MUTATE_PASSES=1,
+ *           all passes of {k_mut_apply, k_mut_post, k_pass_lists, k_win_lane, k_win_wave} including the host round trips between
+ *           them; brx_last_mutate_passes() gives the count of launches / passes
  *   SCAN    k_scan_mut
  *   FINAL   the whole final stage: k_fin_join, then k_fin_align<...> for every band class (two streams) +
  *           k_fin_qscore, one set of launches per scratch chunk (and per phase: brx_last_window_misses)

@@ -47,7 +47,7 @@ def main():
         for name in names:
             bare = name.replace('void ', '')
             # names as badread_amd.engine.KERNEL_NAMES has them (bench.py looks the run's top kernel up by that name)
-            label = ('k_mutate_seg' if bare.startswith('k_mutate_seg<') else 'k_mut_post' if bare.startswith('k_mut_post<') else bare.replace(' ', ''))
+            label = (bare.split('<')[0] if bare.startswith(('k_mutate_seg<', 'k_mut_')) else bare.replace(' ', ''))      # k_mutate_seg, k_mut_lanes, k_mut_fill, k_mut_post ...
             if not label.startswith(('k_mutate_seg', 'k_mut_', 'k_win_lane', 'k_fin_align', 'k_fin_qscore', 'k_fin_quad', 'k_fin_lanes')) or '_Z' in label or label in out:
                 continue
             # few-launches-per-batch kernels: the two batches' full-size launches (k_mutate_seg: head + tail each; the others one or two)
