@@ -183,7 +183,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
        half the waves: 4.62-4.67 with both; round 6 removed its instantiation.  brx_quad.h keeps the words per lane a template
        parameter.) */
     { const char *v = getenv("BRX_FIN_QUAD"); c->fin_quad = v ? (atoi(v) & 1) : 1; }
-    { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 512u; }
+    { const char *hr = getenv("BRX_HEAD_READS"); c->head_reads = hr ? (uint32_t)atoi(hr) : 1024u; }      /* (512 until the lane kernel: 6.33-6.43 against 6.47-6.55 Gbases/s at 1024, three A/B pairs; 768: 6.44, 1536: 6.46 -- profiles/r06aa) */
     { const char *fh = getenv("BRX_FIN_HEAD_READS"); c->fin_head_reads = fh ? (uint32_t)atoi(fh) : 2048u; }
     { const char *ws = getenv("BRX_WIDE_STREAM"); c->wide_stream = ws ? atoi(ws) : 1; }
     /* a context owns exactly three streams besides the caller's: every stream of a context takes a hardware queue, and two idle
@@ -497,7 +497,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
 
     /* ---- stages: mutate + final, as TWO CHAINS per batch ------------------------------------------------------
      * `order` lists the reads by expected changes, most first (and, inside a bucket of equal work, by error rate).  The first
-     * n_head of them (the HEAD set: BRX_HEAD_READS, default 512) are the batch's critical path: a 150 kb read is ~300 dependent
+     * n_head of them (the HEAD set: BRX_HEAD_READS, default 1024) are the batch's critical path: a 150 kb read is ~300 dependent
      * {mutate segment, window alignment} cycles and then a final alignment with 8-16 band words per lane.  They run on the
      * side stream from the start: one launch of k_mutate_seg takes each of them to completion with in-place window
      * alignments, and their final alignment + qscores follow on that stream as soon as they are done.  The BULK set
