@@ -462,7 +462,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *F2buf = (uint32_t *)A.take(((size_t)f_bytes / 16 + 16) * 4);       /* the fragments as 2-bit codes: word F_off / 16 (k_build) */
     uint32_t *Cbuf = (uint32_t *)A.take(((size_t)f_bytes / 16 + 16) * 4);        /* a bit per base: replaced (same index) */
     const uint32_t side_waves = std::min<uint32_t>(n_reads, 4096u);                 /* wave-level window aligner / legacy */
-    const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, c->mutate_passes_route ? 512u : 1024u);   /* lane-level window aligner: one 6.4 MB store of move codes per wave */
+    const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, c->mutate_passes_route ? 512u : (uint32_t)BRX_LANES_MAX_WAVES);   /* lane-level window aligner: one 6.4 MB store of move codes per wave */
     uint8_t *win = (uint8_t *)A.take((size_t)(side_waves + 1) * c->win_bytes);      /* one slot per wave */
     MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
     uint32_t *mctr = (uint32_t *)A.take(8 * MC_WORDS * sizeof(uint32_t));   /* pass counters 0/1, 2 first bulk input, 3 bulk legacy, 4 head input, 5 head legacy, 6 head pass */

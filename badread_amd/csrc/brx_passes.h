@@ -425,6 +425,9 @@ __global__ void __launch_bounds__(64) k_pass_lists(const MS *msv, const uint32_t
  * Ring of read r: entries [ring_base(r), + ring_cap(r)) of sv_a / sv_z with ring_base = F_off / 8 + 128 r, ring_cap = n / 8 + 128:
  * the fragment offsets are a prefix sum over the reads already, so no layout pass is needed; n / 8 entries hold every survivor of a
  * read down to ~88 % identity, a rougher read wraps around and is refilled. */
+#ifndef BRX_LANES_MAX_WAVES
+#define BRX_LANES_MAX_WAVES 1024u                        /* waves of one k_mut_lanes launch (a 6.6 MB store of move codes each); a bigger batch's groups of 64 reads follow each other in a wave */
+#endif
 #ifndef BRX_RING_SHIFT
 #define BRX_RING_SHIFT 3                                 /* ring entries per read: n >> BRX_RING_SHIFT ... */
 #define BRX_RING_MIN 128u                                /* ... + BRX_RING_MIN (at least a trip's 64 U; the tests build tiny rings) */

@@ -172,7 +172,8 @@ def test_one_wave_keeps_its_reads_to_the_end_with_rings_that_run_empty(head, cyc
     p = SimParams(frag_mean=1600, frag_stdev=1100, identity_mode=0, id_max=0.88)
     orc = H.configure(H.oracle_engine(), pref, 'nanopore2023', 'nanopore2023', p)
     out_o, st_o = orc.simulate_batch(91, 40, 70)                  # two waves: 64 reads + 6
-    for defines in ((), ('-DBRX_RING_SHIFT=12', '-DBRX_RING_MIN=72u', '-DBRX_POST_U=1')):
+    # (the second build also runs both groups of 64 reads on ONE wave, one after the other: a batch beyond 1024 x 64 reads does that)
+    for defines in ((), ('-DBRX_RING_SHIFT=12', '-DBRX_RING_MIN=72u', '-DBRX_POST_U=1', '-DBRX_LANES_MAX_WAVES=1u')):
         eng = H.configure(EE.EmuEngine(1 << 29, defines=defines), pref, 'nanopore2023', 'nanopore2023', p)
         out_h, st_h = eng.simulate_batch(91, 40, 70)
         for f in STAT_FIELDS:
