@@ -59,6 +59,7 @@ struct brx_ctx {
     int fin_spread;                      /* BRX_FIN_SPREAD (default 1) */
     uint32_t quad_min_reads;             /* BRX_QUAD_MIN_READS (default 4096): a set with fewer four-per-wave reads aligns them on whole waves */
     int fin_lanes;                       /* BRX_FIN_LANES (default 1): narrow-band final alignments one read per lane (k_fin_lanes) */
+    uint32_t lanes_min_reads;            /* BRX_LANES_MIN_READS (default 2048): a set with fewer by-lane reads aligns them on whole waves */
     int fin_quad;                        /* BRX_FIN_QUAD (default 1): final alignments of one-word bands four per wave (k_fin_quad<1>) */
     hipStream_t side;            /* second stream: the wide-band align kernels run beside the narrow one (one stream for all
                                     three wide classes: a stream per class measured 30 % slower, r01d) */
@@ -178,6 +179,7 @@ extern "C" int brx_create(int device_id, brx_ctx **out) {
     { const char *v = getenv("BRX_FIN_SPREAD"); c->fin_spread = v ? atoi(v) : 1; }
     { const char *v = getenv("BRX_QUAD_MIN_READS"); c->quad_min_reads = v ? (uint32_t)atoi(v) : 4096u; }
     { const char *v = getenv("BRX_FIN_LANES"); c->fin_lanes = v ? atoi(v) : 1; }
+    { const char *v = getenv("BRX_LANES_MIN_READS"); c->lanes_min_reads = v ? (uint32_t)atoi(v) : 2048u; }
     /* the one-word class.  Measured on configs[3] (profiles/r05a): 5.30 Gbases/s with it against 5.22 without.  (A two-word class --
        14-26 superblocks of 32 rows as 7-13 of 64 -- cost 20.6 instructions per read column where the whole-wave kernel costs 25, on
        half the waves: 4.62-4.67 with both; round 6 removed its instantiation.  brx_quad.h keeps the words per lane a template
@@ -582,9 +584,18 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         /* Four per wave pays when the class fills the chip: a group is as slow as its longest read plus four tracebacks, and a
            class of a few hundred groups is all tail.  configs[4] (1509 such reads beside 63 435 by lane) lost 4 % to it
            (17.2 against 17.9 Gbases/s, profiles/r05g); below BRX_QUAD_MIN_READS the set's reads keep to whole waves. */
-        uint32_t n_quad_flagged = 0;
-        for (uint32_t i = S.b; i < S.e; ++i) { const RS &r = h_rs[h_order[i]]; n_quad_flagged += (r.n && (r.klass & BRX_KL_QUAD)) ? 1u : 0u; }
+        uint32_t n_quad_flagged = 0, n_lanes_flagged = 0;
+        for (uint32_t i = S.b; i < S.e; ++i) {
+            const RS &r = h_rs[h_order[i]];
+            n_quad_flagged += (r.n && (r.klass & BRX_KL_QUAD)) ? 1u : 0u; n_lanes_flagged += (r.n && (r.klass & BRX_KL_LANES)) ? 1u : 0u;
+        }
         const bool use_quad = n_quad_flagged >= c->quad_min_reads;
+        /* The same for one read per lane: a wave is as slow as its longest read, computed by ONE lane.  configs[4]'s head set (the 1024
+           reads with the most expected changes: its longest, 100-200 kb) holds a few hundred reads whose band fits the lane aligner --
+           a handful of waves that run a 200 kb alignment lane-serially while the chip waits for the set (k_fin_lanes 197 -> 278 ms
+           per batch, 18.7 -> 15.6 Gbases/s when the head grew from 512 reads, none of which qualified, to 1024).  Below
+           BRX_LANES_MIN_READS a set's reads keep to whole waves (k_fin_align reads klass's band words: the flag is only a route). */
+        const bool use_lanes = n_lanes_flagged >= c->lanes_min_reads;
         for (uint32_t i = S.b; i < S.e; ++i) {
             const RS &r = h_rs[h_order[i]];
             const uint64_t col_units = 0;      /* (rounds 1-5: col_of[], 4 bytes per read base, for k_fin_qscore -- 4 GB of a human batch's arena; round 6 scores by column) */
@@ -596,7 +607,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             const uint64_t raw_cols = ((uint64_t)r.m * 4 + 7) / 8 + 2;
             const uint64_t u = (phase == 1 ? brx_final_units(r.m, r.n, r.ub, 0, &too_wide) : r.units) - raw_cols;     /* the aligner's share */
             const uint32_t kl = r.klass & 0xFFFFu;
-            if ((r.klass & BRX_KL_LANES) && phase == 0) {      /* no windowed store: a repeat means the lane aligner failed; k_fin_align takes the read then (the flag is cleared) */
+            if ((r.klass & BRX_KL_LANES) && phase == 0 && use_lanes) {      /* no windowed store: a repeat means the lane aligner failed; k_fin_align takes the read then (the flag is cleared) */
                 cls_list[4].push_back(h_order[i]);
                 cls_units[4].push_back(((uint64_t)r.n << 8) | (uint64_t)brx_finl_blocks(r.m, r.n, r.ub));     /* sorted by fragment length below; units per group follow */
                 continue;
@@ -868,11 +879,14 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         uint32_t n_quad_set = 0;
         for (uint32_t i = S.b; i < S.e; ++i) { const RS &r = h_rs[h_order[i]]; n_quad_set += (r.n && (r.klass & BRX_KL_QUAD)) ? 1u : 0u; }
         const bool quad_on = n_quad_set >= c->quad_min_reads;          /* as launch_final_phase decides */
+        uint32_t n_lanes_set = 0;
+        for (uint32_t i = S.b; i < S.e; ++i) { const RS &r = h_rs[h_order[i]]; n_lanes_set += (r.n && (r.klass & BRX_KL_LANES)) ? 1u : 0u; }
+        const bool lanes_on = n_lanes_set >= c->lanes_min_reads;
         for (uint32_t i = S.b; i < S.e; ++i) {
             const RS &r = h_rs[h_order[i]];
             if (!r.n) continue;
             const uint32_t kl = r.klass & 0xFFFFu;
-            S.bases_by_class[(r.klass & BRX_KL_LANES) ? 5 : ((r.klass & BRX_KL_QUAD) && quad_on) ? (brx_quad_words(r.m, r.n, r.ub) == 2 ? 7 : 6) : kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3] += r.n;
+            S.bases_by_class[((r.klass & BRX_KL_LANES) && lanes_on) ? 5 : ((r.klass & BRX_KL_QUAD) && quad_on) ? (brx_quad_words(r.m, r.n, r.ub) == 2 ? 7 : 6) : kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3] += r.n;
             S.bases_by_class[4] += r.n;
         }
         return launch_final_phase(S, 0);

@@ -9,6 +9,12 @@ for p in (REPO, os.path.join(REPO, 'oracle'), os.path.join(REPO, 'tests')):
         sys.path.insert(0, p)
 
 
+# A set of the final stage with fewer than BRX_LANES_MIN_READS (2048) reads for the by-lane aligner keeps them on whole waves: the few dozen
+# reads of a test case would never reach k_fin_lanes.  The suite runs with the rule off; the full-size tests (tests/test_gpu_fullsize.py)
+# take the variable away again and run the shipped default.
+os.environ.setdefault('BRX_LANES_MIN_READS', '0')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -88,6 +88,7 @@ ROUTES = [
     {'BRX_FIN_LANES': 0, 'BRX_QUAD_MIN_READS': 0},             # narrow bands too go four per wave, a row of 16 lanes each (k_fin_quad), instead of one read per lane
     {'BRX_FIN_LANES': 0, 'BRX_TB_WINDOW': -1, 'BRX_QUAD_MIN_READS': 0},   # ... and the misses of an 8-row traceback window are repeated by k_fin_align with the full store
     {'BRX_FIN_QUAD': 0, 'BRX_FIN_LANES': 0},                   # every final alignment on a whole wave
+    {'BRX_LANES_MIN_READS': 2048, 'BRX_TB_WINDOW': -1},        # the shipped rule: a set with few by-lane reads aligns them on whole waves (flag set, route not taken), with a retry phase
 ]
 
 

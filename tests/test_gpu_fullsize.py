@@ -66,6 +66,12 @@ ALL_FIELDS = ('status', 'frag_len', 'seq_len', 'n_cols', 'n_match', 'padded_len'
               'rec_len', 'target_identity', 'qerr_sum')
 
 
+@pytest.fixture(autouse=True)
+def shipped_final_stage_rules(monkeypatch):
+    """tests/conftest.py runs the suite with BRX_LANES_MIN_READS=0 (small sets reach k_fin_lanes); full batches run the shipped default."""
+    monkeypatch.delenv('BRX_LANES_MIN_READS', raising=False)
+
+
 @pytest.fixture(scope='module')
 def workload():
     import bench
