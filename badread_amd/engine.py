@@ -634,14 +634,17 @@ class HipEngine(EngineBase):
             nb = len(block_off) - 1
             keep = torch.from_numpy(block_off.view(np.int64).copy()).to(self.device)
             d_off = ctypes.c_void_p(keep.data_ptr())
-        scratch = torch.empty(int(self.lib.brx_gzip_device_scratch(n, nb)) + 8, dtype=torch.uint8, device=self.device)
+        # capacities in steps of 64 MB: a batch's size differs from the last one's by a few MB, and torch's allocator keeps a cached block
+        # that is too small for the next request beside the new one (simulate._BatchPool._copy_of: what that crept up to over a 94-batch job)
+        step = lambda b: b if b <= (1 << 24) else -(-b // (1 << 26)) * (1 << 26)
+        scratch = torch.empty(step(int(self.lib.brx_gzip_device_scratch(n, nb)) + 8), dtype=torch.uint8, device=self.device)
         blocks = nb or -(-n // 65536)
         # FASTQ packs to about half; the worst case (brx_gzip_device_bound: 15 bits per byte) is only allocated when the
         # library asks for it
         cap = min(int(0.7 * n) + 200 * blocks + 4096, int(self.lib.brx_gzip_device_bound(n, nb)) + 8)
         got = ctypes.c_size_t(0)
         for _ in range(2):
-            out = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            out = torch.empty(step(cap), dtype=torch.uint8, device=self.device)
             rc = self.lib.brx_gzip_device(self.ctx, ctypes.c_void_p(data.data_ptr()), n, d_off, nb, ctypes.c_void_p(out.data_ptr()), out.numel(),
                                           ctypes.c_void_p(scratch.data_ptr()), scratch.numel(), ctypes.byref(got), self._stream())
             if rc != E_OUTPUT:

@@ -577,6 +577,24 @@ class _BatchPool(object):
             n -= 1
         return n
 
+    COPY_STEP = 1 << 28
+
+    @classmethod
+    def _copy_of(cls, torch, out):
+        """The batch's bytes out of the engine's buffer, in a block whose CAPACITY is a multiple of 256 MB.  A plain clone() asks
+        torch's caching allocator for the batch's exact size -- 2.05-2.10 GB, a different one every time -- and a cached block that is
+        a few MB short serves nobody: it stays cached (per stream) and a new one is mapped.  Over the 94 batches of the 30x job
+        the cache crept through the 24 GB this driver leaves to the runtime, and a queue that needed its private segment then
+        died with HSA_STATUS_ERROR_OUT_OF_RESOURCES at 88 % of the job (`Available Free mem : 0 MB`; no allocation of ours had
+        failed).  With the capacity in steps every freed block fits the next batch."""
+        n = int(out.numel())
+        if n <= (1 << 24):
+            return out.clone()
+        cap = -(-n // cls.COPY_STEP) * cls.COPY_STEP
+        buf = torch.empty(cap, dtype=torch.uint8, device=out.device)
+        buf[:n].copy_(out)
+        return buf[:n]
+
     def submit(self, seed, first, n_mine, pack=False):
         self.submitted += 1
         while self.started < min(self.submitted - 1, len(self.makers)):      # the k-th batch in the pipeline is what clone k - 1 is for
@@ -610,7 +628,7 @@ class _BatchPool(object):
                             nbytes = int(stats['rec_off'][live[-1]] + stats['rec_len'][live[-1]])
                             blocks = fastq_blocks(stats['rec_off'], stats['rec_len'], stats['seq_len'], nbytes)
                             packed = (nbytes, eng.gzip_device(out[:nbytes], blocks))      # a new tensor, made on this batch's stream
-                    out = out.clone() if packed is None else None          # the engine's buffer is free again; the copy runs on this batch's stream ...
+                    out = self._copy_of(torch, out) if packed is None else None   # the engine's buffer is free again; the copy runs on this batch's stream ...
                     stream.synchronize()                     # ... and is complete before the engine is handed to the next batch
                     return (out, stats) if not self.device_gzip else (out, stats, packed)
             finally:
@@ -831,6 +849,14 @@ def run_batches(engine, seed, target_size, mean_length, write, output, shard=Non
         for _, fut, *_ in pending:          # speculative batches past the stopping read
             try:
                 fut.result()
+            except Exception:
+                pass
+        if getattr(getattr(engine, 'device', None), 'type', '') == 'cuda':       # what the device looked like when the last batch was through (BRX_DRIVER_TIMING)
+            try:
+                free_b, _total_b = torch.cuda.mem_get_info(engine.device)
+                timing['device_free_gb_at_end'] = free_b / float(1 << 30)
+                timing['torch_reserved_gb_at_end'] = torch.cuda.memory_reserved(engine.device) / float(1 << 30)
+                timing['torch_allocated_gb_at_end'] = torch.cuda.memory_allocated(engine.device) / float(1 << 30)
             except Exception:
                 pass
         t0 = time.perf_counter()
