@@ -588,7 +588,7 @@ class _BatchPool(object):
         died with HSA_STATUS_ERROR_OUT_OF_RESOURCES at 88 % of the job (`Available Free mem : 0 MB`; no allocation of ours had
         failed).  With the capacity in steps every freed block fits the next batch."""
         n = int(out.numel())
-        if n <= (1 << 24):
+        if n <= cls.COPY_STEP // 16:
             return out.clone()
         cap = -(-n // cls.COPY_STEP) * cls.COPY_STEP
         buf = torch.empty(cap, dtype=torch.uint8, device=out.device)

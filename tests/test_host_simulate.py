@@ -382,3 +382,21 @@ def test_batches_in_flight_follow_the_free_device_memory(monkeypatch):
     monkeypatch.setenv('BRX_DRIVER_RESERVE_GB', '0')
     t.cuda = FakeCuda(229 * GB)
     assert fit(t, FakeEngine(), 6, 2 * GB) == 6
+
+
+def test_device_copies_of_a_batch_come_in_size_steps(monkeypatch):
+    """simulate._BatchPool._copy_of: the bytes of a finished batch leave the engine's buffer in a block whose capacity is a multiple of
+    COPY_STEP, so that torch's caching allocator can hand a freed block to the next batch (exact sizes -- 2.05-2.10 GB, never the same twice
+    -- made the cache creep until the 30x job died with HSA_STATUS_ERROR_OUT_OF_RESOURCES at 88 %).  The bytes are those of the source."""
+    import torch
+    from badread_amd.simulate import _BatchPool
+    monkeypatch.setattr(_BatchPool, 'COPY_STEP', 1 << 12)
+    caps = set()
+    for n in (4097, 5000, 8191, 8192):
+        src = torch.arange(n, dtype=torch.int64).to(torch.uint8)
+        got = _BatchPool._copy_of(torch, src)
+        assert got.numel() == n and bool((got == src).all())
+        caps.add(got.untyped_storage().nbytes())
+    assert caps == {8192}
+    small = torch.arange(100, dtype=torch.uint8)
+    assert _BatchPool._copy_of(torch, small).untyped_storage().nbytes() == 100      # small batches: a plain clone
