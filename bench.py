@@ -65,7 +65,7 @@ for _p in (REPO, os.path.join(REPO, 'tools')):
 
 ALGO_BYTES_PER_BASE = 2.26          # 0.25 B packed reference read + 2 B FASTQ written + header share
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
-SCRATCH_GB_DEFAULT = 40.0           # scratch arena per in-flight device batch (tests/test_gpu_fullsize.py runs the shipped geometry with it)
+SCRATCH_GB_DEFAULT = 32.0           # scratch arena per in-flight device batch (tests/test_gpu_fullsize.py runs the shipped geometry with it); 40 until the mutate stage's buffers and the bulk set's slabs shared their room (6.58 at 40, 32 and 28 GiB)
 VALU_PEAK_PER_S = 6.56e11           # wave64 32-bit integer VALU instructions/s, chip-wide, MEASURED (profiles/valu_rate.json, tools/native/valu_bench.hip):
                                     # 4 cycles per instruction per SIMD -- half of what the 2-cycle v_fma_f32 rate of MI355X_MICROARCH.md would give
 VALU_PEAK_GUIDE_PER_S = 256 * 4 * 2.4e9 / 2    # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 2.4 GHz, one wave64 VALU instruction per 2 cycles = 1.229e12
