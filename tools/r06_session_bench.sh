@@ -7,7 +7,7 @@ sleep 20      # as tools/cli_30x.sh: the driver clears the memory the runs above
 timeout 600 python bench.py --scaling strong --cpu-seconds 0 2>> gpurun_out/r06_bench.err | grep '^{' > gpurun_out/r06_bench_strong_n1.json
 sleep 20
 BRX_DEVICE=0 BRX_DIST_BACKEND=gloo timeout 900 python bench.py --scaling strong --gpus 2 --streams 3 --reads-per-step 196608 --cpu-seconds 0 2>> gpurun_out/r06_bench.err | grep '^{' > gpurun_out/r06_bench_strong_n2_one_gpu.json
-bash tools/cli_30x.sh 30x 2>&1 | head -1 | cut -c1-600
+for i in 1 2 3; do bash tools/cli_30x.sh 30x 2>&1 | head -1 | cut -c1-600; cp gpurun_out/r06_cli_30x.json gpurun_out/r06_cli_30x_run$i.json; done
 bash tools/cli_30x.sh 30x "--error_model pacbio2021 --qscore_model pacbio2021 --identity 30,3" 2>&1 | head -1 | cut -c1-600
 bash tools/cli_30x.sh 30x "--gzip-device" 2>&1 | head -1 | cut -c1-600
 python -c "
