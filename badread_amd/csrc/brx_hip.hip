@@ -98,6 +98,10 @@ static bool brx_debug() { static int v = -1; if (v < 0) { const char *e = getenv
  * the per-wave window scratch: 11.9 GB of a 65 536-read batch of configs[3] -- and release_top() hands that region back when that chain
  * is done, so that the bulk set's traceback slabs (13 GB, allocated after it) lie over it: the arena holds the larger of the two, not
  * their sum (40 -> 30 GB per batch in flight; VERDICT r5 #5 asked for <= 30). */
+#ifndef BRX_GIANT_UNITS
+#define BRX_GIANT_UNITS ((uint64_t)64 << 17)       /* launch_final_phase: a store of the widest band class above this is a class of its own (a test build sets it low) */
+#endif
+
 struct Arena {
     uint8_t *base; size_t cap; size_t used; size_t top;
     void *take(size_t bytes) {
@@ -589,8 +593,15 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
      * (Rounds 1-5 kept col_of[] -- 4 bytes per read base for k_fin_qscore -- per read in front of the slabs; round 6 scores by column.) */
     auto launch_final_phase = [&](FinalSet &S, int phase) -> int {
         const uint32_t ns = S.e - S.b;
-        constexpr int NCLS = 7;                     /* [4]: the narrow-band class (k_fin_lanes), its units are per GROUP of 64 reads; [5], [6]: four
-                                                       reads per wave with one / two words per lane (k_fin_quad), units per GROUP of 4 */
+        constexpr int NCLS = 8;                     /* [4]: the narrow-band class (k_fin_lanes), its units are per GROUP of 64 reads; [5], [6]: four
+                                                       reads per wave with one / two words per lane (k_fin_quad), units per GROUP of 4;
+                                                       [7]: the widest class's reads whose store is above BRX_GIANT_UNITS (below) */
+        /* A wave's slab holds the largest store it can meet: wave w of a class the w-th largest.  The widest class of a batch at
+           --identity 85,95,5 --chimeras 25 holds a few reads whose store is GBs (a 300 kb chimera at 75 %: the memory-resident path
+           keeps every cell) beside thousands of 10 MB: with the giants at the head of the class's queue, W waves needed the W largest
+           stores, the set's share held two or three of them, and 400 Mbases of a batch ran on two or three waves -- 46.6 s of a 48 s
+           batch.  The giants are a class of their own (same kernel, own queue, own few slabs); the others keep their 256 waves. */
+        /* BRX_GIANT_UNITS (file scope): 64 MB in 8-byte units, above any windowed store of configs[3] (58 MB: 150 kb at 87 %) */
         std::vector<uint32_t> cls_list[NCLS];
         std::vector<uint64_t> cls_units[NCLS];
         uint64_t col_total = 0;
@@ -632,7 +643,8 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 cls_units[kq].push_back(brx_align_units(gq));       /* sorted by the read's own store below; units per group follow */
                 continue;
             }
-            const int k = kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3;
+            int k = kl <= 1 ? 0 : kl == 2 ? 1 : kl == 4 ? 2 : 3;
+            if (k == 3 && ((u + 31) & ~31ull) > BRX_GIANT_UNITS) k = 7;
             cls_list[k].push_back(h_order[i]);
             cls_units[k].push_back((u + 31) & ~31ull);
         }
@@ -644,7 +656,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         const uint32_t limit[NCLS] = {(uint32_t)c->n_cu * std::max(wpc / 2u, 1u), (uint32_t)c->n_cu * std::max(wpc / 4u, 1u),
                                       (uint32_t)c->n_cu * std::max(wpc / 8u, 1u), (uint32_t)c->n_cu * std::max(wpc / 16u, 1u),
                                       (uint32_t)c->n_cu * std::max(wpc / 4u, 1u), (uint32_t)c->n_cu * std::max(wpc / 4u, 1u),
-                                      (uint32_t)c->n_cu * std::max(wpc / 4u, 1u)};
+                                      (uint32_t)c->n_cu * std::max(wpc / 4u, 1u), 16u};
         uint32_t grid[NCLS];
         std::vector<uint64_t> sufmax[NCLS];
         for (int k = 0; k < NCLS; ++k) {
@@ -666,7 +678,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
                 }
                 cls_units[4].swap(gu);
             }
-            if (k >= 5) {                             /* groups of four reads: rows for the longest of them, slots for the widest window */
+            if (k == 5 || k == 6) {                   /* groups of four reads: rows for the longest of them, slots for the widest window */
                 const size_t ng = (cls_list[k].size() + 3) / 4;
                 std::vector<uint64_t> gu(ng);
                 for (size_t gidx = 0; gidx < ng; ++gidx) {
@@ -717,9 +729,9 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
            grids), the room is what counts -- a head set of --identity 85,95,5 --chimeras 25 holds reads whose store alone is GBs (a
            300 kb chimera at 75 %: the memory-resident wide path keeps every cell) */
         if (need() > left && need() <= room_now) left = (size_t)need();
-        DBG("final set %d phase %d: %u reads, classes %zu/%zu/%zu/%zu + %zu by lane + %zu/%zu four per wave, slabs %u/%u/%u/%u + %u + %u/%u, need %.2f GB, left %.2f GB, arena used %.2f GB", S.id, phase, ns,
-            cls_list[0].size(), cls_list[1].size(), cls_list[2].size(), cls_list[3].size(), cls_list[4].size(), cls_list[5].size(), cls_list[6].size(),
-            grid[0], grid[1], grid[2], grid[3], grid[4], grid[5], grid[6], (double)need() / 1e9, (double)left / 1e9, (double)A.used / 1e9);
+        DBG("final set %d phase %d: %u reads, classes %zu/%zu/%zu/%zu(+%zu giant) + %zu by lane + %zu/%zu four per wave, slabs %u/%u/%u/%u(+%u) + %u + %u/%u, need %.2f GB, left %.2f GB, arena used %.2f GB", S.id, phase, ns,
+            cls_list[0].size(), cls_list[1].size(), cls_list[2].size(), cls_list[3].size(), cls_list[7].size(), cls_list[4].size(), cls_list[5].size(), cls_list[6].size(),
+            grid[0], grid[1], grid[2], grid[3], grid[7], grid[4], grid[5], grid[6], (double)need() / 1e9, (double)left / 1e9, (double)A.used / 1e9);
         if (need() > left) return scratch_short(c, c->scratch_bytes + (size_t)(need() - left) + ((size_t)1 << 28));
         uint8_t *region = c->scratch + at;
         if (phase == 0) { S.tb_at = at; S.tb_cap = (size_t)need(); S.col_bytes = (size_t)col_total * 8; (void)A.take(S.tb_cap); }
@@ -758,7 +770,7 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
         uint32_t *cq = counters + 16 + 32 * (((size_t)S.id * 2 + (size_t)phase));      /* queue heads of this set and phase: [0..7] four 64-bit class counters, [8]..[11], [14] qscore, [12] by lane, [16], [18] four per wave, [20], [21] their qscore */
         uint32_t *misses = set_counter(S, 1);
         const uint32_t cnt[NCLS] = {(uint32_t)cls_list[0].size(), (uint32_t)cls_list[1].size(), (uint32_t)cls_list[2].size(), (uint32_t)cls_list[3].size(),
-                                    (uint32_t)cls_list[4].size(), (uint32_t)cls_list[5].size(), (uint32_t)cls_list[6].size()};
+                                    (uint32_t)cls_list[4].size(), (uint32_t)cls_list[5].size(), (uint32_t)cls_list[6].size(), (uint32_t)cls_list[7].size()};
         /* The widest bands (8+ words per lane: a few dozen reads, each a chain of ~100 k column steps of ~2 us) go first, on
            the set's wide stream when it has one; then the 4-, 2- and 1-word classes on the set's own stream, each scored
            (k_fin_qscore) as soon as its class is aligned. */
@@ -772,13 +784,18 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(grid[3]), dim3(64), 0, S.wide, dev, rs, d_lists + list_at[3], cnt[3],
                                reinterpret_cast<unsigned long long *>(cq + 6), d_slabs + slab_at[3], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
         }
+        if (cnt[7]) {                                 /* ... and its giants behind them, on their few slabs (queue head: cq[22..23]) */
+            KTIMED(BRX_KERN_FIN_ALIGN16, S.wide);
+            hipLaunchKernelGGL((k_fin_align<16, 8, 0xFFFF>), dim3(grid[7]), dim3(64), 0, S.wide, dev, rs, d_lists + list_at[7], cnt[7],
+                               reinterpret_cast<unsigned long long *>(cq + 22), d_slabs + slab_at[7], misses, phase, Fbuf, c->scratch, c->scratch, slab_base, clk);
+        }
         if (fork) {
             /* ... and is scored there as well.  (Until round 5 the set's own stream waited for the wide stream at this point and
                scored the class itself: for the head set that stream is `side`, the wait was enqueued when the head's final stage
                was launched, and everything the BULK set later put on `side` -- its two-word class -- sat behind the head's
                widest alignments: 391 ms into a 454 ms batch alone on the chip, profiles/r05_batch_timeline.json.  The host waits
                for both streams in finish_final instead.) */
-            if (cnt[3]) {
+            if (cnt[3] || cnt[7]) {
                 KTIMED(BRX_KERN_FIN_QSCORE, S.wide);
                 hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.wide, dev, rs, order, b, e,
                                    cq + 9, phase, 5, 0xFFFF, c->scratch, c->scratch, col_base, clk);
@@ -843,12 +860,12 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join3[0], 0));
             HIPCHK(c, hipStreamWaitEvent(S.st, c->ev_join3[1], 0));
         }
-        if (cnt[3] && !fork) {
+        if ((cnt[3] || cnt[7]) && !fork) {
             KTIMED(BRX_KERN_FIN_QSCORE, S.st);
             hipLaunchKernelGGL(k_fin_qscore, dim3(std::min<uint32_t>(waves, (uint32_t)c->n_cu * 8u)), dim3(64), 0, S.st, dev, rs, order, b, e,
                                cq + 9, phase, 5, 0xFFFF, c->scratch, c->scratch, col_base, clk);
         }
-        if (phase == 0) c->final_launches += grid[0] + grid[1] + grid[2] + grid[3] + grid[4] + grid[5] + grid[6];     /* slabs = waves of the set's align kernels */
+        if (phase == 0) c->final_launches += grid[0] + grid[1] + grid[2] + grid[3] + grid[4] + grid[5] + grid[6] + grid[7];     /* slabs = waves of the set's align kernels */
         return BRX_OK;
     };
 

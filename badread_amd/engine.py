@@ -319,7 +319,11 @@ def arena_estimate(n_reads, mean_length, error_rate=None):
     low = 5.5 * bases + 600.0 * n_reads
     rings = 2.5 * bases + 2600.0 * n_reads
     mutate_only = rings + min(n_reads, 4096) * 0.62e6 + min(n_reads / 64.0, 1024.0) * 6.6e6
-    final = 4.0 * bases + min(per_base * bases, 20e9)
+    # the cap on the slabs: 20 GB holds full grids at the 5 % of the defaults; at 10 % a batch's widest reads (the memory-resident
+    # path keeps every cell of a 300 kb chimera at 75 %) are GBs each and a head set squeezed into 4 GB ran its widest class on ONE
+    # wave -- a rough batch took 150 s instead of 50 (tests/test_gpu_fullsize.py, round 6): the cap follows the error rate up to 32 GB
+    slab_cap = 20e9 * (1.0 if error_rate is None else min(1.6, max(1.0, float(error_rate) / 0.05)))
+    final = 4.0 * bases + min(per_base * bases, slab_cap)
     return int(low + max(mutate_only + 0.35 * final, final) + (1 << 30))
 
 

@@ -224,14 +224,16 @@ def test_driver_on_the_emulated_device_equals_the_oracle_driver(monkeypatch):
     assert a.getvalue() == b.getvalue() and a.getvalue().count(b'\n') >= 4 * 20
 
 
-@pytest.mark.parametrize('route', ['default'])      # the overflowing reads leave the passes at their first window: the pass route does not matter (80 s each)
+@pytest.mark.parametrize('route', ['default', 'giants'])      # the overflowing reads leave the passes at their first window: the pass route does not matter (80 s each)
 def test_window_overflow_goes_through_the_whole_read_kernel(tmp_path, route, monkeypatch):
-    for k, v in MUTATE_ROUTES[route].items():
+    """... 'giants': the same two reads on a build whose widest band class calls every store above 512 bytes a giant -- the class of
+    its own (own queue, own few slabs) that keeps a batch's few GB-sized stores from taking the slabs of the thousands beside them."""
+    for k, v in MUTATE_ROUTES['default' if route == 'giants' else route].items():
         monkeypatch.setenv(k, str(v))
-    _window_overflow(tmp_path)
+    _window_overflow(tmp_path, defines=('-DBRX_GIANT_UNITS=64ull',) if route == 'giants' else ())
 
 
-def _window_overflow(tmp_path):
+def _window_overflow(tmp_path, defines=()):
     """A synthetic error model whose alternatives insert 60 bases: the joined 1000-base windows outgrow their pass slots
     (BRX_WIN_TMAX), so those reads are handed to the whole-read kernel k_mutate with inline alignments -- a route no
     packaged model reaches.  Mutated reads of 17x the fragment length also push the final alignment into the widest
@@ -248,7 +250,8 @@ def _window_overflow(tmp_path):
     path.write_text(''.join(lines))
     tables = ErrorModel(str(path), io.StringIO(), aligner=pyoracle.oracle_align_batch, use_cache=False).tables()
     pref, _ = H.small_reference()
-    eng, orc = H.configure(emu_engine(), pref), H.configure(H.oracle_engine(), pref)
+    import emu_engine as EE
+    eng, orc = H.configure(EE.EmuEngine(1 << 29, defines=defines) if defines else emu_engine(), pref), H.configure(H.oracle_engine(), pref)
     for e in (eng, orc):
         e.set_error_model(tables)
         e.set_qscore_model(H.qscore_tables('ideal'))

@@ -251,7 +251,7 @@ ROUGH_CHECKED = 32768          # reads of the shipped batch the oracle re-comput
 
 def test_off_default_parameters_full_batch_equals_the_oracle(tmp_path):
     """full-size parity away from the default parameters.  A SHIPPED device batch (65536 reads, the
-    bench's arena, default environment) of configs[3]'s reference with --identity 85,95,5 --chimeras 25 --glitches 1000,100,100
+    CLI's arena for the job, default environment) of configs[3]'s reference with --identity 85,95,5 --chimeras 25 --glitches 1000,100,100
     (bench.py workload 'rough'): three times the edits per base of the defaults, so most bases leave the one-word band class -- the
     2- and 4-word classes and k_fin_align<16,8,...> carry what is a few percent at the defaults -- and a quarter of the reads are
     chimeras.  The batch runs WITHOUT a retry (round 5's retry was the OUTPUT buffer, not the arena: chimeras make reads a third
@@ -263,13 +263,16 @@ def test_off_default_parameters_full_batch_equals_the_oracle(tmp_path):
     from badread_amd.engine import HipEngine, RS_EMPTY
     ref_dir = bench.default_ref_dir()
     wl = bench.build_workload(io.StringIO(), 'rough', ref_dir)
-    eng = bench.configure(HipEngine(0, scratch_bytes=int(bench.SCRATCH_GB_DEFAULT * (1 << 30))), wl)
+    # the arena the CLI gives this job (HipEngine.presize from its identity law and chimera rate: 42 GiB; the bench's 32 GiB hold the
+    # batch too, without a retry, but squeeze the head set's widest class onto one wave: 150 s for the batch instead of 50)
+    eng = bench.configure(HipEngine(0, scratch_bytes=1 << 30), wl)
+    eng.presize(SHIPPED_BATCH, 15000.0, 0.10)
     out, st = eng.simulate_batch(SEED, 0, SHIPPED_BATCH)
     out, st = out.copy(), st.copy()
     cyc = eng.read_cycles(SHIPPED_BATCH)
     retries = getattr(eng, 'retries', 0)
     eng.close()
-    assert retries == 0, 'a shipped batch of this workload must fit the shipped arena and the output buffer sized from its parameters'
+    assert retries == 0, 'a shipped batch of this workload must fit the arena and the output buffer sized from its parameters'
     assert (st['status'] & ~np.uint32(RS_EMPTY) == 0).all()
     words = (cyc[:, 7] & 0xFFFF).astype(np.int64)
     bases = st['frag_len'].astype(np.float64)
@@ -287,7 +290,7 @@ def test_the_cli_sizes_arena_and_output_for_the_job(wlname, error_rate, tmp_path
     """what a USER gets is the CLI's sizing -- HipEngine.presize from the job's identity law and the output buffer
     from its chimera rate -- not the bench's 40 GB.  A shipped batch through an engine sized that way: NO retry (an arena that is
     short is grown and the batch repeated: correct, but six engines growing 20 GB arenas once filled the device -- round 6, the
-    configs[4] job after the survivor rings were added), and the same bytes as the engine with the bench's arena gives."""
+    configs[4] job after the survivor rings were added), and the same bytes as the engine with the bench's arena (48 GiB for the rough job) gives."""
     import bench
     from badread_amd.engine import HipEngine
     ref_dir = bench.default_ref_dir()
@@ -299,7 +302,7 @@ def test_the_cli_sizes_arena_and_output_for_the_job(wlname, error_rate, tmp_path
     digest = (len(out), int(st['seq_len'].sum()), int(st['n_match'].astype(np.int64).sum()))
     assert getattr(eng, 'retries', 0) == 0
     eng.close()
-    big = bench.configure(HipEngine(0, scratch_bytes=int(bench.SCRATCH_GB_DEFAULT * (1 << 30))), wl)
+    big = bench.configure(HipEngine(0, scratch_bytes=int((48.0 if wlname == 'rough' else bench.SCRATCH_GB_DEFAULT) * (1 << 30))), wl)
     out2, st2 = big.simulate_batch(SEED, 0, SHIPPED_BATCH)
     assert digest == (len(out2), int(st2['seq_len'].sum()), int(st2['n_match'].astype(np.int64).sum()))
     assert bytes(out[:1 << 24]) == bytes(out2[:1 << 24])

@@ -1,8 +1,14 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-run() { tag=$1; shift; python bench.py --cpu-seconds 0 "$@" > gpurun_out/ab_$tag.json 2>> gpurun_out/ab.err; python -c "
-import json; d=json.load(open('gpurun_out/ab_$tag.json')); print('$tag', round(d['value']/1e9,3), d['scratch_or_output_retries'], round(d['ms_per_step']), {k: round(v['ms']) for k,v in d['kernels_per_device_batch'].items() if v['ms']>150})"; }
-run s6 --streams 6 --reads-per-step 393216 --scratch-gb 30
-run s7 --streams 7 --reads-per-step 458752 --scratch-gb 30
-run s8 --streams 8 --reads-per-step 524288 --scratch-gb 30
-run s9 --streams 9 --reads-per-step 589824 --scratch-gb 28
-run s6b --streams 6 --reads-per-step 393216 --scratch-gb 30
+python bench.py --workload rough --steps 1 --warmup 0 --streams 1 --reads-per-step 65536 --scratch-gb 44 --cpu-seconds 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1])
+print('rough one batch', round(d['value']/1e9,3), round(d['ms_per_step']), d['stage_ms_per_device_batch'])
+for k,v in sorted(d['kernels_per_device_batch'].items(), key=lambda kv:-kv[1]['ms'])[:5]: print('  ',k, round(v['ms'],1), v['launches'], round(v['mbases'],1))
+"
+python bench.py --cpu-seconds 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1]); print('human', round(d['value']/1e9,3), d['scratch_or_output_retries'])"
+python bench.py --workload rough --scratch-gb 42 --steps 2 --warmup 1 --cpu-seconds 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1]); print('rough six in flight', round(d['value']/1e9,3), d['scratch_or_output_retries'], round(d['ms_per_step']))"
+timeout 1200 python -m pytest tests/test_gpu_fullsize.py -x -q --durations=4 -k "off_default or cli_sizes or pinned" 2>&1 | tail -9
