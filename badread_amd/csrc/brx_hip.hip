@@ -719,11 +719,40 @@ static int run_pipeline_impl(brx_ctx *c, uint64_t seed, uint64_t first_read, uin
             const size_t later = c->scratch_bytes > at ? c->scratch_bytes - at : 0;
             left = std::max<size_t>(std::min<size_t>(left, later > reserve ? later - reserve : 0), left / 4);
         } else if (S.tb_cap > left) { at = S.tb_at + S.col_bytes; left = S.tb_cap - S.col_bytes; }      /* the set's own slab area is free again */
-        for (int guard = 0; need() > left && guard < 96; ++guard) {
-            int big = -1;
-            for (int k = 0; k < NCLS; ++k) if (grid[k] > 1 && (big < 0 || slab_units(k) > slab_units(big))) big = k;
-            if (big < 0) break;
-            grid[big] = (grid[big] + 1) / 2;
+        /* A set that does not fit halves the waves of the class where that frees the most room for the least time.  A class's time is its
+           work (the sum of its stores: length x band) over its waves, and halving the waves adds that much; what it frees is the slabs of
+           the upper half of its queue positions.  (Until round 6 the FATTEST class was halved: on a batch of --identity 85,95,5 the
+           four-word class -- 14 717 reads -- went down to 32 slabs while 21 488 short reads kept 2048 that held 0.2 MB each.) */
+        double work[NCLS];
+        uint32_t grid_full[NCLS];
+        for (int k = 0; k < NCLS; ++k) { double w = 0; for (uint64_t u_ : cls_units[k]) w += (double)u_; work[k] = w; grid_full[k] = grid[k]; }
+        for (int guard = 0; need() > left && guard < 128; ++guard) {
+            int pick = -1; double best = -1.0;
+            for (int k = 0; k < NCLS; ++k) {
+                if (grid[k] <= 1) continue;
+                const uint32_t half = (grid[k] + 1) / 2;
+                uint64_t freed = 0;
+                for (uint32_t w = half; w < grid[k]; ++w) freed += sufmax[k][w];
+                const double score = (double)freed / (work[k] / (double)grid[k] + 1.0);
+                if (score > best) { best = score; pick = k; }
+            }
+            if (pick < 0) break;
+            grid[pick] = (grid[pick] + 1) / 2;
+        }
+        /* ... and halving is coarse: give back what fits, to the class whose waves carry the most work each */
+        for (int guard = 0; guard < 64; ++guard) {
+            int pick = -1; double best = -1.0;
+            for (int k = 0; k < NCLS; ++k) {
+                if (grid[k] >= grid_full[k]) continue;
+                const uint32_t was = grid[k];
+                grid[k] = std::min<uint32_t>(grid_full[k], was * 2u);
+                const bool fits = need() <= left;
+                grid[k] = was;
+                const double load = work[k] / (double)was;
+                if (fits && load > best) { best = load; pick = k; }
+            }
+            if (pick < 0) break;
+            grid[pick] = std::min<uint32_t>(grid_full[pick], grid[pick] * 2u);
         }
         /* one wave per class and still more than the set's share: the share is a courtesy to the sets to come (they halve their own
            grids), the room is what counts -- a head set of --identity 85,95,5 --chimeras 25 holds reads whose store alone is GBs (a
