@@ -38,9 +38,19 @@ PASS_ROUTES = [{'BRX_TAIL_READS': t, 'BRX_HEAD_READS': h} for t in ('0', '2', '5
 PASS_DEFINES = [(), ('-DBRX_SV_STOCK=3u', '-DBRX_SV_CAP=128u', '-DBRX_POST_U=1'), ('-DBRX_SV_STOCK=1u', '-DBRX_SV_CAP=256u', '-DBRX_POST_U=3')]
 
 
+# round 6, last day: the arena (mutate-only buffers in a releasable top region, the bulk set's slabs over them), sets short of room
+# (halving by freed room per added time, then giving back), giant stores of the widest class in a class of their own: small arenas of
+# random size (a short arena is grown and the batch repeated: that path too), two sets or one, builds whose giants start at 32 KB / 2 MB
+ARENA_ROUTES = [{'BRX_LANES_MIN_READS': '0'}, {'BRX_TAIL_READS': '0', 'BRX_HEAD_READS': '0', 'BRX_LANES_MIN_READS': '0'},
+                {'BRX_TAIL_READS': '4', 'BRX_HEAD_READS': '5', 'BRX_TB_WINDOW': '0'}, {'BRX_TAIL_READS': '0', 'BRX_HEAD_READS': '6', 'BRX_WAVES_PER_CU': '4'},
+                {'BRX_TAIL_READS': '0', 'BRX_HEAD_READS': '0', 'BRX_FIN_HEAD_READS': '7', 'BRX_FIN_LANES': '0', 'BRX_QUAD_MIN_READS': '0'},
+                {'BRX_TAIL_READS': '3', 'BRX_HEAD_READS': '4', 'BRX_MUTATE_PASSES': '1', 'BRX_TB_WINDOW': '0', 'BRX_FIN_LANES': '0'}]
+ARENA_DEFINES = [(), ('-DBRX_GIANT_UNITS=4096ull',), ('-DBRX_GIANT_UNITS=262144ull',)]
+
+
 def draw_case(rng, focus=None):
     mode = int(rng.integers(0, 3))
-    p = dict(frag_mean=float(rng.choice([60, 300, 900, 2500, 4500] if focus != 'quad' else [900, 2500, 4500, 7000])), frag_stdev=float(rng.choice([0, 50, 800, 3000])),
+    p = dict(frag_mean=float(rng.choice([60, 300, 900, 2500, 4500] if focus not in ('quad', 'arena') else [900, 2500, 4500, 7000])), frag_stdev=float(rng.choice([0, 50, 800, 3000])),
              identity_mode=mode, start_rate=float(rng.choice([0, 0.5, 0.9, 1.0])), start_amount=float(rng.choice([0.1, 0.6, 1.0])),
              end_rate=float(rng.choice([0, 0.5, 1.0])), end_amount=float(rng.choice([0.2, 0.9, 1.0])),
              start_adapter=str(rng.choice(['', 'AATGTACTTCGTTCAGTTACGTATTGCT', 'ACGT'])),
@@ -60,7 +70,11 @@ def draw_case(rng, focus=None):
     return dict(params=p, em=str(rng.choice(MODELS)), qm=str(rng.choice(QMODELS)), seed=int(rng.integers(0, 2 ** 40)),
                 first=int(rng.integers(0, 10 ** 6)), n=int(rng.choice([1, 7, 16, 30])), with_n=bool(rng.integers(0, 2)),
                 route=dict((QUAD_ROUTES if focus == 'quad' else PASS_ROUTES if focus == 'pass' else ROUTES)[int(rng.integers(0, len(QUAD_ROUTES if focus == 'quad' else PASS_ROUTES if focus == 'pass' else ROUTES)))]),
-                defines=list(PASS_DEFINES[int(rng.integers(0, len(PASS_DEFINES)))]) if focus == 'pass' else [])
+                defines=list(PASS_DEFINES[int(rng.integers(0, len(PASS_DEFINES)))]) if focus == 'pass' else []) if focus != 'arena' else \
+        dict(params=p, em=str(rng.choice(MODELS)), qm=str(rng.choice(QMODELS)), seed=int(rng.integers(0, 2 ** 40)),
+             first=int(rng.integers(0, 10 ** 6)), n=int(rng.choice([7, 16, 30])), with_n=bool(rng.integers(0, 2)),
+             route=dict(ARENA_ROUTES[int(rng.integers(0, len(ARENA_ROUTES)))]), defines=list(ARENA_DEFINES[int(rng.integers(0, len(ARENA_DEFINES)))]),
+             scratch_mb=int(rng.choice([5, 7, 9, 12, 16, 24, 48])))
 
 
 def run_case(case):
@@ -71,7 +85,7 @@ def run_case(case):
     os.environ.update(case['route'])
     pref, _ = H.small_reference(with_n=case['with_n'])
     p = SimParams(**case['params'])
-    emu = H.configure(EE.EmuEngine(1 << 29, tuple(case.get('defines', ()))), pref, case['em'], case['qm'], p)
+    emu = H.configure(EE.EmuEngine(int(case.get('scratch_mb', 512)) << 20, tuple(case.get('defines', ()))), pref, case['em'], case['qm'], p)
     orc = H.configure(H.oracle_engine(), pref, case['em'], case['qm'], p)
     out_h, st_h = emu.simulate_batch(case['seed'], case['first'], case['n'], allow_nofrag=True)
     out_o, st_o = orc.simulate_batch(case['seed'], case['first'], case['n'], allow_nofrag=True)
@@ -85,7 +99,7 @@ def run_case(case):
 def main():
     seconds, wid = float(sys.argv[1]), int(sys.argv[2])
     logdir = sys.argv[3] if len(sys.argv) > 3 else '/tmp/brx_fuzz'
-    focus = sys.argv[4] if len(sys.argv) > 4 else None          # 'quad': only the k_fin_quad routes, longer reads; 'pass': the bulk passes
+    focus = sys.argv[4] if len(sys.argv) > 4 else None          # 'quad': only the k_fin_quad routes, longer reads; 'pass': the bulk passes; 'arena': small arenas, giants' class
     os.makedirs(logdir, exist_ok=True)
     rng = np.random.default_rng(1000 + wid)
     t0, cases, bases, fails = time.time(), 0, 0, 0
