@@ -631,7 +631,7 @@ def main():
         'config': {'workload': WORKLOADS[args.workload]['text'] + ('' if args.ref_scale == 1.0 else f' [REFERENCE SCALED x{args.ref_scale}: dry run]'),
                    'reference_bases': int(pref.n_bases), 'reference_contigs': len(pref.names), 'reference_non_acgt_runs': int(len(pref.exceptions)),
                    'reads_per_step_per_gpu': R * C, 'bases_per_step_per_gpu': bases_per_step_rank0,
-                   'device_batches_per_step': C, 'reads_per_device_batch': R,
+                   'device_batches_per_step': C, 'reads_per_device_batch': R, 'scratch_arena_gib_per_device_batch': args.scratch_gb,
                    'parallelism': f'reads sharded by index over {world} GPU(s), reference replicated per GPU, no collectives on the data path'},
         'reference_load': ref_timing,
         'reads_flagged_band_segs_qmiss': bad,
